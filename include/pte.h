@@ -1,0 +1,152 @@
+/* pte.h -- C ABI of the MI355X-native parallel-tempering engine ("pte").
+ *
+ * Drop-in boundary for the explore-then-swap hot path of Pigeons.jl v0.4.10.
+ * The reference has NO C ABI on this path (it is Julia multiple dispatch); the
+ * entry points below are what a Julia `ccall` glue (INTEGRATION.md,
+ * pigeons.jl_amd/julia/PigeonsMI355X.jl) binds at the three dispatch hooks that
+ * bracket the hot path, plus construction / adaptation / checkpoint hooks:
+ *
+ *   create_replicas(inputs, shared, source)      src/replicas/replicas.jl:65-98   -> pte_create
+ *   explore!(pt, explorer, ::Val)                src/pt/pigeons.jl:82-132         -> pte_explore
+ *   swap!(pair_swapper, replicas, swap_graph)    src/swap/swap.jl:6-39,106-126    -> pte_swap
+ *   `while next_scan!(pt)` loop                  src/pt/pigeons.jl:49-52          -> pte_run_scans (fused)
+ *   reduce_recorders!(pt, replicas)              src/recorders/recorders.jl:88-120 -> pte_reduce + pte_get_*
+ *   adapt_tempering / discretize                 src/tempering/NonReversiblePT.jl:46-66 -> pte_set_schedule
+ *   adapt_explorer(::AutoMALA, ...)              src/explorers/AutoMALA.jl:70-79   -> pte_set_explorer_adaptation
+ *   checkpoint (Replica fields)                  src/pt/checkpoint.jl:110-145     -> pte_get_state / pte_set_state
+ *
+ * Conventions (precedent: the reference's only FFI, ext/PigeonsBridgeStanExt/interface.jl:118-183):
+ *   - every call returns int: 0 = ok, != 0 = error; message via pte_last_error().
+ *   - plain pointers and sizes; caller allocates all output arrays (host memory).
+ *   - the engine owns all device memory; handles are freed by pte_destroy.
+ *   - all calls on one handle come from one host thread; calls are synchronous at
+ *     return (results visible to the host), asynchronous internally (HIP streams).
+ *   - indices are 0-based: chain 0 = reference (beta = 0), chain N-1 = target;
+ *     replica r = reference `replica_index` r+1.
+ *   - floating point is IEEE binary64 throughout ("f64").
+ *   - there is NO CPU fallback: on a machine without a HIP device pte_create fails.
+ */
+#ifndef PTE_H
+#define PTE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTE_ABI_VERSION 1
+
+/* Device log-potential families (closed set; arbitrary Julia closures cannot run
+ * on the GPU -- unsupported combinations make pte_create fail, and the caller
+ * keeps the reference CPU path). */
+enum {
+    PTE_TARGET_MVN_SCALED_PRECISION = 0, /* toy_mvn_target: src/paths/ScaledPrecisionNormalPath.jl:5-48   */
+    PTE_TARGET_TEST_SWAPPER         = 1, /* TestSwapper:    src/swap/pair_swapper.jl:100-149               */
+    PTE_TARGET_FUNNEL               = 2  /* InterpolatingPath(normal ref, Neal's funnel)                   */
+};
+enum {
+    PTE_EXPLORER_NONE     = 0,           /* `nothing` (TestSwapper)                                        */
+    PTE_EXPLORER_TOY      = 1,           /* ToyExplorer:  src/explorers/ToyExplorer.jl:5-14                */
+    PTE_EXPLORER_SLICE    = 2,           /* SliceSampler: src/explorers/SliceSampler.jl:8-237              */
+    PTE_EXPLORER_AUTOMALA = 3            /* AutoMALA:     src/explorers/AutoMALA.jl:29-294                 */
+};
+enum {                                   /* Inputs.record (src/pt/Inputs.jl:57-62)                         */
+    PTE_RECORD_ROUND_TRIP    = 1u << 0,  /* round_trip     src/recorders/RoundTripRecorder.jl              */
+    PTE_RECORD_INDEX_PROCESS = 1u << 1,  /* index_process  src/recorders/recorder.jl:81                    */
+    PTE_RECORD_ONLINE        = 1u << 2   /* online / _transformed_online (target chain mean, variance)     */
+};
+
+/* Mirrors the fields of `Inputs` (src/pt/Inputs.jl:9-102) and of the explorer
+ * structs that the hot path reads. */
+typedef struct pte_config {
+    uint32_t struct_size;        /* = sizeof(pte_config); checked by pte_create                            */
+    uint32_t abi_version;        /* = PTE_ABI_VERSION                                                      */
+    int32_t  device;             /* HIP device ordinal                                                     */
+    int32_t  target;             /* PTE_TARGET_*                                                           */
+    int32_t  explorer;           /* PTE_EXPLORER_*                                                         */
+    uint32_t record_flags;       /* PTE_RECORD_*                                                           */
+    int64_t  n_chains;           /* Inputs.n_chains (global N)                                             */
+    int64_t  dim;                /* state dimension d                                                      */
+    uint64_t seed;               /* Inputs.seed                                                            */
+    int64_t  max_scans_per_round;/* capacity of the index-process buffer, 2^n_rounds                       */
+    double   target_params[4];   /* MVN: {precision0, precision1}; TestSwapper: {accept pr};
+                                    FUNNEL: {reference precision}                                          */
+    /* SliceSampler fields (SliceSampler.jl:8-20) */
+    double   slice_w;
+    int32_t  slice_p;
+    int32_t  slice_n_passes;
+    int32_t  slice_max_iter;
+    /* AutoMALA fields (AutoMALA.jl:29-68) */
+    int32_t  am_base_n_refresh;
+    double   am_exponent_n_refresh;
+    double   am_step_size;
+    double   am_p0, am_p1;       /* MixDiagonalPreconditioner(p0, p1), Preconditioner.jl:43-52             */
+    int32_t  am_preconditioner;  /* 0 identity, 1 diagonal, 2 mix-diagonal                                 */
+    /* chain sharding: this engine owns chains [rank*N/world, (rank+1)*N/world)                           */
+    int32_t  rank;
+    int32_t  world_size;
+    int32_t  reserved;
+} pte_config;
+
+typedef struct pte_engine pte_engine;
+
+/* Fill `cfg` with the reference defaults (Inputs.jl:14-20, SliceSampler.jl:8-20, AutoMALA.jl:29-68). */
+int pte_default_config(pte_config *cfg);
+
+/* create_replicas: split RNG streams, initial states, chain = replica index, equally spaced schedule. */
+int pte_create(const pte_config *cfg, pte_engine **out);
+int pte_destroy(pte_engine *h);
+const char *pte_last_error(const pte_engine *h);   /* h may be NULL: error of the last failed pte_create */
+
+/* Schedule.grids (src/schedules/Schedule.jl) -> log_potentials along the ladder (discretize). */
+int pte_set_schedule(pte_engine *h, const double *betas, int64_t n_chains);
+int pte_get_schedule(const pte_engine *h, double *betas);
+
+/* adapt_explorer(::AutoMALA): new step size and estimated_target_std_deviations (NULL = nothing). */
+int pte_set_explorer_adaptation(pte_engine *h, double step_size, const double *target_std, int64_t dim);
+
+/* One explore! over all local replicas for scan index `scan` (1-based within the round,
+ * src/pt/Iterators.jl:37-47; AutoMALA skips the MH step when scan == 1). */
+int pte_explore(pte_engine *h, int64_t scan);
+/* One communicate!: DEO graph parity = iseven(scan) (src/swap/DEO.jl:12). */
+int pte_swap(pte_engine *h, int64_t scan);
+/* The fused scan loop: for s = first_scan .. first_scan+n_scans-1: explore!(s); communicate!(s). */
+int pte_run_scans(pte_engine *h, int64_t first_scan, int64_t n_scans);
+
+/* reduce_recorders!: snapshot the round's accumulators to the host and reset them on the
+ * device (incl. the round-trip state machines, RoundTripRecorder.jl:30-34). */
+int pte_reduce(pte_engine *h);
+
+/* Reduced recorders of the last pte_reduce. Array lengths in brackets. */
+int pte_get_swap_acceptance(const pte_engine *h, double *mean /*N-1*/, int64_t *n /*N-1*/);
+int pte_get_log_sum_ratio(const pte_engine *h, double *up /*N-1*/, int64_t *up_n, double *dn /*N-1*/, int64_t *dn_n);
+int pte_get_round_trip(const pte_engine *h, int64_t *n_tempered_restarts, int64_t *n_round_trips);
+int pte_get_index_process(const pte_engine *h, int64_t *out /*N * n_scans, [replica][scan]*/, int64_t *n_scans);
+int pte_get_explorer_stats(const pte_engine *h, double *acceptance_mean /*N*/, int64_t *acceptance_n /*N*/,
+                           double *n_steps_sum /*N*/, int64_t *n_steps_n /*N*/);
+int pte_get_automala_stats(const pte_engine *h, double *factor_mean /*N*/, int64_t *factor_n /*N*/,
+                           double *reversibility_mean /*N*/, int64_t *reversibility_n /*N*/);
+int pte_get_online(const pte_engine *h, double *mean /*d*/, double *variance /*d*/, int64_t *n);
+
+/* Replica fields in replica order (src/replicas/Replica.jl:5-30): state [N*d], chain [N],
+ * rng [2N] = (seed, gamma) of each SplittableRandom.  NULL pointers are skipped. */
+int pte_get_state(const pte_engine *h, double *state, int64_t *chain, uint64_t *rng);
+int pte_set_state(pte_engine *h, const double *state, const int64_t *chain, const uint64_t *rng);
+
+/* Measurement hooks (bench.py): per-kernel HIP-event timing accumulated on the engine's stream
+ * over pte_run_scans calls since the last reset.  kernel: 0 = explore, 1 = swap. */
+int pte_timing_reset(pte_engine *h, int enable);
+int pte_timing_get(const pte_engine *h, int kernel, double *total_ms, int64_t *launches);
+
+/* RNG building blocks exposed for parity tests of the device samplers: fill `n` draws from the
+ * stream (seed, gamma) on the device, in the reference's sequential order.
+ * kind: 0 = rand (Float64 in [0,1)), 1 = randn, 2 = randexp.  Returns the advanced stream. */
+int pte_test_rng_fill(int32_t device, uint64_t *seed_gamma /*2, in-out*/, int32_t kind, int64_t n, double *out);
+/* sqr_norm of each row of x [rows][d] with the engine's fixed reduction tree. */
+int pte_test_sqr_norm(int32_t device, const double *x, int64_t rows, int64_t d, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTE_H */

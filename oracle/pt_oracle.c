@@ -1,0 +1,823 @@
+/* pt_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ * See pt_oracle.h for the scope and the "PARITY UNPINNED" statement.
+ *
+ * Every function cites the reference file:line (relative to /root/reference)
+ * whose behaviour it restates.  Build: see oracle/Makefile (-ffp-contract=off:
+ * Julia never contracts a*b+c).
+ */
+#define _GNU_SOURCE
+#include "pt_oracle.h"
+#include "zig_tables.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ========================================================================== */
+/* RNG                                                                        */
+/* ========================================================================== */
+
+/* SplittableRandoms.jl 0.1 == Java 8 SplittableRandom (SplitMix64).  Not under
+ * /root/reference; call sites src/replicas/replicas.jl:88, src/utils/misc.jl:28-30. */
+static inline uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+static inline uint64_t mix_gamma(uint64_t z) {
+    z = (z ^ (z >> 33)) * 0xff51afd7ed558ccdULL;
+    z = (z ^ (z >> 33)) * 0xc4ceb9fe1a85ec53ULL;
+    z = (z ^ (z >> 33)) | 1ULL;
+    int n = __builtin_popcountll(z ^ (z >> 1));
+    return (n < 24) ? (z ^ 0xaaaaaaaaaaaaaaaaULL) : z;
+}
+po_rng po_rng_new(uint64_t seed) {
+    po_rng r = { seed, 0x9e3779b97f4a7c15ULL };
+    return r;
+}
+uint64_t po_rng_next_u64(po_rng *r) {
+    r->seed += r->gamma;
+    return mix64(r->seed);
+}
+po_rng po_rng_split(po_rng *r) {
+    po_rng c;
+    c.seed = po_rng_next_u64(r);       /* nextLong()            */
+    r->seed += r->gamma;               /* nextSeed()            */
+    c.gamma = mix_gamma(r->seed);
+    return c;
+}
+
+/* Julia Random stdlib, generic AbstractRNG path: rand(rng) = CloseOpen12 - 1.0
+ * built from the low 52 bits of one UInt64 draw. Call sites e.g.
+ * src/swap/pair_swapper.jl:46, src/explorers/SliceSampler.jl:110,130,188. */
+#define MASK52 0x000fffffffffffffULL
+static inline double u52_to_unit(uint64_t u) {
+    union { uint64_t u; double d; } v;
+    v.u = (u & MASK52) | 0x3ff0000000000000ULL;
+    return v.d - 1.0;
+}
+double po_rand(po_rng *r) { return u52_to_unit(po_rng_next_u64(r)); }
+
+/* randn: Random/src/normal.jl `randn` + `randn_unlikely` (256-layer ziggurat). */
+double po_randn(po_rng *r) {
+    for (;;) {
+        uint64_t u = po_rng_next_u64(r) & MASK52;
+        int64_t rabs = (int64_t)(u >> 1);
+        int idx = (int)(rabs & 0xFF);
+        double x = (double)((u & 1) ? -rabs : rabs) * ZIG_WI[idx];
+        if ((uint64_t)rabs < ZIG_KI[idx]) return x;
+        if (idx == 0) {
+            for (;;) {
+                double xx = -ZIG_NOR_INV_R * log(po_rand(r));
+                double yy = -log(po_rand(r));
+                if (yy + yy > xx * xx)
+                    return ((rabs >> 8) & 1) ? (-ZIG_NOR_R - xx) : (ZIG_NOR_R + xx);
+            }
+        } else if ((ZIG_FI[idx - 1] - ZIG_FI[idx]) * po_rand(r) + ZIG_FI[idx] < exp(-0.5 * x * x)) {
+            return x;
+        }
+        /* else: return randn(rng) -> loop */
+    }
+}
+
+/* randexp: Random/src/normal.jl `randexp` + `randexp_unlikely`. */
+double po_randexp(po_rng *r) {
+    for (;;) {
+        uint64_t ri = po_rng_next_u64(r) & MASK52;
+        int idx = (int)(ri & 0xFF);
+        double x = (double)ri * ZIG_WE[idx];
+        if (ri < ZIG_KE[idx]) return x;
+        if (idx == 0) return ZIG_EXP_R - log(po_rand(r));
+        if ((ZIG_FE[idx - 1] - ZIG_FE[idx]) * po_rand(r) + ZIG_FE[idx] < exp(-x)) return x;
+    }
+}
+
+/* ========================================================================== */
+/* numerics                                                                   */
+/* ========================================================================== */
+
+static int64_t next_pow2(int64_t n) { int64_t p = 1; while (p < n) p <<= 1; return p; }
+
+/* sqr_norm(x) = sum(abs2, x)  (src/utils/misc.jl:10).  Julia's reduction order
+ * is compiler dependent (@simd); the build fixes ONE association, used by the
+ * oracle and by every HIP kernel: the balanced binary tree over the leaves
+ * x_i^2 in natural order, zero-padded to the next power of two
+ * (node[i] = node[2i] + node[2i+1]).  x + 0.0 is exact, so padding is inert. */
+double po_sqr_norm(const double *x, int64_t d) {
+    if (d <= 0) return 0.0;
+    int64_t P = next_pow2(d);
+    double stackbuf[1024];
+    double *a = (P / 2 <= 1024) ? stackbuf : (double *)malloc(sizeof(double) * (size_t)(P / 2));
+    if (P == 1) return x[0] * x[0];
+    for (int64_t i = 0; i < P / 2; i++) {
+        double l = (2 * i < d) ? x[2 * i] * x[2 * i] : 0.0;
+        double r = (2 * i + 1 < d) ? x[2 * i + 1] * x[2 * i + 1] : 0.0;
+        a[i] = l + r;
+    }
+    for (int64_t len = P / 2; len > 1; len /= 2)
+        for (int64_t i = 0; i < len / 2; i++) a[i] = a[2 * i] + a[2 * i + 1];
+    double s = a[0];
+    if (a != stackbuf) free(a);
+    return s;
+}
+
+/* LogExpFunctions.logaddexp (0.3.x): max + log1pexp(-|x-y|); used by
+ * src/recorders/LogSum.jl:11,16. */
+double po_logaddexp(double x, double y) {
+    double delta = (x == y) ? 0.0 : fabs(x - y);
+    double m = (x > y) ? x : y;
+    double nd = -delta;
+    double t = (nd <= -37.0) ? exp(nd) : log1p(exp(nd));
+    return m + t;
+}
+
+/* Interpolations.jl FritschCarlsonMonotonicInterpolation (monotonic.jl), used by
+ * src/tempering/adaptation.jl:61,85.  m: n tangents; c,dd: n-1 coefficients. */
+void po_fc_build(const double *x, const double *y, int64_t n, double *m, double *c, double *dd) {
+    double *D = (double *)malloc(sizeof(double) * (size_t)(n > 1 ? n - 1 : 1));
+    for (int64_t k = 0; k < n - 1; k++) {
+        double Dk = (y[k + 1] - y[k]) / (x[k + 1] - x[k]);
+        D[k] = Dk;
+        if (k == 0) m[k] = Dk;
+        else if (D[k - 1] * Dk <= 0.0) m[k] = 0.0;
+        else m[k] = (D[k - 1] + Dk) / 2.0;
+    }
+    m[n - 1] = D[n - 2];
+    for (int64_t k = 0; k < n - 1; k++) {
+        double Dk = D[k];
+        if (Dk == 0.0) { m[k] = 0.0; m[k + 1] = 0.0; continue; }
+        double al = m[k] / Dk, be = m[k + 1] / Dk;
+        double tau = 3.0 / sqrt(al * al + be * be);
+        if (tau < 1.0) { m[k] = tau * al * Dk; m[k + 1] = tau * be * Dk; }
+    }
+    for (int64_t k = 0; k < n - 1; k++) {
+        double xd = x[k + 1] - x[k];
+        c[k] = (3.0 * D[k] - 2.0 * m[k] - m[k + 1]) / xd;
+        dd[k] = (m[k] + m[k + 1] - 2.0 * D[k]) / (xd * xd);
+    }
+    free(D);
+}
+double po_fc_eval(const double *x, const double *y, const double *m, const double *c,
+                  const double *dd, int64_t n, double t) {
+    /* k = searchsortedfirst(knots, t); if k > 1: k -= 1  (1-based) */
+    int64_t k = 0;
+    while (k < n && x[k] < t) k++;      /* 0-based index of first knot >= t */
+    if (k > 0) k -= 1;
+    if (k > n - 2) k = n - 2;
+    double xd = t - x[k];
+    return y[k] + m[k] * xd + c[k] * xd * xd + dd[k] * xd * xd * xd;
+}
+
+/* ========================================================================== */
+/* OnlineStatsBase statistics (Mean / Sum / Variance / LogSum) and recorders   */
+/* ========================================================================== */
+typedef struct { double mu; int64_t n; } po_mean;
+typedef struct { double value; int64_t n; } po_logsum;
+typedef struct { double sum; int64_t n; } po_sum;
+typedef struct { double s2, mu; int64_t n; } po_var;
+
+static inline void mean_fit(po_mean *o, double x) {      /* mu += (1/n)(x - mu) */
+    o->n += 1;
+    o->mu = o->mu + (1.0 / (double)o->n) * (x - o->mu);
+}
+static inline void mean_merge(po_mean *a, const po_mean *b) {
+    if (b->n == 0) return;                /* GroupBy: key absent in b            */
+    if (a->n == 0) { *a = *b; return; }   /* GroupBy: key absent in a -> copy    */
+    a->n += b->n;
+    a->mu = a->mu + ((double)b->n / (double)a->n) * (b->mu - a->mu);
+}
+static inline void sum_fit(po_sum *o, double x) { o->n += 1; o->sum += x; }
+static inline void sum_merge(po_sum *a, const po_sum *b) {
+    if (b->n == 0) return;
+    if (a->n == 0) { *a = *b; return; }
+    a->n += b->n; a->sum += b->sum;
+}
+static inline void var_fit(po_var *o, double x) {
+    double mu = o->mu;
+    o->n += 1;
+    double g = 1.0 / (double)o->n;
+    o->mu = o->mu + g * (x - o->mu);
+    o->s2 = o->s2 + g * ((x - o->mu) * (x - mu) - o->s2);
+}
+static inline void var_merge(po_var *a, const po_var *b) {
+    if (b->n == 0) return;
+    if (a->n == 0) { *a = *b; return; }
+    a->n += b->n;
+    double g = (double)b->n / (double)a->n;
+    double delta = b->mu - a->mu;
+    a->s2 = (a->s2 + g * (b->s2 - a->s2)) + delta * delta * g * (1.0 - g);
+    a->mu = a->mu + g * (b->mu - a->mu);
+}
+static inline double var_value(const po_var *o) {
+    return o->n > 1 ? o->s2 * ((double)o->n / (double)(o->n - 1)) : 1.0;
+}
+/* src/recorders/LogSum.jl:1-24 */
+static inline void logsum_fit(po_logsum *o, double y) { o->value = po_logaddexp(o->value, y); o->n += 1; }
+static inline void logsum_merge(po_logsum *a, const po_logsum *b) {
+    if (b->n == 0) return;
+    if (a->n == 0) { *a = *b; return; }
+    a->value = po_logaddexp(a->value, b->value);
+    a->n += b->n;
+}
+
+/* src/recorders/RoundTripRecorder.jl:4-54 */
+typedef struct { int64_t n_tempered_restarts, n_round_trips, state; } po_round_trip;
+static inline void round_trip_record(po_round_trip *r, int is_ref, int is_target) {
+    if (r->state == 0 && is_ref) r->state = 1;
+    else if (r->state == 1 && is_target) { r->state = 2; r->n_tempered_restarts += 1; }
+    else if (r->state == 2 && is_ref) { r->state = 1; r->n_round_trips += 1; }
+}
+
+/* One replica's `recorders` NamedTuple (src/recorders/recorders.jl:37-70), as
+ * dense arrays keyed by chain / pair; a key is "absent" iff its n == 0. */
+typedef struct {
+    po_mean   *swap_pr;     /* [N-1] key (c,c+1)   src/recorders/recorder.jl:60   */
+    po_logsum *lsr_up;      /* [N-1] key (c,c+1)   recorder.jl:87                 */
+    po_logsum *lsr_dn;      /* [N-1] key (c+1,c)                                  */
+    po_mean   *expl_acc;    /* [N]   explorer_acceptance_pr  recorder.jl:67       */
+    po_sum    *expl_steps;  /* [N]   explorer_n_steps        recorder.jl:74       */
+    po_mean   *am_factors;  /* [N]   src/explorers/AutoMALA.jl:277                */
+    po_mean   *rev_rate;    /* [N]   AutoMALA.jl:294                              */
+    po_round_trip rt;
+    int64_t   *ip; int64_t ip_len, ip_cap;   /* index_process[replica_index]      */
+    po_mean   *on_mean;     /* [d] _transformed_online / online, target chain     */
+    po_var    *on_var;      /* [d]                                                */
+} po_recorders;
+
+static void rec_alloc(po_recorders *r, int64_t N, int64_t d) {
+    memset(r, 0, sizeof(*r));
+    int64_t np = N > 1 ? N - 1 : 1;
+    r->swap_pr = (po_mean *)calloc((size_t)np, sizeof(po_mean));
+    r->lsr_up = (po_logsum *)calloc((size_t)np, sizeof(po_logsum));
+    r->lsr_dn = (po_logsum *)calloc((size_t)np, sizeof(po_logsum));
+    r->expl_acc = (po_mean *)calloc((size_t)N, sizeof(po_mean));
+    r->expl_steps = (po_sum *)calloc((size_t)N, sizeof(po_sum));
+    r->am_factors = (po_mean *)calloc((size_t)N, sizeof(po_mean));
+    r->rev_rate = (po_mean *)calloc((size_t)N, sizeof(po_mean));
+    r->on_mean = (po_mean *)calloc((size_t)(d > 0 ? d : 1), sizeof(po_mean));
+    r->on_var = (po_var *)calloc((size_t)(d > 0 ? d : 1), sizeof(po_var));
+}
+static void rec_empty(po_recorders *r, int64_t N, int64_t d) {
+    int64_t np = N > 1 ? N - 1 : 1;
+    memset(r->swap_pr, 0, sizeof(po_mean) * (size_t)np);
+    for (int64_t i = 0; i < np; i++) {
+        r->lsr_up[i].value = -INFINITY; r->lsr_up[i].n = 0;
+        r->lsr_dn[i].value = -INFINITY; r->lsr_dn[i].n = 0;
+    }
+    memset(r->expl_acc, 0, sizeof(po_mean) * (size_t)N);
+    memset(r->expl_steps, 0, sizeof(po_sum) * (size_t)N);
+    memset(r->am_factors, 0, sizeof(po_mean) * (size_t)N);
+    memset(r->rev_rate, 0, sizeof(po_mean) * (size_t)N);
+    memset(&r->rt, 0, sizeof(r->rt));
+    r->ip_len = 0;
+    memset(r->on_mean, 0, sizeof(po_mean) * (size_t)(d > 0 ? d : 1));
+    memset(r->on_var, 0, sizeof(po_var) * (size_t)(d > 0 ? d : 1));
+}
+static void rec_free(po_recorders *r) {
+    free(r->swap_pr); free(r->lsr_up); free(r->lsr_dn); free(r->expl_acc); free(r->expl_steps);
+    free(r->am_factors); free(r->rev_rate); free(r->ip); free(r->on_mean); free(r->on_var);
+}
+/* merge_recorders (src/recorders/recorders.jl:122-130): a <- merge(a, b).
+ * index_process dicts have disjoint keys (one per replica) and are collected by
+ * the caller; the merged RoundTripRecorder has state 0 (RoundTripRecorder.jl:36-41). */
+static void rec_merge(po_recorders *a, const po_recorders *b, int64_t N, int64_t d) {
+    for (int64_t i = 0; i + 1 < N; i++) {
+        mean_merge(&a->swap_pr[i], &b->swap_pr[i]);
+        logsum_merge(&a->lsr_up[i], &b->lsr_up[i]);
+        logsum_merge(&a->lsr_dn[i], &b->lsr_dn[i]);
+    }
+    for (int64_t i = 0; i < N; i++) {
+        mean_merge(&a->expl_acc[i], &b->expl_acc[i]);
+        sum_merge(&a->expl_steps[i], &b->expl_steps[i]);
+        mean_merge(&a->am_factors[i], &b->am_factors[i]);
+        mean_merge(&a->rev_rate[i], &b->rev_rate[i]);
+    }
+    a->rt.n_tempered_restarts += b->rt.n_tempered_restarts;
+    a->rt.n_round_trips += b->rt.n_round_trips;
+    a->rt.state = 0;
+    for (int64_t i = 0; i < d; i++) {
+        mean_merge(&a->on_mean[i], &b->on_mean[i]);
+        var_merge(&a->on_var[i], &b->on_var[i]);
+    }
+}
+
+/* ========================================================================== */
+/* PT structures                                                              */
+/* ========================================================================== */
+/* src/replicas/Replica.jl:5-30 */
+typedef struct {
+    double  *state;
+    int64_t  chain;          /* 0-based */
+    po_rng   rng;
+    po_recorders rec;
+    int64_t  replica_index;  /* 0-based */
+    /* AutoMALA scratch (src/explorers/Augmentation.jl buffers) */
+    double  *buf;
+} po_replica;
+
+struct po_pt {
+    po_config cfg;
+    int64_t N, d;
+    po_replica *replicas;        /* by replica_index                              */
+    int64_t *replica_of_chain;   /* the sorted Vector{Replica} view (swap.jl:7)   */
+    double  *betas;              /* Schedule.grids                                */
+    int64_t round, scan;         /* Iterators (src/pt/Iterators.jl:9-25)          */
+    /* explorer adaptation state (AutoMALA) */
+    double   step_size;
+    double  *target_std;         /* estimated_target_std_deviations or NULL       */
+    /* reduced recorders of the last round + what adapt() derived from them       */
+    po_recorders reduced;
+    int64_t  reduced_n_scans;
+    int64_t *reduced_ip;         /* [replica][scan]                               */
+    int64_t  reduced_ip_cap;
+    double   global_barrier;
+    double  *cb_x, *cb_y, *cb_m, *cb_c, *cb_d;  /* cumulative barrier interpolant */
+    int      cb_valid;
+    double   stepping_stone[2];
+    char     err[512];
+    int      failed;
+};
+
+const char *po_last_error(const po_pt *pt) { return pt->err; }
+int64_t po_round(const po_pt *pt) { return pt->round; }
+
+void po_default_config(po_config *c) {
+    memset(c, 0, sizeof(*c));
+    c->n_chains = 10; c->dim = 2; c->seed = 1;          /* src/pt/Inputs.jl:14-20 */
+    c->target = PO_TARGET_MVN; c->explorer = PO_EXPLORER_TOY;
+    c->p0 = 1.0; c->p1 = 10.0;                          /* ScaledPrecisionNormalPath.jl:43-44 */
+    c->slice_w = 10.0; c->slice_p = 20; c->slice_n_passes = 3; c->slice_max_iter = 1024;
+    c->am_base_n_refresh = 3; c->am_exponent_n_refresh = 0.35; c->am_step_size = 1.0;
+    c->am_preconditioner = 2; c->am_p0 = 1.0 / 3.0; c->am_p1 = 1.0 / 3.0;
+    c->record_round_trip = 1; c->record_index_process = 1; c->record_online = 0;
+    c->n_threads = 1;
+}
+
+/* ---- the path: log potentials along the ladder ---------------------------- */
+/* precision(path, beta), src/paths/ScaledPrecisionNormalPath.jl:45-46 */
+static inline double mvn_precision(const po_pt *pt, double beta) {
+    return (1.0 - beta) * pt->cfg.p0 + beta * pt->cfg.p1;
+}
+/* ScaledPrecisionNormalLogPotential(x), ScaledPrecisionNormalPath.jl:19-20 */
+static inline double mvn_lp(double prec, const double *x, int64_t d) {
+    return (-0.5 * prec) * po_sqr_norm(x, d);
+}
+/* log_potentials[chain](x) (src/tempering/NonReversiblePT.jl:72, src/schedules/discretize.jl:6-7) */
+static double lp_at_chain(const po_pt *pt, int64_t chain, const double *x) {
+    switch (pt->cfg.target) {
+    case PO_TARGET_MVN: return mvn_lp(mvn_precision(pt, pt->betas[chain]), x, pt->d);
+    default: return NAN;
+    }
+}
+
+/* ---- DEO swap graph -------------------------------------------------------- */
+/* partner_chain(::OddEven, chain), src/swap/OddEven.jl:23-31, 1-based there.
+ * `even` = iseven(scan) (src/swap/DEO.jl:12). */
+static int64_t partner_chain(int64_t N, int even, int64_t chain0) {
+    int64_t chain = chain0 + 1;
+    int chain_even = (chain % 2 == 0);
+    int64_t proposed = chain + ((chain_even == even) ? 1 : -1);
+    if (proposed == 0) return 0;
+    if (proposed == N + 1) return N - 1;
+    return proposed - 1;
+}
+static inline int is_reference(int64_t N, int64_t chain0) { return chain0 == 0 && N > 1; }  /* DEO.jl:13 */
+static inline int is_target(int64_t N, int64_t chain0) { return chain0 == N - 1; }          /* DEO.jl:14 */
+
+/* ========================================================================== */
+/* explorers                                                                  */
+/* ========================================================================== */
+static void fail(po_pt *pt, const char *msg) {
+#pragma omp critical
+    { if (!pt->failed) { pt->failed = 1; snprintf(pt->err, sizeof(pt->err), "%s", msg); } }
+}
+
+/* rand!(rng, x, lp) / sample_iid! / ToyExplorer.step!
+ * (src/targets/toy_mvn_target.jl:15-21, src/explorers/ToyExplorer.jl:7-12) */
+static void mvn_sample_iid(po_pt *pt, po_replica *r) {
+    double prec = mvn_precision(pt, pt->betas[r->chain]);
+    double sd = sqrt(prec);
+    for (int64_t i = 0; i < pt->d; i++) r->state[i] = po_randn(&r->rng) / sd;
+}
+
+/* ---- SliceSampler (src/explorers/SliceSampler.jl) -------------------------- */
+typedef struct { po_pt *pt; po_replica *r; int64_t chain; int64_t c; } slice_ctx;
+
+static inline double slice_lp(slice_ctx *s) { return lp_at_chain(s->pt, s->chain, s->r->state); }
+
+static inline int jl_isapprox(double x, double y) {  /* Base.isapprox defaults, rtol = sqrt(eps) */
+    if (x == y) return 1;
+    if (!isfinite(x) || !isfinite(y)) return 0;
+    double ax = fabs(x), ay = fabs(y);
+    return fabs(x - y) <= 1.4901161193847656e-8 * (ax > ay ? ax : ay);
+}
+
+/* slice_accept, SliceSampler.jl:192-237 */
+static int slice_accept(slice_ctx *s, double new_position, double z, double L, double R,
+                        double lp_L, double lp_R) {
+    const po_config *h = &s->pt->cfg;
+    double *ptr = &s->r->state[s->c];
+    double old_position = *ptr;
+    double Lhat = L, Rhat = R;
+    int Rstale = 0, Lstale = 0, D = 0;
+    while (Rhat - Lhat > 1.1 * h->slice_w) {
+        double M = (Lhat + Rhat) / 2.0;
+        if ((old_position < M && new_position >= M) || (old_position >= M && new_position < M)) D = 1;
+        if (new_position < M) { Rhat = M; Rstale = 1; }
+        else { Lhat = M; Lstale = 1; }
+        if (D) {
+            if (Lstale) { *ptr = Lhat; lp_L = slice_lp(s); Lstale = 0; }
+            if (Rstale) { *ptr = Rhat; lp_R = slice_lp(s); Rstale = 0; }
+            if (z >= lp_L && z >= lp_R) {
+                *ptr = old_position;
+                mean_fit(&s->r->rec.expl_acc[s->chain], 0.0);
+                return 0;
+            }
+        }
+    }
+    *ptr = old_position;
+    mean_fit(&s->r->rec.expl_acc[s->chain], 1.0);
+    return 1;
+}
+
+/* slice_sample_coord! (generic Float64 case), SliceSampler.jl:89-95 with
+ * slice_double :97-126, initialize_slice_endpoints :129-133, slice_shrink! :144-186 */
+static int slice_sample_coord(slice_ctx *s, double *cached_lp) {
+    const po_config *h = &s->pt->cfg;
+    po_rng *rng = &s->r->rng;
+    double *ptr = &s->r->state[s->c];
+    double z = *cached_lp - po_randexp(rng);
+    /* slice_double */
+    double old_position = *ptr;
+    double L = old_position - h->slice_w * po_rand(rng);
+    double R = L + h->slice_w;
+    int K = h->slice_p;
+    *ptr = L; double potent_L = slice_lp(s);
+    *ptr = R; double potent_R = slice_lp(s);
+    while (K > 0 && (z < potent_L || z < potent_R)) {
+        double V = po_rand(rng);
+        if (V <= 0.5) { L = L - (R - L); *ptr = L; potent_L = slice_lp(s); }
+        else { R = R + (R - L); *ptr = R; potent_R = slice_lp(s); }
+        K -= 1;
+    }
+    sum_fit(&s->r->rec.expl_steps[s->chain], (double)(h->slice_p - K));
+    *ptr = old_position;
+    /* slice_shrink! */
+    double Lbar = L, Rbar = R, new_lp = 0.0;
+    for (int n = 1; n <= h->slice_max_iter; n++) {
+        double new_position = Lbar + po_rand(rng) * (Rbar - Lbar);   /* draw_new_position :188 */
+        *ptr = new_position;
+        new_lp = slice_lp(s);
+        int consider = z < new_lp;
+        *ptr = old_position;
+        if (consider && slice_accept(s, new_position, z, L, R, potent_L, potent_R)) {
+            *ptr = new_position;
+            sum_fit(&s->r->rec.expl_steps[s->chain], (double)n);
+            *cached_lp = new_lp;
+            return 0;
+        }
+        if (new_position < *ptr) Lbar = new_position; else Rbar = new_position;
+        if (jl_isapprox(Lbar, Rbar)) {
+            *ptr = old_position;
+            sum_fit(&s->r->rec.expl_steps[s->chain], (double)n);
+            *cached_lp = slice_lp(s);
+            return 0;
+        }
+    }
+    fail(s->pt, "SliceSampler: maximum number of iterations reached");
+    return 1;
+}
+
+/* step!(::SliceSampler) :24-30, slice_sample! :43-62, cached_log_potential :32-41 */
+static int slice_step(po_pt *pt, po_replica *r) {
+    slice_ctx s = { pt, r, r->chain, 0 };
+    double cached_lp = -INFINITY;
+    for (int pass = 0; pass < pt->cfg.slice_n_passes; pass++) {
+        if (cached_lp == -INFINITY) {
+            cached_lp = slice_lp(&s);
+            if (cached_lp == -INFINITY) { fail(pt, "SliceSampler: initialized outside the support"); return 1; }
+        }
+        for (int64_t c = 0; c < pt->d; c++) {
+            s.c = c;
+            if (slice_sample_coord(&s, &cached_lp)) return 1;
+            if (!isfinite(cached_lp)) { fail(pt, "SliceSampler: invalid log density after update"); return 1; }
+        }
+    }
+    return 0;
+}
+
+/* explore!(pt, replica, explorer), src/pt/pigeons.jl:101-132 */
+static int explore_replica(po_pt *pt, po_replica *r) {
+    const int64_t N = pt->N;
+    if (pt->cfg.target == PO_TARGET_TEST_SWAPPER) return 0;   /* state nothing, step! no-op (pair_swapper.jl:137-143) */
+    if (is_reference(N, r->chain)) {
+        mvn_sample_iid(pt, r);
+    } else {
+        switch (pt->cfg.explorer) {
+        case PO_EXPLORER_TOY:   mvn_sample_iid(pt, r); break;
+        case PO_EXPLORER_SLICE: if (slice_step(pt, r)) return 1; break;
+        case PO_EXPLORER_NONE:  break;
+        default: fail(pt, "oracle: explorer not implemented"); return 1;
+        }
+    }
+    if (is_target(N, r->chain) && pt->cfg.record_online) {
+        for (int64_t i = 0; i < pt->d; i++) {       /* OnlineStateRecorder.jl:87-96 */
+            mean_fit(&r->rec.on_mean[i], r->state[i]);
+            var_fit(&r->rec.on_var[i], r->state[i]);
+        }
+    }
+    return 0;
+}
+
+/* ========================================================================== */
+/* communicate!  (src/pt/pigeons.jl:64-69, src/swap/swap.jl:6-39,106-126)       */
+/* ========================================================================== */
+typedef struct { double log_ratio, uniform; } swap_stat_t;   /* pair_swapper.jl:8-11 */
+
+/* swap_stat, pair_swapper.jl:42-47 (TestSwapper :128) */
+static int swap_stat(po_pt *pt, po_replica *r, int64_t partner, swap_stat_t *out) {
+    if (pt->cfg.target == PO_TARGET_TEST_SWAPPER) {
+        out->log_ratio = 0.0;
+        out->uniform = po_rand(&r->rng);
+        return 0;
+    }
+    /* log_unnormalized_ratio(lps, partner, my_chain, state), log_potentials.jl:43-51 */
+    double lp_num = lp_at_chain(pt, partner, r->state);
+    double lp_den = lp_at_chain(pt, r->chain, r->state);
+    double ans = lp_num - lp_den;
+    if (isnan(ans)) { fail(pt, "Got NaN log-unnormalized ratio"); return 1; }
+    out->log_ratio = ans;
+    out->uniform = po_rand(&r->rng);
+    return 0;
+}
+static inline double swap_acceptance_probability(const swap_stat_t *a, const swap_stat_t *b) {
+    double e = exp(a->log_ratio + b->log_ratio);            /* pair_swapper.jl:88 */
+    return e < 1.0 ? e : 1.0;
+}
+static int swap_decision(const po_pt *pt, int64_t c1, const swap_stat_t *s1, int64_t c2, const swap_stat_t *s2) {
+    double uniform = c1 < c2 ? s1->uniform : s2->uniform;
+    if (pt->cfg.target == PO_TARGET_TEST_SWAPPER) return uniform < pt->cfg.p0;   /* :135-138 */
+    return uniform < swap_acceptance_probability(s1, s2);                          /* :81-85  */
+}
+/* _swap!, swap.jl:106-126 */
+static void half_swap(po_pt *pt, po_replica *r, const swap_stat_t *mine, const swap_stat_t *theirs, int64_t partner) {
+    const int64_t N = pt->N;
+    int64_t my_chain = r->chain;
+    if (pt->cfg.record_index_process) {
+        if (r->rec.ip_len == r->rec.ip_cap) {
+            r->rec.ip_cap = r->rec.ip_cap ? 2 * r->rec.ip_cap : 64;
+            r->rec.ip = (int64_t *)realloc(r->rec.ip, sizeof(int64_t) * (size_t)r->rec.ip_cap);
+        }
+        r->rec.ip[r->rec.ip_len++] = r->chain;
+    }
+    if (pt->cfg.record_round_trip) round_trip_record(&r->rec.rt, is_reference(N, r->chain), is_target(N, r->chain));
+    if (my_chain == partner) return;
+    int do_swap = swap_decision(pt, my_chain, mine, partner, theirs);
+    if (my_chain < partner && pt->cfg.target != PO_TARGET_TEST_SWAPPER) {
+        /* record_swap_stats!, pair_swapper.jl:59-66 */
+        double acc = swap_acceptance_probability(mine, theirs);
+        mean_fit(&r->rec.swap_pr[my_chain], acc);
+        logsum_fit(&r->rec.lsr_up[my_chain], mine->log_ratio);
+        logsum_fit(&r->rec.lsr_dn[my_chain], theirs->log_ratio);
+    }
+    if (do_swap) r->chain = partner;
+}
+static int communicate(po_pt *pt) {
+    const int64_t N = pt->N;
+    int even = (pt->scan % 2 == 0);
+    for (int64_t my_chain = 0; my_chain < N; my_chain++) {
+        po_replica *me = &pt->replicas[pt->replica_of_chain[my_chain]];
+        int64_t partner = partner_chain(N, even, my_chain);
+        if (partner >= my_chain) {
+            po_replica *other = &pt->replicas[pt->replica_of_chain[partner]];
+            swap_stat_t mine, theirs;
+            if (swap_stat(pt, me, partner, &mine)) return 1;
+            if (partner == my_chain) theirs = mine;
+            else if (swap_stat(pt, other, my_chain, &theirs)) return 1;
+            half_swap(pt, me, &mine, &theirs, partner);
+            if (partner != my_chain) half_swap(pt, other, &theirs, &mine, my_chain);
+        }
+    }
+    for (int64_t r = 0; r < N; r++) pt->replica_of_chain[pt->replicas[r].chain] = r;   /* resort_replicas! */
+    return 0;
+}
+
+/* ========================================================================== */
+/* round loop                                                                 */
+/* ========================================================================== */
+po_pt *po_create(const po_config *cfg) {
+    po_pt *pt = (po_pt *)calloc(1, sizeof(po_pt));
+    pt->cfg = *cfg;
+    const int64_t N = pt->N = cfg->n_chains;
+    const int64_t d = pt->d = (cfg->target == PO_TARGET_TEST_SWAPPER) ? 0 : cfg->dim;
+    pt->replicas = (po_replica *)calloc((size_t)N, sizeof(po_replica));
+    pt->replica_of_chain = (int64_t *)calloc((size_t)N, sizeof(int64_t));
+    pt->betas = (double *)calloc((size_t)N, sizeof(double));
+    /* equally_spaced_schedule, src/schedules/Schedule.jl:36-44 (range elements i/(N-1)) */
+    if (N == 1) pt->betas[0] = 1.0;
+    else for (int64_t i = 0; i < N; i++) pt->betas[i] = (i == N - 1) ? 1.0 : (double)i / (double)(N - 1);
+    pt->step_size = cfg->am_step_size;
+    /* _create_locals, src/replicas/replicas.jl:87-98; split_slice, src/utils/misc.jl:21-31 */
+    po_rng master = po_rng_new(cfg->seed);
+    for (int64_t i = 0; i < N; i++) {
+        po_replica *r = &pt->replicas[i];
+        r->rng = po_rng_split(&master);
+        r->chain = i; r->replica_index = i;
+        pt->replica_of_chain[i] = i;
+        r->state = (double *)calloc((size_t)(d > 0 ? d : 1), sizeof(double));
+        r->buf = (double *)calloc((size_t)(8 * (d > 0 ? d : 1)), sizeof(double));
+        rec_alloc(&r->rec, N, d);
+        rec_empty(&r->rec, N, d);
+        if (cfg->target == PO_TARGET_MVN) {
+            /* initialization, src/targets/toy_mvn_target.jl:10-11 */
+            double s = sqrt(cfg->p1);
+            for (int64_t k = 0; k < d; k++) r->state[k] = po_randn(&r->rng);
+            for (int64_t k = 0; k < d; k++) r->state[k] = r->state[k] / s;
+        }
+    }
+    rec_alloc(&pt->reduced, N, d);
+    rec_empty(&pt->reduced, N, d);
+    pt->cb_x = (double *)calloc((size_t)N * 5, sizeof(double));
+    pt->cb_y = pt->cb_x + N; pt->cb_m = pt->cb_y + N; pt->cb_c = pt->cb_m + N; pt->cb_d = pt->cb_c + N;
+    return pt;
+}
+void po_destroy(po_pt *pt) {
+    if (!pt) return;
+    for (int64_t i = 0; i < pt->N; i++) { free(pt->replicas[i].state); free(pt->replicas[i].buf); rec_free(&pt->replicas[i].rec); }
+    rec_free(&pt->reduced);
+    free(pt->replicas); free(pt->replica_of_chain); free(pt->betas); free(pt->target_std);
+    free(pt->reduced_ip); free(pt->cb_x);
+    free(pt);
+}
+
+/* next_round!, src/pt/Iterators.jl:27-35 */
+int po_begin_round(po_pt *pt) { pt->round += 1; pt->scan = 0; return 0; }
+
+/* the `while next_scan!` loop of run_one_round!, src/pt/pigeons.jl:49-52 */
+int po_run_scans(po_pt *pt, int64_t n_scans) {
+    const int64_t N = pt->N;
+    for (int64_t t = 0; t < n_scans; t++) {
+        pt->scan += 1;
+        int nt = pt->cfg.n_threads > 1 ? pt->cfg.n_threads : 1;
+        (void)nt;
+        /* explore!: @threads static over replicas sorted by chain (pigeons.jl:82-85) */
+#pragma omp parallel for schedule(static) num_threads(nt) if (nt > 1)
+        for (int64_t c = 0; c < N; c++) {
+            if (!pt->failed) explore_replica(pt, &pt->replicas[pt->replica_of_chain[c]]);
+        }
+        if (pt->failed) return 1;
+        if (communicate(pt)) return 1;
+    }
+    return 0;
+}
+
+/* rejections, src/tempering/adaptation.jl:109-112 */
+static void rejections(const po_pt *pt, double *r) {
+    for (int64_t i = 0; i + 1 < pt->N; i++)
+        r[i] = 1.0 - (pt->reduced.swap_pr[i].n > 0 ? pt->reduced.swap_pr[i].mu : 0.5);
+}
+
+/* optimal_schedule(_generator), communication_barriers, adaptation.jl:56-93 */
+static int adapt_tempering(po_pt *pt) {
+    const int64_t N = pt->N;
+    if (N == 1) return 0;                                   /* NonReversiblePT.jl:53-55 */
+    double *rej = (double *)malloc(sizeof(double) * (size_t)N * 8);
+    double *x = rej + N, *xn = x + N, *m = xn + N, *c = m + N, *dd = c + N, *newb = dd + N, *work = newb + N;
+    rejections(pt, rej);
+    for (int64_t i = 0; i + 1 < N; i++) if (!(rej[i] >= 0.0)) { free(rej); fail(pt, "Bad intensities"); return 1; }
+    /* communication_barriers on the OLD schedule */
+    pt->cb_x[0] = pt->betas[0]; pt->cb_y[0] = 0.0;
+    double acc = 0.0;
+    for (int64_t i = 0; i + 1 < N; i++) { acc += rej[i]; pt->cb_x[i + 1] = pt->betas[i + 1]; pt->cb_y[i + 1] = acc; }
+    pt->global_barrier = acc;
+    po_fc_build(pt->cb_x, pt->cb_y, N, pt->cb_m, pt->cb_c, pt->cb_d);
+    pt->cb_valid = 1;
+    /* optimal_schedule_generator */
+    int nudged = 0;
+    for (;;) {
+        memcpy(work, rej, sizeof(double) * (size_t)(N - 1));
+        if (nudged) for (int64_t i = 0; i + 1 < N; i++) work[i] = rej[i] + 1e-6;
+        x[0] = 0.0; acc = 0.0;
+        for (int64_t i = 0; i + 1 < N; i++) { acc += work[i]; x[i + 1] = acc; }
+        double norm = x[N - 1];
+        int dup = 0;
+        for (int64_t i = 0; i < N; i++) xn[i] = x[i] / norm;
+        for (int64_t i = 0; i + 1 < N; i++) if (xn[i] == xn[i + 1]) dup = 1;
+        if (dup) {
+            if (nudged) { free(rej); fail(pt, "optimal_schedule: duplicate knots after nudge"); return 1; }
+            nudged = 1; continue;
+        }
+        break;
+    }
+    po_fc_build(xn, pt->betas, N, m, c, dd);
+    newb[0] = 0.0; newb[N - 1] = 1.0;
+    for (int64_t i = 1; i + 1 < N; i++) newb[i] = po_fc_eval(xn, pt->betas, m, c, dd, N, (double)i / (double)(N - 1));
+    /* Schedule constructor asserts, src/schedules/Schedule.jl:19-23 */
+    for (int64_t i = 0; i + 1 < N; i++) if (!(newb[i] < newb[i + 1])) { free(rej); fail(pt, "Invalid schedule"); return 1; }
+    memcpy(pt->betas, newb, sizeof(double) * (size_t)N);
+    free(rej);
+    return 0;
+}
+
+/* stepping_stone_pair, src/evidence/stepping_stone.jl:28-43 */
+static void stepping_stone(po_pt *pt) {
+    double e1 = 0.0, e2 = 0.0;
+    for (int64_t i = 0; i + 1 < pt->N; i++) {
+        if (pt->reduced.lsr_up[i].n > 0) e1 += pt->reduced.lsr_up[i].value - log((double)pt->reduced.lsr_up[i].n);
+        if (pt->reduced.lsr_dn[i].n > 0) e2 += pt->reduced.lsr_dn[i].value - log((double)pt->reduced.lsr_dn[i].n);
+    }
+    pt->stepping_stone[0] = e1; pt->stepping_stone[1] = -e2;
+}
+
+/* reduce_recorders! (src/recorders/recorders.jl:88-120) with the binary tree of
+ * all_reduce_deterministically over replica indices (src/mpi_utils/Entangler.jl:188-251),
+ * then adapt (src/pt/pigeons.jl:152-162). */
+int po_end_round(po_pt *pt) {
+    const int64_t N = pt->N, d = pt->d;
+    int64_t n_scans = pt->scan;
+    /* collect index_process first (disjoint keys) */
+    if (pt->cfg.record_index_process) {
+        if (pt->reduced_ip_cap < N * n_scans) {
+            pt->reduced_ip_cap = N * n_scans;
+            pt->reduced_ip = (int64_t *)realloc(pt->reduced_ip, sizeof(int64_t) * (size_t)pt->reduced_ip_cap);
+        }
+        for (int64_t r = 0; r < N; r++)
+            memcpy(pt->reduced_ip + r * n_scans, pt->replicas[r].rec.ip, sizeof(int64_t) * (size_t)pt->replicas[r].rec.ip_len);
+    }
+    pt->reduced_n_scans = n_scans;
+    for (int64_t s = 1; s < N; s *= 2)
+        for (int64_t i = 0; i + s < N; i += 2 * s)
+            rec_merge(&pt->replicas[i].rec, &pt->replicas[i + s].rec, N, d);
+    rec_empty(&pt->reduced, N, d);
+    rec_merge(&pt->reduced, &pt->replicas[0].rec, N, d);
+    pt->reduced.rt.state = 0;
+    for (int64_t r = 0; r < N; r++) rec_empty(&pt->replicas[r].rec, N, d);
+    pt->scan = 0;                                           /* Iterators.jl:43-45 */
+    if (pt->cfg.target != PO_TARGET_TEST_SWAPPER) {
+        stepping_stone(pt);                                 /* report uses pre-adapt recorders */
+        if (adapt_tempering(pt)) return 1;
+    }
+    return 0;
+}
+
+int po_run_round(po_pt *pt) {
+    po_begin_round(pt);
+    if (po_run_scans(pt, (int64_t)1 << pt->round)) return 1;   /* n_scans_in_round, Iterators.jl:49 */
+    return po_end_round(pt);
+}
+
+/* ========================================================================== */
+/* getters                                                                    */
+/* ========================================================================== */
+void po_get_states(const po_pt *pt, double *x, int64_t *chain, uint64_t *rng) {
+    for (int64_t r = 0; r < pt->N; r++) {
+        if (x && pt->d > 0) memcpy(x + r * pt->d, pt->replicas[r].state, sizeof(double) * (size_t)pt->d);
+        if (chain) chain[r] = pt->replicas[r].chain;
+        if (rng) { rng[2 * r] = pt->replicas[r].rng.seed; rng[2 * r + 1] = pt->replicas[r].rng.gamma; }
+    }
+}
+void po_get_schedule(const po_pt *pt, double *b) { memcpy(b, pt->betas, sizeof(double) * (size_t)pt->N); }
+void po_set_schedule(po_pt *pt, const double *b) { memcpy(pt->betas, b, sizeof(double) * (size_t)pt->N); }
+void po_get_swap_pr(const po_pt *pt, double *mean, int64_t *n) {
+    for (int64_t i = 0; i + 1 < pt->N; i++) { mean[i] = pt->reduced.swap_pr[i].mu; n[i] = pt->reduced.swap_pr[i].n; }
+}
+void po_get_log_sum_ratio(const po_pt *pt, double *up, int64_t *up_n, double *dn, int64_t *dn_n) {
+    for (int64_t i = 0; i + 1 < pt->N; i++) {
+        up[i] = pt->reduced.lsr_up[i].value; up_n[i] = pt->reduced.lsr_up[i].n;
+        dn[i] = pt->reduced.lsr_dn[i].value; dn_n[i] = pt->reduced.lsr_dn[i].n;
+    }
+}
+void po_get_round_trip(const po_pt *pt, int64_t *restarts, int64_t *trips) {
+    *restarts = pt->reduced.rt.n_tempered_restarts; *trips = pt->reduced.rt.n_round_trips;
+}
+int64_t po_get_index_process(const po_pt *pt, int64_t *out) {
+    if (out && pt->reduced_ip) memcpy(out, pt->reduced_ip, sizeof(int64_t) * (size_t)(pt->N * pt->reduced_n_scans));
+    return pt->reduced_n_scans;
+}
+void po_get_explorer_stats(const po_pt *pt, double *acc_mean, int64_t *acc_n, double *steps_sum, int64_t *steps_n) {
+    for (int64_t i = 0; i < pt->N; i++) {
+        acc_mean[i] = pt->reduced.expl_acc[i].mu; acc_n[i] = pt->reduced.expl_acc[i].n;
+        steps_sum[i] = pt->reduced.expl_steps[i].sum; steps_n[i] = pt->reduced.expl_steps[i].n;
+    }
+}
+void po_get_am_stats(const po_pt *pt, double *fm, int64_t *fn, double *rm, int64_t *rn) {
+    for (int64_t i = 0; i < pt->N; i++) {
+        fm[i] = pt->reduced.am_factors[i].mu; fn[i] = pt->reduced.am_factors[i].n;
+        rm[i] = pt->reduced.rev_rate[i].mu; rn[i] = pt->reduced.rev_rate[i].n;
+    }
+}
+int64_t po_get_online(const po_pt *pt, double *mean, double *var) {
+    for (int64_t i = 0; i < pt->d; i++) { mean[i] = pt->reduced.on_mean[i].mu; var[i] = var_value(&pt->reduced.on_var[i]); }
+    return pt->d > 0 ? pt->reduced.on_mean[0].n : 0;
+}
+void po_get_stepping_stone(const po_pt *pt, double *pair) { pair[0] = pt->stepping_stone[0]; pair[1] = pt->stepping_stone[1]; }
+double po_get_global_barrier(const po_pt *pt) { return pt->global_barrier; }
+double po_cumulative_barrier(const po_pt *pt, double beta) {
+    if (!pt->cb_valid) return NAN;
+    return po_fc_eval(pt->cb_x, pt->cb_y, pt->cb_m, pt->cb_c, pt->cb_d, pt->N, beta);
+}
+double po_get_step_size(const po_pt *pt) { return pt->step_size; }

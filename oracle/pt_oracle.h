@@ -1,0 +1,110 @@
+/* pt_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the explore-then-swap hot path of Pigeons.jl v0.4.10
+ * (reference tree at /root/reference, pure Julia).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; the
+ * product library (pigeons.jl_amd/csrc) never links, includes or calls it.
+ *
+ * PARITY UNPINNED: the reference cannot be executed in the build container (no
+ * Julia) and its tests hold no bit-level golden vectors for this path, so this
+ * restatement is pinned only by (i) the reference's RNG-free / analytic known
+ * answers (tests/test_oracle_kat.py) and (ii) the public SplitMix64 vector and the
+ * four recalled ziggurat table entries.  Third-party arithmetic restated from
+ * published algorithms: SplittableRandoms.jl 0.1 (Java SplittableRandom),
+ * Julia Random stdlib rand/randn/randexp, OnlineStatsBase 1.x Mean/Variance/Sum,
+ * Interpolations.jl FritschCarlsonMonotonicInterpolation, LogExpFunctions logaddexp.
+ *
+ * All indices crossing this API are 0-based (chain 0 = reference, chain N-1 =
+ * target; replica r = reference replica_index r+1).
+ */
+#ifndef PT_ORACLE_H
+#define PT_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- RNG: SplittableRandoms.jl + Julia Random samplers ------------------- */
+typedef struct { uint64_t seed, gamma; } po_rng;
+po_rng   po_rng_new(uint64_t seed);          /* SplittableRandom(seed)            */
+uint64_t po_rng_next_u64(po_rng *r);         /* rand(rng, UInt64)                  */
+po_rng   po_rng_split(po_rng *r);            /* split(rng)                         */
+double   po_rand(po_rng *r);                 /* rand(rng)    :: Float64 in [0,1)   */
+double   po_randn(po_rng *r);                /* randn(rng)   (ziggurat)            */
+double   po_randexp(po_rng *r);              /* randexp(rng) (ziggurat)            */
+
+/* ---- numerics ------------------------------------------------------------ */
+double po_sqr_norm(const double *x, int64_t d);       /* fixed pairwise tree       */
+double po_logaddexp(double a, double b);
+/* Fritsch-Carlson monotone cubic: build (m,c,dd from knots x,y; n>=2) / evaluate */
+void   po_fc_build(const double *x, const double *y, int64_t n, double *m, double *c, double *dd);
+double po_fc_eval(const double *x, const double *y, const double *m, const double *c,
+                  const double *dd, int64_t n, double t);
+
+/* ---- parallel tempering --------------------------------------------------- */
+enum { PO_TARGET_MVN = 0, PO_TARGET_TEST_SWAPPER = 1, PO_TARGET_FUNNEL = 2 };
+enum { PO_EXPLORER_NONE = 0, PO_EXPLORER_TOY = 1, PO_EXPLORER_SLICE = 2, PO_EXPLORER_AUTOMALA = 3 };
+
+typedef struct po_config {
+    int64_t  n_chains;
+    int64_t  dim;
+    uint64_t seed;
+    int32_t  target;            /* PO_TARGET_*                                     */
+    int32_t  explorer;          /* PO_EXPLORER_*                                   */
+    double   p0, p1;            /* MVN: precision0/1. TestSwapper: p0 = accept pr.
+                                   Funnel: p0 = precision of the normal reference  */
+    /* SliceSampler (src/explorers/SliceSampler.jl:8-20) */
+    double   slice_w;
+    int32_t  slice_p, slice_n_passes, slice_max_iter;
+    /* AutoMALA (src/explorers/AutoMALA.jl:29-68) */
+    int32_t  am_base_n_refresh;
+    double   am_exponent_n_refresh;
+    double   am_step_size;
+    int32_t  am_preconditioner;  /* 0 identity, 1 diagonal, 2 mix-diagonal         */
+    double   am_p0, am_p1;       /* mix proportions (1/3, 1/3)                     */
+    /* recorders */
+    int32_t  record_round_trip, record_index_process, record_online;
+    int32_t  n_threads;          /* OpenMP threads over replicas in explore!       */
+} po_config;
+
+typedef struct po_pt po_pt;
+
+void        po_default_config(po_config *cfg);
+po_pt      *po_create(const po_config *cfg);
+void        po_destroy(po_pt *pt);
+const char *po_last_error(const po_pt *pt);
+
+/* One full round (src/pt/pigeons.jl:17-19): 2^round scans, reduce, adapt.       */
+int         po_run_round(po_pt *pt);
+/* Pieces of the above, for timing and fine-grained tests. */
+int         po_begin_round(po_pt *pt);                 /* round += 1, scan = 0     */
+int         po_run_scans(po_pt *pt, int64_t n_scans);  /* explore!+communicate!    */
+int         po_end_round(po_pt *pt);                   /* reduce_recorders!, adapt */
+int64_t     po_round(const po_pt *pt);
+
+/* State (replica order). rng: 2 words per replica (seed, gamma). */
+void po_get_states(const po_pt *pt, double *x, int64_t *chain, uint64_t *rng);
+void po_get_schedule(const po_pt *pt, double *betas);
+void po_set_schedule(po_pt *pt, const double *betas);
+
+/* Reduced recorders of the last completed round. */
+void    po_get_swap_pr(const po_pt *pt, double *mean, int64_t *n);              /* N-1      */
+void    po_get_log_sum_ratio(const po_pt *pt, double *up, int64_t *up_n,
+                             double *dn, int64_t *dn_n);                         /* N-1 each */
+void    po_get_round_trip(const po_pt *pt, int64_t *restarts, int64_t *trips);
+int64_t po_get_index_process(const po_pt *pt, int64_t *out);  /* [replica][scan]; returns n_scans */
+void    po_get_explorer_stats(const po_pt *pt, double *acc_mean, int64_t *acc_n,
+                              double *steps_sum, int64_t *steps_n);              /* N each   */
+void    po_get_am_stats(const po_pt *pt, double *factor_mean, int64_t *factor_n,
+                        double *rev_mean, int64_t *rev_n);                       /* N each   */
+int64_t po_get_online(const po_pt *pt, double *mean, double *var);               /* d each; returns n */
+void    po_get_stepping_stone(const po_pt *pt, double *pair);                    /* 2        */
+double  po_get_global_barrier(const po_pt *pt);
+double  po_cumulative_barrier(const po_pt *pt, double beta);
+double  po_get_step_size(const po_pt *pt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,258 @@
+"""ctypes binding of the CPU oracle (oracle/pt_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB_PATH = os.path.join(ORACLE_DIR, "_build", "libpt_oracle.so")
+
+TARGET_MVN, TARGET_TEST_SWAPPER, TARGET_FUNNEL = 0, 1, 2
+EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA = 0, 1, 2, 3
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("n_chains", C.c_int64), ("dim", C.c_int64), ("seed", C.c_uint64),
+        ("target", C.c_int32), ("explorer", C.c_int32),
+        ("p0", C.c_double), ("p1", C.c_double),
+        ("slice_w", C.c_double),
+        ("slice_p", C.c_int32), ("slice_n_passes", C.c_int32), ("slice_max_iter", C.c_int32),
+        ("am_base_n_refresh", C.c_int32),
+        ("am_exponent_n_refresh", C.c_double), ("am_step_size", C.c_double),
+        ("am_preconditioner", C.c_int32),
+        ("am_p0", C.c_double), ("am_p1", C.c_double),
+        ("record_round_trip", C.c_int32), ("record_index_process", C.c_int32),
+        ("record_online", C.c_int32), ("n_threads", C.c_int32),
+    ]
+
+
+class Rng(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("gamma", C.c_uint64)]
+
+
+def build(force=False):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("pt_oracle.c", "pt_oracle.h", "zig_tables.h", "Makefile")]
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(LIB_PATH)
+    dp, ip, up = C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
+    L.po_rng_new.restype = Rng
+    L.po_rng_new.argtypes = [C.c_uint64]
+    L.po_rng_next_u64.restype = C.c_uint64
+    L.po_rng_next_u64.argtypes = [C.POINTER(Rng)]
+    L.po_rng_split.restype = Rng
+    L.po_rng_split.argtypes = [C.POINTER(Rng)]
+    for f in ("po_rand", "po_randn", "po_randexp"):
+        getattr(L, f).restype = C.c_double
+        getattr(L, f).argtypes = [C.POINTER(Rng)]
+    L.po_sqr_norm.restype = C.c_double
+    L.po_sqr_norm.argtypes = [dp, C.c_int64]
+    L.po_logaddexp.restype = C.c_double
+    L.po_logaddexp.argtypes = [C.c_double, C.c_double]
+    L.po_fc_build.argtypes = [dp, dp, C.c_int64, dp, dp, dp]
+    L.po_fc_eval.restype = C.c_double
+    L.po_fc_eval.argtypes = [dp, dp, dp, dp, dp, C.c_int64, C.c_double]
+    L.po_default_config.argtypes = [C.POINTER(Config)]
+    L.po_create.restype = C.c_void_p
+    L.po_create.argtypes = [C.POINTER(Config)]
+    L.po_destroy.argtypes = [C.c_void_p]
+    L.po_last_error.restype = C.c_char_p
+    L.po_last_error.argtypes = [C.c_void_p]
+    for f in ("po_run_round", "po_begin_round", "po_end_round"):
+        getattr(L, f).restype = C.c_int
+        getattr(L, f).argtypes = [C.c_void_p]
+    L.po_run_scans.restype = C.c_int
+    L.po_run_scans.argtypes = [C.c_void_p, C.c_int64]
+    L.po_round.restype = C.c_int64
+    L.po_round.argtypes = [C.c_void_p]
+    L.po_get_states.argtypes = [C.c_void_p, dp, ip, up]
+    L.po_get_schedule.argtypes = [C.c_void_p, dp]
+    L.po_set_schedule.argtypes = [C.c_void_p, dp]
+    L.po_get_swap_pr.argtypes = [C.c_void_p, dp, ip]
+    L.po_get_log_sum_ratio.argtypes = [C.c_void_p, dp, ip, dp, ip]
+    L.po_get_round_trip.argtypes = [C.c_void_p, ip, ip]
+    L.po_get_index_process.restype = C.c_int64
+    L.po_get_index_process.argtypes = [C.c_void_p, ip]
+    L.po_get_explorer_stats.argtypes = [C.c_void_p, dp, ip, dp, ip]
+    L.po_get_am_stats.argtypes = [C.c_void_p, dp, ip, dp, ip]
+    L.po_get_online.restype = C.c_int64
+    L.po_get_online.argtypes = [C.c_void_p, dp, dp]
+    L.po_get_stepping_stone.argtypes = [C.c_void_p, dp]
+    L.po_get_global_barrier.restype = C.c_double
+    L.po_get_global_barrier.argtypes = [C.c_void_p]
+    L.po_cumulative_barrier.restype = C.c_double
+    L.po_cumulative_barrier.argtypes = [C.c_void_p, C.c_double]
+    L.po_get_step_size.restype = C.c_double
+    L.po_get_step_size.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def _up(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+class OracleRng:
+    """SplittableRandom + Julia samplers (for RNG parity tests)."""
+
+    def __init__(self, seed=None, state=None):
+        self.L = lib()
+        self.r = self.L.po_rng_new(seed) if state is None else Rng(*state)
+
+    def next_u64(self):
+        return self.L.po_rng_next_u64(C.byref(self.r))
+
+    def split(self):
+        c = self.L.po_rng_split(C.byref(self.r))
+        return OracleRng(state=(c.seed, c.gamma))
+
+    def rand(self):
+        return self.L.po_rand(C.byref(self.r))
+
+    def randn(self):
+        return self.L.po_randn(C.byref(self.r))
+
+    def randexp(self):
+        return self.L.po_randexp(C.byref(self.r))
+
+    @property
+    def state(self):
+        return (self.r.seed, self.r.gamma)
+
+
+class OraclePT:
+    """The reference's `pigeons()` loop restated on the CPU."""
+
+    def __init__(self, **kw):
+        self.L = lib()
+        self.cfg = Config()
+        self.L.po_default_config(C.byref(self.cfg))
+        for k, v in kw.items():
+            if not hasattr(self.cfg, k):
+                raise AttributeError(k)
+            setattr(self.cfg, k, v)
+        self.h = self.L.po_create(C.byref(self.cfg))
+        self.N = int(self.cfg.n_chains)
+        self.d = 0 if self.cfg.target == TARGET_TEST_SWAPPER else int(self.cfg.dim)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.po_destroy(self.h)
+            self.h = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.L.po_last_error(self.h).decode())
+
+    def run_round(self):
+        self._chk(self.L.po_run_round(self.h))
+
+    def begin_round(self):
+        self._chk(self.L.po_begin_round(self.h))
+
+    def run_scans(self, n):
+        self._chk(self.L.po_run_scans(self.h, n))
+
+    def end_round(self):
+        self._chk(self.L.po_end_round(self.h))
+
+    @property
+    def round(self):
+        return int(self.L.po_round(self.h))
+
+    def states(self):
+        x = np.zeros((self.N, max(self.d, 1)))
+        chain = np.zeros(self.N, dtype=np.int64)
+        rng = np.zeros((self.N, 2), dtype=np.uint64)
+        self.L.po_get_states(self.h, _dp(x), _ip(chain), _up(rng))
+        return x[:, :self.d], chain, rng
+
+    def schedule(self):
+        b = np.zeros(self.N)
+        self.L.po_get_schedule(self.h, _dp(b))
+        return b
+
+    def set_schedule(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        self.L.po_set_schedule(self.h, _dp(b))
+
+    def swap_pr(self):
+        m = np.zeros(max(self.N - 1, 1)); n = np.zeros(max(self.N - 1, 1), dtype=np.int64)
+        self.L.po_get_swap_pr(self.h, _dp(m), _ip(n))
+        return m[:self.N - 1], n[:self.N - 1]
+
+    def log_sum_ratio(self):
+        k = max(self.N - 1, 1)
+        up = np.zeros(k); dn = np.zeros(k)
+        un = np.zeros(k, dtype=np.int64); dnn = np.zeros(k, dtype=np.int64)
+        self.L.po_get_log_sum_ratio(self.h, _dp(up), _ip(un), _dp(dn), _ip(dnn))
+        return up[:self.N - 1], un[:self.N - 1], dn[:self.N - 1], dnn[:self.N - 1]
+
+    def round_trip(self):
+        a = np.zeros(1, dtype=np.int64); b = np.zeros(1, dtype=np.int64)
+        self.L.po_get_round_trip(self.h, _ip(a), _ip(b))
+        return int(a[0]), int(b[0])   # (n_tempered_restarts, n_round_trips)
+
+    def index_process(self):
+        n = int(self.L.po_get_index_process(self.h, None))
+        out = np.zeros((self.N, n), dtype=np.int64)
+        self.L.po_get_index_process(self.h, _ip(out))
+        return out
+
+    def explorer_stats(self):
+        am = np.zeros(self.N); sn = np.zeros(self.N)
+        an = np.zeros(self.N, dtype=np.int64); ssn = np.zeros(self.N, dtype=np.int64)
+        self.L.po_get_explorer_stats(self.h, _dp(am), _ip(an), _dp(sn), _ip(ssn))
+        return am, an, sn, ssn
+
+    def am_stats(self):
+        fm = np.zeros(self.N); rm = np.zeros(self.N)
+        fn = np.zeros(self.N, dtype=np.int64); rn = np.zeros(self.N, dtype=np.int64)
+        self.L.po_get_am_stats(self.h, _dp(fm), _ip(fn), _dp(rm), _ip(rn))
+        return fm, fn, rm, rn
+
+    def online(self):
+        m = np.zeros(max(self.d, 1)); v = np.zeros(max(self.d, 1))
+        n = self.L.po_get_online(self.h, _dp(m), _dp(v))
+        return m[:self.d], v[:self.d], int(n)
+
+    def stepping_stone_pair(self):
+        p = np.zeros(2)
+        self.L.po_get_stepping_stone(self.h, _dp(p))
+        return float(p[0]), float(p[1])
+
+    def global_barrier(self):
+        return float(self.L.po_get_global_barrier(self.h))
+
+    def cumulative_barrier(self, beta):
+        return float(self.L.po_cumulative_barrier(self.h, beta))
+
+    def step_size(self):
+        return float(self.L.po_get_step_size(self.h))
