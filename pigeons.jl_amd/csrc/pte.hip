@@ -1,0 +1,554 @@
+// pte.hip -- host side of the C ABI declared in include/pte.h (libpte.so).
+// Owns device memory, one HIP stream per engine, launches the kernels of pte_kernels.hpp.
+// There is no CPU fallback: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pte.h"
+#include "pte_kernels.hpp"
+
+using namespace pte;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Snapshot {   // reduced recorders of the last round, host side
+    std::vector<double> swap_mean; std::vector<int64_t> swap_n;
+    std::vector<double> lsr_up, lsr_dn; std::vector<int64_t> lsr_n;
+    int64_t restarts = 0, trips = 0;
+    std::vector<double> acc_mean, steps_sum; std::vector<int64_t> acc_n, steps_n;
+    std::vector<double> on_mean, on_var; int64_t on_n = 0;
+    std::vector<int64_t> index_process; int64_t n_scans = 0;
+};
+
+}  // namespace
+
+struct pte_engine {
+    pte_config cfg{};
+    EngineDev dev{};
+    hipStream_t stream = nullptr;
+    int nlu = 0;
+    int64_t N = 0, d = 0;
+    std::vector<double> betas;
+    std::vector<void *> allocs;
+    double *d_nhp = nullptr, *d_sd = nullptr;
+    int64_t scans_in_round = 0;      // scans run since the last pte_reduce
+    Snapshot snap;
+    std::string err;
+    // timing
+    bool timing = false;
+    struct Ev { hipEvent_t a, b; int kernel; };
+    std::vector<Ev> events;
+    double t_ms[2] = {0, 0};
+    int64_t t_n[2] = {0, 0};
+};
+
+namespace {
+
+int fail(pte_engine *h, const char *fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return 1;
+}
+#define HIP_OK(h, call)                                                                          \
+    do { hipError_t e_ = (call);                                                                 \
+         if (e_ != hipSuccess) return fail(h, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+template <typename T>
+int dev_alloc(pte_engine *h, T **p, size_t n, bool zero = true) {
+    void *q = nullptr;
+    size_t bytes = sizeof(T) * (n ? n : 1);
+    HIP_OK(h, hipMalloc(&q, bytes));
+    h->allocs.push_back(q);
+    if (zero) HIP_OK(h, hipMemsetAsync(q, 0, bytes, h->stream));
+    *p = (T *)q;
+    return 0;
+}
+
+int next_pow2_log(int64_t n) { int l = 0; while (((int64_t)1 << l) < n) ++l; return l; }
+
+#define DISPATCH_NLU(nlu, KERNEL, grid, block, stream, ...)                                      \
+    switch (nlu) {                                                                               \
+    case 0: hipLaunchKernelGGL(KERNEL<0>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    case 1: hipLaunchKernelGGL(KERNEL<1>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    case 3: hipLaunchKernelGGL(KERNEL<3>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    case 5: hipLaunchKernelGGL(KERNEL<5>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    default: hipLaunchKernelGGL(KERNEL<6>, grid, block, 0, stream, __VA_ARGS__); break;          \
+    }
+
+// discretize(path, schedule): per-chain constants of ScaledPrecisionNormalLogPotential
+// (reference src/paths/ScaledPrecisionNormalPath.jl:45-48, src/schedules/discretize.jl:6-7).
+int upload_ladder(pte_engine *h) {
+    const int64_t N = h->N;
+    std::vector<double> nhp(N, 0.0), sd(N, 1.0);
+    if (h->cfg.target == PTE_TARGET_MVN_SCALED_PRECISION) {
+        const double p0 = h->cfg.target_params[0], p1 = h->cfg.target_params[1];
+        for (int64_t c = 0; c < N; ++c) {
+            const double beta = h->betas[c];
+            const double prec = (1.0 - beta) * p0 + beta * p1;
+            nhp[c] = -0.5 * prec;
+            sd[c] = std::sqrt(prec);
+        }
+    }
+    HIP_OK(h, hipMemcpyAsync(h->d_nhp, nhp.data(), sizeof(double) * N, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipMemcpyAsync(h->d_sd, sd.data(), sizeof(double) * N, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int reset_recorders(pte_engine *h) {
+    EngineDev &e = h->dev;
+    const int64_t N = h->N, np = N > 1 ? N - 1 : 1;
+    HIP_OK(h, hipMemsetAsync(e.swap_sum, 0, sizeof(double) * np, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.swap_n, 0, sizeof(int64_t) * np, h->stream));
+    std::vector<double> ninf(np, -INFINITY);
+    HIP_OK(h, hipMemcpyAsync(e.lsr_up, ninf.data(), sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipMemcpyAsync(e.lsr_dn, ninf.data(), sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.lsr_n, 0, sizeof(int64_t) * np, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.rt_state, 0, sizeof(int64_t) * N, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.rt_restarts, 0, sizeof(int64_t) * N, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.rt_trips, 0, sizeof(int64_t) * N, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.expl_acc_sum, 0, sizeof(double) * N, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.expl_acc_n, 0, sizeof(int64_t) * N, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.expl_steps_sum, 0, sizeof(double) * N, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.expl_steps_n, 0, sizeof(int64_t) * N, h->stream));
+    const int64_t dd = h->d > 0 ? h->d : 1;
+    HIP_OK(h, hipMemsetAsync(e.on_mean, 0, sizeof(double) * dd, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.on_m2, 0, sizeof(double) * dd, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.on_n, 0, sizeof(int64_t), h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));   // `ninf` must outlive the copies
+    h->scans_in_round = 0;
+    return 0;
+}
+
+int check_device_error(pte_engine *h) {
+    int32_t err[4] = {0, 0, 0, 0};
+    HIP_OK(h, hipMemcpyAsync(err, h->dev.error, sizeof err, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    if (err[0] == ERR_NONE) return 0;
+    HIP_OK(h, hipMemsetAsync(h->dev.error, 0, sizeof err, h->stream));
+    switch (err[0]) {
+    case ERR_NAN_RATIO: return fail(h, "Got NaN log-unnormalized ratio (chain %d)", err[1]);
+    case ERR_SLICE_SUPPORT: return fail(h, "SliceSampler supports contrained target, but the sampler should be initialized in the support (chain %d)", err[1]);
+    case ERR_SLICE_INVALID_LP: return fail(h, "Got an invalid log density after updating state at index %d (chain %d)", err[2], err[1]);
+    case ERR_SLICE_MAX_ITER: return fail(h, "Maximum number of iterations reached in slice_shrink! (chain %d, index %d)", err[1], err[2]);
+    default: return fail(h, "device error %d", err[0]);
+    }
+}
+
+void time_begin(pte_engine *h, int kernel) {
+    if (!h->timing) return;
+    pte_engine::Ev ev; ev.kernel = kernel;
+    hipEventCreate(&ev.a); hipEventCreate(&ev.b);
+    hipEventRecord(ev.a, h->stream);
+    h->events.push_back(ev);
+}
+void time_end(pte_engine *h) {
+    if (!h->timing) return;
+    hipEventRecord(h->events.back().b, h->stream);
+}
+void time_collect(pte_engine *h) {
+    for (auto &ev : h->events) {
+        float ms = 0.f;
+        hipEventSynchronize(ev.b);
+        hipEventElapsedTime(&ms, ev.a, ev.b);
+        h->t_ms[ev.kernel] += ms; h->t_n[ev.kernel] += 1;
+        hipEventDestroy(ev.a); hipEventDestroy(ev.b);
+    }
+    h->events.clear();
+}
+
+int launch_explore(pte_engine *h, int64_t scan) {
+    (void)scan;
+    const int64_t N = h->N;
+    switch (h->cfg.explorer) {
+    case PTE_EXPLORER_NONE: return 0;
+    case PTE_EXPLORER_TOY:
+        time_begin(h, 0);
+        DISPATCH_NLU(h->nlu, k_explore_toy, dim3((unsigned)N), dim3(64), h->stream, h->dev);
+        time_end(h);
+        break;
+    case PTE_EXPLORER_SLICE: {
+        SliceParams sp{h->cfg.slice_w, h->cfg.slice_p, h->cfg.slice_n_passes, h->cfg.slice_max_iter};
+        time_begin(h, 0);
+        DISPATCH_NLU(h->nlu, k_explore_slice, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
+        time_end(h);
+        break;
+    }
+    default: return fail(h, "explorer %d is not implemented on the device", h->cfg.explorer);
+    }
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+
+int launch_swap(pte_engine *h, int64_t scan) {
+    const int64_t N = h->N;
+    if ((h->cfg.record_flags & PTE_RECORD_INDEX_PROCESS) && h->scans_in_round >= h->cfg.max_scans_per_round)
+        return fail(h, "index_process buffer full: %lld scans since the last pte_reduce (max_scans_per_round = %lld)",
+                    (long long)h->scans_in_round, (long long)h->cfg.max_scans_per_round);
+    const int even = (scan % 2 == 0) ? 1 : 0;          // create_swap_graph(::DEO), DEO.jl:12
+    const unsigned block = 256, grid = (unsigned)((N + block - 1) / block);
+    time_begin(h, 1);
+    hipLaunchKernelGGL(k_swap, dim3(grid), dim3(block), 0, h->stream, h->dev, even, h->scans_in_round);
+    time_end(h);
+    HIP_OK(h, hipGetLastError());
+    h->scans_in_round += 1;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pte_default_config(pte_config *c) {
+    if (!c) return 1;
+    std::memset(c, 0, sizeof *c);
+    c->struct_size = sizeof(pte_config);
+    c->abi_version = PTE_ABI_VERSION;
+    c->device = 0;
+    c->target = PTE_TARGET_MVN_SCALED_PRECISION;
+    c->explorer = PTE_EXPLORER_TOY;
+    c->record_flags = PTE_RECORD_ROUND_TRIP | PTE_RECORD_INDEX_PROCESS;
+    c->n_chains = 10; c->dim = 2; c->seed = 1;
+    c->max_scans_per_round = 1024;
+    c->target_params[0] = 1.0; c->target_params[1] = 10.0;
+    c->slice_w = 10.0; c->slice_p = 20; c->slice_n_passes = 3; c->slice_max_iter = 1024;
+    c->am_base_n_refresh = 3; c->am_exponent_n_refresh = 0.35; c->am_step_size = 1.0;
+    c->am_p0 = 1.0 / 3.0; c->am_p1 = 1.0 / 3.0; c->am_preconditioner = 2;
+    c->rank = 0; c->world_size = 1;
+    return 0;
+}
+
+const char *pte_last_error(const pte_engine *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int pte_create(const pte_config *cfg, pte_engine **out) {
+    if (!cfg || !out) return fail(nullptr, "pte_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(pte_config) || cfg->abi_version != PTE_ABI_VERSION)
+        return fail(nullptr, "pte_create: ABI mismatch (struct_size %u vs %zu, version %u vs %d)",
+                    cfg->struct_size, sizeof(pte_config), cfg->abi_version, PTE_ABI_VERSION);
+    if (cfg->n_chains < 1) return fail(nullptr, "pte_create: n_chains must be >= 1");
+    if (cfg->world_size != 1) return fail(nullptr, "pte_create: world_size > 1 is driven by the host-side sharding layer");
+    const bool swapper = cfg->target == PTE_TARGET_TEST_SWAPPER;
+    if (!swapper && cfg->target != PTE_TARGET_MVN_SCALED_PRECISION)
+        return fail(nullptr, "pte_create: target %d has no device log-potential; use the reference CPU path", cfg->target);
+    if (!swapper && (cfg->dim < 1 || cfg->dim > 4096))
+        return fail(nullptr, "pte_create: dim must be in 1..4096 (got %lld)", (long long)cfg->dim);
+    if (swapper && cfg->explorer != PTE_EXPLORER_NONE)
+        return fail(nullptr, "pte_create: TestSwapper has no explorer");
+    if (!swapper && cfg->explorer != PTE_EXPLORER_TOY && cfg->explorer != PTE_EXPLORER_SLICE)
+        return fail(nullptr, "pte_create: explorer %d is not implemented on the device", cfg->explorer);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, "pte_create: no HIP device available (this library has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, "pte_create: bad device ordinal %d", cfg->device);
+
+    pte_engine *h = new pte_engine();
+    h->cfg = *cfg;
+    const int64_t N = h->N = cfg->n_chains;
+    const int64_t d = h->d = swapper ? 0 : cfg->dim;
+    auto bail = [&](int) { g_create_error = h->err; pte_destroy(h); return 1; };
+    if (hipSetDevice(cfg->device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(1); }
+    if (hipStreamCreate(&h->stream) != hipSuccess) { h->err = "hipStreamCreate failed"; return bail(1); }
+    const int64_t B = (d + 63) / 64;
+    h->nlu = next_pow2_log(B > 0 ? B : 1);
+    EngineDev &e = h->dev;
+    e.N = N; e.d = d; e.ld = (d + 1) & ~(int64_t)1;
+    e.record_flags = cfg->record_flags; e.target = cfg->target; e.test_swapper_pr = cfg->target_params[0];
+    const int64_t np = N > 1 ? N - 1 : 1, dd = d > 0 ? d : 1;
+    int rc = 0;
+    rc |= dev_alloc(h, &e.x, (size_t)(N * (e.ld > 0 ? e.ld : 1)));
+    rc |= dev_alloc(h, &e.rng, (size_t)(2 * N));
+    rc |= dev_alloc(h, &e.chain_of_slot, (size_t)N);
+    rc |= dev_alloc(h, &e.slot_of_chain, (size_t)N);
+    rc |= dev_alloc(h, &e.suff, (size_t)N);
+    rc |= dev_alloc(h, &h->d_nhp, (size_t)N);
+    rc |= dev_alloc(h, &h->d_sd, (size_t)N);
+    rc |= dev_alloc(h, &e.swap_sum, (size_t)np);  rc |= dev_alloc(h, &e.swap_n, (size_t)np);
+    rc |= dev_alloc(h, &e.lsr_up, (size_t)np);    rc |= dev_alloc(h, &e.lsr_dn, (size_t)np);
+    rc |= dev_alloc(h, &e.lsr_n, (size_t)np);
+    rc |= dev_alloc(h, &e.rt_state, (size_t)N);   rc |= dev_alloc(h, &e.rt_restarts, (size_t)N);
+    rc |= dev_alloc(h, &e.rt_trips, (size_t)N);
+    rc |= dev_alloc(h, &e.expl_acc_sum, (size_t)N);   rc |= dev_alloc(h, &e.expl_acc_n, (size_t)N);
+    rc |= dev_alloc(h, &e.expl_steps_sum, (size_t)N); rc |= dev_alloc(h, &e.expl_steps_n, (size_t)N);
+    rc |= dev_alloc(h, &e.on_mean, (size_t)dd);   rc |= dev_alloc(h, &e.on_m2, (size_t)dd);
+    rc |= dev_alloc(h, &e.on_n, 1);
+    const int64_t ipcap = (cfg->record_flags & PTE_RECORD_INDEX_PROCESS) ? cfg->max_scans_per_round * N : 1;
+    rc |= dev_alloc(h, &e.index_process, (size_t)ipcap, false);
+    rc |= dev_alloc(h, &e.error, 4);
+    if (rc) return bail(1);
+    e.nhp = h->d_nhp; e.sd = h->d_sd;
+
+    // equally_spaced_schedule (reference src/schedules/Schedule.jl:36-44)
+    h->betas.resize(N);
+    if (N == 1) h->betas[0] = 1.0;
+    else for (int64_t i = 0; i < N; ++i) h->betas[i] = (i == N - 1) ? 1.0 : (double)i / (double)(N - 1);
+    if (upload_ladder(h)) return bail(1);
+    if (reset_recorders(h)) return bail(1);
+    const double init_sd = swapper ? 1.0 : std::sqrt(cfg->target_params[1]);   // toy_mvn_target.jl:10-11
+    DISPATCH_NLU(h->nlu, k_init, dim3((unsigned)N), dim3(64), h->stream, e, (uint64_t)cfg->seed, init_sd);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
+        h->err = "k_init launch failed"; return bail(1);
+    }
+    *out = h;
+    return 0;
+}
+
+int pte_destroy(pte_engine *h) {
+    if (!h) return 0;
+    hipSetDevice(h->cfg.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    time_collect(h);
+    for (void *p : h->allocs) hipFree(p);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int pte_set_schedule(pte_engine *h, const double *betas, int64_t n) {
+    if (!h || !betas) return 1;
+    if (n != h->N) return fail(h, "pte_set_schedule: expected %lld grid points, got %lld", (long long)h->N, (long long)n);
+    // Schedule constructor asserts (reference src/schedules/Schedule.jl:14-27)
+    if (n == 1) { if (betas[0] != 1.0) return fail(h, "Invalid schedule"); }
+    else {
+        if (betas[0] != 0.0 || betas[n - 1] != 1.0) return fail(h, "Invalid schedule: end points must be 0 and 1");
+        for (int64_t i = 0; i + 1 < n; ++i) if (!(betas[i] < betas[i + 1])) return fail(h, "Invalid schedule: not strictly increasing");
+    }
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    h->betas.assign(betas, betas + n);
+    return upload_ladder(h);
+}
+
+int pte_get_schedule(const pte_engine *h, double *betas) {
+    if (!h || !betas) return 1;
+    std::memcpy(betas, h->betas.data(), sizeof(double) * h->N);
+    return 0;
+}
+
+int pte_set_explorer_adaptation(pte_engine *h, double step_size, const double *target_std, int64_t dim) {
+    (void)step_size; (void)target_std; (void)dim;
+    if (!h) return 1;
+    if (h->cfg.explorer != PTE_EXPLORER_AUTOMALA) return 0;   // nothing to adapt for SliceSampler / ToyExplorer
+    return fail(h, "AutoMALA is not implemented on the device yet");
+}
+
+int pte_explore(pte_engine *h, int64_t scan) {
+    if (!h) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    if (launch_explore(h, scan)) return 1;
+    return check_device_error(h);
+}
+
+int pte_swap(pte_engine *h, int64_t scan) {
+    if (!h) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    if (launch_swap(h, scan)) return 1;
+    return check_device_error(h);
+}
+
+int pte_run_scans(pte_engine *h, int64_t first_scan, int64_t n_scans) {
+    if (!h) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    for (int64_t s = first_scan; s < first_scan + n_scans; ++s) {
+        if (launch_explore(h, s)) return 1;
+        if (launch_swap(h, s)) return 1;
+    }
+    int rc = check_device_error(h);
+    time_collect(h);
+    return rc;
+}
+
+int pte_reduce(pte_engine *h) {
+    if (!h) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    const int64_t N = h->N, np = N > 1 ? N - 1 : 1, d = h->d;
+    EngineDev &e = h->dev;
+    Snapshot &s = h->snap;
+    std::vector<double> swap_sum(np);
+    s.swap_mean.assign(np, 0.0); s.swap_n.assign(np, 0);
+    s.lsr_up.assign(np, 0.0); s.lsr_dn.assign(np, 0.0); s.lsr_n.assign(np, 0);
+    std::vector<int64_t> rs(N), rr(N);
+    std::vector<double> acc_sum(N);
+    s.acc_mean.assign(N, 0.0); s.acc_n.assign(N, 0); s.steps_sum.assign(N, 0.0); s.steps_n.assign(N, 0);
+    const int64_t dd = d > 0 ? d : 1;
+    std::vector<double> m2(dd);
+    s.on_mean.assign(dd, 0.0); s.on_var.assign(dd, 0.0);
+#define D2H(dst, src, n) HIP_OK(h, hipMemcpyAsync(dst, src, sizeof(*(dst)) * (n), hipMemcpyDeviceToHost, h->stream))
+    D2H(swap_sum.data(), e.swap_sum, np); D2H(s.swap_n.data(), e.swap_n, np);
+    D2H(s.lsr_up.data(), e.lsr_up, np);   D2H(s.lsr_dn.data(), e.lsr_dn, np);   D2H(s.lsr_n.data(), e.lsr_n, np);
+    D2H(rs.data(), e.rt_restarts, N);     D2H(rr.data(), e.rt_trips, N);
+    D2H(acc_sum.data(), e.expl_acc_sum, N); D2H(s.acc_n.data(), e.expl_acc_n, N);
+    D2H(s.steps_sum.data(), e.expl_steps_sum, N); D2H(s.steps_n.data(), e.expl_steps_n, N);
+    D2H(s.on_mean.data(), e.on_mean, dd); D2H(m2.data(), e.on_m2, dd); D2H(&s.on_n, e.on_n, 1);
+    s.n_scans = h->scans_in_round;
+    std::vector<int32_t> ip;
+    if (h->cfg.record_flags & PTE_RECORD_INDEX_PROCESS) {
+        ip.resize((size_t)(s.n_scans * N));
+        if (!ip.empty()) D2H(ip.data(), e.index_process, (size_t)(s.n_scans * N));
+    }
+#undef D2H
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < np; ++i) s.swap_mean[i] = s.swap_n[i] > 0 ? swap_sum[i] / (double)s.swap_n[i] : 0.0;
+    s.restarts = 0; s.trips = 0;
+    for (int64_t i = 0; i < N; ++i) { s.restarts += rs[i]; s.trips += rr[i]; }
+    for (int64_t i = 0; i < N; ++i) s.acc_mean[i] = s.acc_n[i] > 0 ? acc_sum[i] / (double)s.acc_n[i] : 0.0;
+    for (int64_t i = 0; i < dd; ++i) s.on_var[i] = s.on_n > 1 ? m2[i] / (double)(s.on_n - 1) : 1.0;
+    s.index_process.assign((size_t)(s.n_scans * N), 0);
+    for (int64_t t = 0; t < s.n_scans && !ip.empty(); ++t)
+        for (int64_t r = 0; r < N; ++r) s.index_process[(size_t)(r * s.n_scans + t)] = ip[(size_t)(t * N + r)];
+    return reset_recorders(h);
+}
+
+int pte_get_swap_acceptance(const pte_engine *h, double *mean, int64_t *n) {
+    if (!h) return 1;
+    for (int64_t i = 0; i + 1 < h->N; ++i) { mean[i] = h->snap.swap_mean[i]; n[i] = h->snap.swap_n[i]; }
+    return 0;
+}
+int pte_get_log_sum_ratio(const pte_engine *h, double *up, int64_t *up_n, double *dn, int64_t *dn_n) {
+    if (!h) return 1;
+    for (int64_t i = 0; i + 1 < h->N; ++i) {
+        up[i] = h->snap.lsr_up[i]; dn[i] = h->snap.lsr_dn[i];
+        up_n[i] = h->snap.lsr_n[i]; dn_n[i] = h->snap.lsr_n[i];
+    }
+    return 0;
+}
+int pte_get_round_trip(const pte_engine *h, int64_t *restarts, int64_t *trips) {
+    if (!h) return 1;
+    *restarts = h->snap.restarts; *trips = h->snap.trips;
+    return 0;
+}
+int pte_get_index_process(const pte_engine *h, int64_t *out, int64_t *n_scans) {
+    if (!h) return 1;
+    if (n_scans) *n_scans = h->snap.n_scans;
+    if (out && !h->snap.index_process.empty())
+        std::memcpy(out, h->snap.index_process.data(), sizeof(int64_t) * h->snap.index_process.size());
+    return 0;
+}
+int pte_get_explorer_stats(const pte_engine *h, double *am, int64_t *an, double *ss, int64_t *sn) {
+    if (!h) return 1;
+    for (int64_t i = 0; i < h->N; ++i) {
+        am[i] = h->snap.acc_mean[i]; an[i] = h->snap.acc_n[i];
+        ss[i] = h->snap.steps_sum[i]; sn[i] = h->snap.steps_n[i];
+    }
+    return 0;
+}
+int pte_get_automala_stats(const pte_engine *h, double *fm, int64_t *fn, double *rm, int64_t *rn) {
+    if (!h) return 1;
+    for (int64_t i = 0; i < h->N; ++i) { fm[i] = 0; fn[i] = 0; rm[i] = 0; rn[i] = 0; }
+    return 0;
+}
+int pte_get_online(const pte_engine *h, double *mean, double *variance, int64_t *n) {
+    if (!h) return 1;
+    for (int64_t i = 0; i < h->d; ++i) { mean[i] = h->snap.on_mean[i]; variance[i] = h->snap.on_var[i]; }
+    if (n) *n = h->snap.on_n;
+    return 0;
+}
+
+int pte_get_state(const pte_engine *hc, double *state, int64_t *chain, uint64_t *rng) {
+    pte_engine *h = const_cast<pte_engine *>(hc);
+    if (!h) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    const int64_t N = h->N, d = h->d;
+    if (state && d > 0)
+        HIP_OK(h, hipMemcpy2DAsync(state, sizeof(double) * d, h->dev.x, sizeof(double) * h->dev.ld,
+                                   sizeof(double) * d, N, hipMemcpyDeviceToHost, h->stream));
+    std::vector<int32_t> ch(N);
+    if (chain) HIP_OK(h, hipMemcpyAsync(ch.data(), h->dev.chain_of_slot, sizeof(int32_t) * N, hipMemcpyDeviceToHost, h->stream));
+    if (rng) HIP_OK(h, hipMemcpyAsync(rng, h->dev.rng, sizeof(uint64_t) * 2 * N, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    if (chain) for (int64_t i = 0; i < N; ++i) chain[i] = ch[i];
+    return 0;
+}
+
+int pte_set_state(pte_engine *h, const double *state, const int64_t *chain, const uint64_t *rng) {
+    if (!h) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    const int64_t N = h->N, d = h->d;
+    if (state && d > 0)
+        HIP_OK(h, hipMemcpy2DAsync(h->dev.x, sizeof(double) * h->dev.ld, state, sizeof(double) * d,
+                                   sizeof(double) * d, N, hipMemcpyHostToDevice, h->stream));
+    std::vector<int32_t> ch(N), inv(N, -1);
+    if (chain) {
+        for (int64_t i = 0; i < N; ++i) {
+            if (chain[i] < 0 || chain[i] >= N || inv[chain[i]] != -1) return fail(h, "pte_set_state: chain is not a permutation");
+            ch[i] = (int32_t)chain[i]; inv[chain[i]] = (int32_t)i;
+        }
+        HIP_OK(h, hipMemcpyAsync(h->dev.chain_of_slot, ch.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice, h->stream));
+        HIP_OK(h, hipMemcpyAsync(h->dev.slot_of_chain, inv.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice, h->stream));
+    }
+    if (rng) HIP_OK(h, hipMemcpyAsync(h->dev.rng, rng, sizeof(uint64_t) * 2 * N, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    if (state && d > 0) {   // refresh the swap statistic of every slot
+        std::vector<double> suff(N);
+        std::vector<double> row(d);
+        double *tmp = nullptr;
+        HIP_OK(h, hipMalloc((void **)&tmp, sizeof(double) * N * d));
+        HIP_OK(h, hipMemcpy(tmp, state, sizeof(double) * N * d, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_test_sqr_norm, dim3((unsigned)N), dim3(64), 0, h->stream, tmp, N, d, h->nlu, h->dev.suff);
+        hipError_t e1 = hipStreamSynchronize(h->stream);
+        hipFree(tmp);
+        HIP_OK(h, e1);
+    }
+    return 0;
+}
+
+int pte_timing_reset(pte_engine *h, int enable) {
+    if (!h) return 1;
+    hipSetDevice(h->cfg.device);
+    hipStreamSynchronize(h->stream);
+    time_collect(h);
+    h->timing = enable != 0;
+    h->t_ms[0] = h->t_ms[1] = 0.0; h->t_n[0] = h->t_n[1] = 0;
+    return 0;
+}
+int pte_timing_get(const pte_engine *hc, int kernel, double *total_ms, int64_t *launches) {
+    pte_engine *h = const_cast<pte_engine *>(hc);
+    if (!h || kernel < 0 || kernel > 1) return 1;
+    hipSetDevice(h->cfg.device);
+    hipStreamSynchronize(h->stream);
+    time_collect(h);
+    if (total_ms) *total_ms = h->t_ms[kernel];
+    if (launches) *launches = h->t_n[kernel];
+    return 0;
+}
+
+int pte_test_rng_fill(int32_t device, uint64_t *sg, int32_t kind, int64_t n, double *out) {
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, "pte_test_rng_fill: no HIP device");
+    uint64_t *d_sg = nullptr; double *d_out = nullptr;
+    if (hipMalloc((void **)&d_sg, 16) != hipSuccess || hipMalloc((void **)&d_out, sizeof(double) * (n ? n : 1)) != hipSuccess)
+        return fail(nullptr, "pte_test_rng_fill: hipMalloc failed");
+    hipMemcpy(d_sg, sg, 16, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_test_rng, dim3(1), dim3(64), 0, 0, d_sg, (int)kind, n, d_out);
+    hipError_t e = hipDeviceSynchronize();
+    hipMemcpy(sg, d_sg, 16, hipMemcpyDeviceToHost);
+    hipMemcpy(out, d_out, sizeof(double) * n, hipMemcpyDeviceToHost);
+    hipFree(d_sg); hipFree(d_out);
+    return e == hipSuccess ? 0 : fail(nullptr, "pte_test_rng_fill: %s", hipGetErrorString(e));
+}
+
+int pte_test_sqr_norm(int32_t device, const double *x, int64_t rows, int64_t d, double *out) {
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, "pte_test_sqr_norm: no HIP device");
+    if (d < 1 || d > 4096) return fail(nullptr, "pte_test_sqr_norm: d must be in 1..4096");
+    double *dx = nullptr, *dout = nullptr;
+    if (hipMalloc((void **)&dx, sizeof(double) * rows * d) != hipSuccess || hipMalloc((void **)&dout, sizeof(double) * rows) != hipSuccess)
+        return fail(nullptr, "pte_test_sqr_norm: hipMalloc failed");
+    hipMemcpy(dx, x, sizeof(double) * rows * d, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_test_sqr_norm, dim3((unsigned)rows), dim3(64), 0, 0, dx, rows, d, next_pow2_log((d + 63) / 64), dout);
+    hipError_t e = hipDeviceSynchronize();
+    hipMemcpy(out, dout, sizeof(double) * rows, hipMemcpyDeviceToHost);
+    hipFree(dx); hipFree(dout);
+    return e == hipSuccess ? 0 : fail(nullptr, "pte_test_sqr_norm: %s", hipGetErrorString(e));
+}
+
+}  // extern "C"

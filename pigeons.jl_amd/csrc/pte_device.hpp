@@ -1,0 +1,194 @@
+// pte_device.hpp -- gfx950 device helpers: per-replica counter-based RNG streams,
+// Julia-compatible samplers evaluated wave-parallel, and the fixed pairwise
+// reduction tree shared by every kernel.
+//
+// One wavefront (64 lanes) owns one replica.  "Uniform" below means: the value is
+// identical in all 64 lanes (the compiler may or may not keep it in SGPRs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ZIG_TABLE_ATTR __device__
+#include "zig_tables.h"
+
+namespace pte {
+
+constexpr uint64_t MASK52 = 0x000fffffffffffffULL;
+
+// ---- SplittableRandom (SplittableRandoms.jl 0.1 == Java SplittableRandom) --------------------
+// The k-th output of a stream is mix64(seed0 + k*gamma): counter based, so 64 lanes can
+// evaluate 64 consecutive draws of ONE replica's stream in one shot.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint64_t mix_gamma(uint64_t z) {
+    z = (z ^ (z >> 33)) * 0xff51afd7ed558ccdULL;
+    z = (z ^ (z >> 33)) * 0xc4ceb9fe1a85ec53ULL;
+    z = (z ^ (z >> 33)) | 1ULL;
+    int n = __popcll(z ^ (z >> 1));
+    return (n < 24) ? (z ^ 0xaaaaaaaaaaaaaaaaULL) : z;
+}
+// rand(rng)::Float64 of Julia's generic AbstractRNG path: [1,2) from the low 52 bits, minus 1.
+__device__ __forceinline__ double u52_to_unit(uint64_t u) {
+    return __longlong_as_double((long long)((u & MASK52) | 0x3ff0000000000000ULL)) - 1.0;
+}
+
+// ---- cross-lane helpers -----------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+__device__ __forceinline__ double readlane_f64(double v, int lane /*uniform*/) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane /*uniform*/) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+
+// ---- the fixed reduction tree -----------------------------------------------------------------
+// sqr_norm(x) (reference src/utils/misc.jl:10) is evaluated as the balanced binary tree over the
+// leaves x_i^2 in natural order, zero padded to a power of two: node[i] = node[2i] + node[2i+1].
+// With lane l holding leaf (64*b + l) of block b, the six in-block levels are an xor butterfly:
+// after level k every lane holds the sum of its 2^(k+1)-aligned group (a+b == b+a bitwise, so both
+// partners agree).  U[k] = node values of level k (U[0] = leaves), U[6] = block sum.
+__device__ __forceinline__ void butterfly6(double leaf, double (&U)[7]) {
+    U[0] = leaf;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) U[k + 1] = U[k] + shfl_xor_f64(U[k], 1 << k);
+}
+__device__ __forceinline__ double wave_tree_sum64(double leaf) {
+    double v = leaf;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v = v + shfl_xor_f64(v, 1 << k);
+    return v;
+}
+// Root of the tree over the block sums: lane b holds block sum b (0 for b >= B).  NLU = log2 of
+// the padded block count.  Result uniform.
+template <int NLU>
+__device__ __forceinline__ double upper_tree_root(double bs) {
+    double v = bs;
+#pragma unroll
+    for (int q = 0; q < NLU; ++q) v = v + shfl_xor_f64(v, 1 << q);
+    return readlane_f64(v, 0);
+}
+__device__ __forceinline__ double upper_tree_root_dyn(double bs, int nlu) {
+    double v = bs;
+    for (int q = 0; q < nlu; ++q) v = v + shfl_xor_f64(v, 1 << q);
+    return readlane_f64(v, 0);
+}
+
+// ---- sequential (uniform) stream: used on slow paths and for single draws ---------------------
+struct SeqRng {
+    uint64_t seed, gamma;   // uniform
+    __device__ __forceinline__ uint64_t next() { seed += gamma; return mix64(seed); }
+    __device__ __forceinline__ double rand() { return u52_to_unit(next()); }
+};
+
+// randn slow path (Julia Random/src/normal.jl `randn_unlikely`), given the failed first draw.
+__device__ inline double randn_seq(SeqRng &r);
+__device__ inline double randn_unlikely(SeqRng &r, int idx, int64_t rabs, double x) {
+    if (idx == 0) {
+        for (;;) {
+            double xx = -ZIG_NOR_INV_R * log(r.rand());
+            double yy = -log(r.rand());
+            if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? (-ZIG_NOR_R - xx) : (ZIG_NOR_R + xx);
+        }
+    } else if ((ZIG_FI[idx - 1] - ZIG_FI[idx]) * r.rand() + ZIG_FI[idx] < exp(-0.5 * x * x)) {
+        return x;
+    }
+    return randn_seq(r);
+}
+__device__ inline double randn_seq(SeqRng &r) {
+    for (;;) {
+        uint64_t u = r.next() & MASK52;
+        int64_t rabs = (int64_t)(u >> 1);
+        int idx = (int)(rabs & 0xFF);
+        double x = (double)((u & 1) ? -rabs : rabs) * ZIG_WI[idx];
+        if ((uint64_t)rabs < ZIG_KI[idx]) return x;
+        if (idx == 0) {
+            for (;;) {
+                double xx = -ZIG_NOR_INV_R * log(r.rand());
+                double yy = -log(r.rand());
+                if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? (-ZIG_NOR_R - xx) : (ZIG_NOR_R + xx);
+            }
+        } else if ((ZIG_FI[idx - 1] - ZIG_FI[idx]) * r.rand() + ZIG_FI[idx] < exp(-0.5 * x * x)) {
+            return x;
+        }
+    }
+}
+// randexp (Julia `randexp` + `randexp_unlikely`), sequential.
+__device__ inline double randexp_from_raw(SeqRng &r, uint64_t raw) {
+    for (;;) {
+        uint64_t ri = raw & MASK52;
+        int idx = (int)(ri & 0xFF);
+        double x = (double)ri * ZIG_WE[idx];
+        if (ri < ZIG_KE[idx]) return x;
+        if (idx == 0) return ZIG_EXP_R - log(r.rand());
+        if ((ZIG_FE[idx - 1] - ZIG_FE[idx]) * r.rand() + ZIG_FE[idx] < exp(-x)) return x;
+        raw = r.next();
+    }
+}
+__device__ inline double randexp_seq(SeqRng &r) { return randexp_from_raw(r, r.next()); }
+
+// ---- wave-parallel block of normals in the reference's sequential draw order -------------------
+// Produces randn #0..n_valid-1 of the stream (lane l gets output l) and advances `r` exactly as
+// n_valid sequential randn(rng) calls would.  99.3 % of draws take the one-draw fast path, so all
+// lanes draw speculatively at consecutive counters; the first lane that needs the slow path is
+// resolved sequentially (it may consume extra draws) and the lanes after it are re-drawn.
+__device__ inline double wave_randn_block(SeqRng &r, int lane, int n_valid /*uniform, <= 64*/) {
+    double out = 0.0;
+    int start = 0;
+    while (start < n_valid) {
+        uint64_t u = mix64(r.seed + (uint64_t)(int64_t)(lane - start + 1) * r.gamma) & MASK52;
+        int64_t rabs = (int64_t)(u >> 1);
+        int idx = (int)(rabs & 0xFF);
+        double x = (double)((u & 1) ? -rabs : rabs) * ZIG_WI[idx];
+        bool active = (lane >= start) && (lane < n_valid);
+        bool ok = (uint64_t)rabs < ZIG_KI[idx];
+        uint64_t failmask = ballot64(active && !ok);
+        int f = failmask ? (int)__builtin_ctzll(failmask) : n_valid;
+        if (active && lane < f) out = x;
+        if (f >= n_valid) {
+            r.seed += (uint64_t)(n_valid - start) * r.gamma;
+            break;
+        }
+        r.seed += (uint64_t)(f - start + 1) * r.gamma;        // up to and incl. lane f's first draw
+        int idx_f = __builtin_amdgcn_readlane(idx, f);
+        int64_t rabs_f = (int64_t)readlane_u64((uint64_t)rabs, f);
+        double x_f = readlane_f64(x, f);
+        double xf = randn_unlikely(r, idx_f, rabs_f, x_f);
+        if (lane == f) out = xf;
+        start = f + 1;
+    }
+    return out;
+}
+
+// ---- 64 buffered raw draws for a uniform sequential consumer ----------------------------------
+struct WaveDraws {
+    uint64_t seed, gamma;   // uniform: stream state BEFORE draw #0 of the buffer
+    uint64_t D;             // per lane: raw draw #lane of the buffer
+    int p;                  // uniform: next unread draw
+    __device__ __forceinline__ void init(uint64_t s, uint64_t g, int lane) {
+        seed = s; gamma = g; p = 0;
+        D = mix64(seed + (uint64_t)(lane + 1) * gamma);
+    }
+    __device__ __forceinline__ uint64_t next_raw(int lane) {
+        if (p == 64) { seed += 64ull * gamma; p = 0; D = mix64(seed + (uint64_t)(lane + 1) * gamma); }
+        uint64_t v = readlane_u64(D, p);
+        p += 1;
+        return v;
+    }
+    __device__ __forceinline__ double rand(int lane) { return u52_to_unit(next_raw(lane)); }
+    __device__ __forceinline__ uint64_t final_seed() const { return seed + (uint64_t)p * gamma; }
+    // hand the stream to a sequential consumer (slow paths) and take it back
+    __device__ __forceinline__ SeqRng to_seq() const { return SeqRng{final_seed(), gamma}; }
+    __device__ __forceinline__ void from_seq(const SeqRng &s, int lane) { init(s.seed, s.gamma, lane); }
+};
+
+}  // namespace pte

@@ -1,0 +1,455 @@
+// pte_kernels.hpp -- the HIP kernels of the explore-then-swap scan loop (gfx950).
+//
+// Layout in HBM (struct-of-arrays over replica *slots*; a replica's state never moves inside a
+// GPU, only its chain label does -- "swap betas, not states", reference src/swap/swap.jl:123-125):
+//   x[slot][ld]           f64  replica state, one contiguous row per slot (coalesced 512 B per wave)
+//   rng[slot][2]          u64  SplittableRandom (seed, gamma) of the replica
+//   chain_of_slot[slot]   i32  Replica.chain          slot_of_chain[chain] i32 (inverse permutation)
+//   suff[slot]            f64  sufficient statistic of the state for the swap: sum_i x_i^2
+//   nhp[chain], sd[chain] f64  -0.5*precision(beta_chain), sqrt(precision(beta_chain))
+//   per-pair / per-chain / per-slot recorder accumulators (see EngineDev)
+//
+// One wavefront per replica; mapping chain -> wave so that wave c works at beta_c.
+#pragma once
+#include "pte_device.hpp"
+
+namespace pte {
+
+enum { ERR_NONE = 0, ERR_NAN_RATIO = 1, ERR_SLICE_SUPPORT = 2, ERR_SLICE_INVALID_LP = 3, ERR_SLICE_MAX_ITER = 4 };
+
+struct EngineDev {
+    int64_t N, d, ld;
+    double *x;
+    uint64_t *rng;
+    int32_t *chain_of_slot;
+    int32_t *slot_of_chain;
+    double *suff;
+    const double *nhp;
+    const double *sd;
+    // recorders (reset every round)
+    double *swap_sum;  int64_t *swap_n;                    // [N-1] swap_acceptance_pr
+    double *lsr_up;    double *lsr_dn;   int64_t *lsr_n;   // [N-1] log_sum_ratio (c,c+1) / (c+1,c)
+    int64_t *rt_state; int64_t *rt_restarts; int64_t *rt_trips;   // [slot] round_trip
+    double *expl_acc_sum; int64_t *expl_acc_n;             // [chain] explorer_acceptance_pr
+    double *expl_steps_sum; int64_t *expl_steps_n;         // [chain] explorer_n_steps
+    double *on_mean; double *on_m2; int64_t *on_n;         // [d],[d],[1] target-chain online stats
+    int32_t *index_process;                                // [scan][slot]
+    int32_t *error;                                        // [4] code, chain, coordinate, spare
+    uint32_t record_flags;
+    int32_t target;
+    double test_swapper_pr;
+};
+
+struct SliceParams { double w; int p; int n_passes; int max_iter; };
+
+__device__ __forceinline__ void set_error(const EngineDev &e, int code, int chain, int coord) {
+    if (atomicCAS(&e.error[0], 0, code) == 0) { e.error[1] = chain; e.error[2] = coord; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_init: create_replicas (reference src/replicas/replicas.jl:87-98, src/utils/misc.jl:21-31,
+// src/targets/toy_mvn_target.jl:10-11).  Replica i gets the i-th sequential split of
+// SplittableRandom(seed); the split is counter based, so every wave derives its own stream.
+// ---------------------------------------------------------------------------------------------
+template <int NLU>
+__global__ __launch_bounds__(64) void k_init(EngineDev e, uint64_t master_seed, double init_sd) {
+    const int lane = lane_id();
+    const int64_t i = blockIdx.x;
+    if (i >= e.N) return;
+    const uint64_t G = 0x9e3779b97f4a7c15ULL;
+    SeqRng r;
+    r.seed = mix64(master_seed + (uint64_t)(2 * i + 1) * G);
+    r.gamma = mix_gamma(master_seed + (uint64_t)(2 * i + 2) * G);
+    if (e.d > 0) {
+        double *xrow = e.x + i * e.ld;
+        const int B = (int)((e.d + 63) >> 6);
+        double BS = 0.0;
+        for (int b = 0; b < B; ++b) {
+            int nl = (int)min((int64_t)64, e.d - 64 * (int64_t)b);
+            double v = wave_randn_block(r, lane, nl) / init_sd;
+            if (lane < nl) xrow[64 * b + lane] = v; else v = 0.0;
+            double s = wave_tree_sum64(v * v);
+            if (lane == b) BS = s;
+        }
+        double S = upper_tree_root<NLU>(BS);
+        if (lane == 0) e.suff[i] = S;
+    }
+    if (lane == 0) {
+        e.rng[2 * i] = r.seed; e.rng[2 * i + 1] = r.gamma;
+        e.chain_of_slot[i] = (int32_t)i; e.slot_of_chain[i] = (int32_t)i;
+    }
+}
+
+// i.i.d. refresh of one replica at precision sd^2 (sample_iid! / ToyExplorer.step!,
+// reference src/targets/toy_mvn_target.jl:15-21, src/explorers/ToyExplorer.jl:7-12) fused with
+// the evaluation of its swap statistic.
+template <int NLU>
+__device__ __forceinline__ void iid_refresh(const EngineDev &e, int slot, double sd, int lane) {
+    SeqRng r{e.rng[2 * slot], e.rng[2 * slot + 1]};
+    double *xrow = e.x + (int64_t)slot * e.ld;
+    const int B = (int)((e.d + 63) >> 6);
+    double BS = 0.0;
+    for (int b = 0; b < B; ++b) {
+        int nl = (int)min((int64_t)64, e.d - 64 * (int64_t)b);
+        double v = wave_randn_block(r, lane, nl) / sd;
+        if (lane < nl) xrow[64 * b + lane] = v; else v = 0.0;
+        double s = wave_tree_sum64(v * v);
+        if (lane == b) BS = s;
+    }
+    double S = upper_tree_root<NLU>(BS);
+    if (lane == 0) { e.suff[slot] = S; e.rng[2 * slot] = r.seed; }
+}
+
+// Target-chain online statistics (reference src/pt/pigeons.jl:110-115,
+// src/recorders/OnlineStateRecorder.jl:87-96): per-coordinate Welford mean / M2.
+__device__ __forceinline__ void record_online(const EngineDev &e, int slot, int lane) {
+    const double *xrow = e.x + (int64_t)slot * e.ld;
+    int64_t n = e.on_n[0] + 1;
+    for (int64_t i = lane; i < e.d; i += 64) {
+        double v = xrow[i], mu = e.on_mean[i];
+        double mu2 = mu + (v - mu) / (double)n;
+        e.on_m2[i] += (v - mu) * (v - mu2);
+        e.on_mean[i] = mu2;
+    }
+    if (lane == 0) e.on_n[0] = n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_explore_toy: explore! with ToyExplorer -- every chain is refreshed i.i.d. at its own precision.
+// HBM-write bound: 8d bytes stored per replica.
+// ---------------------------------------------------------------------------------------------
+template <int NLU>
+__global__ __launch_bounds__(64) void k_explore_toy(EngineDev e) {
+    const int lane = lane_id();
+    const int64_t c = blockIdx.x;
+    if (c >= e.N) return;
+    const int slot = e.slot_of_chain[c];
+    iid_refresh<NLU>(e, slot, e.sd[c], lane);
+    if (c == e.N - 1 && (e.record_flags & 4u)) { __threadfence_block(); record_online(e, slot, lane); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_explore_slice: explore! with SliceSampler (reference src/explorers/SliceSampler.jl:24-237) on
+// the scaled-precision MVN path.  Chain 0 is refreshed i.i.d. (src/pt/pigeons.jl:104-105).
+//
+// The reference re-evaluates the full O(d) log potential after every single-coordinate change.
+// Here sum(abs2, x) is a FIXED binary tree; changing leaf c only changes the log2(P) nodes on the
+// path leaf->root, so lp(x with x_c = v) = nhp * (((v^2 + s_0) + s_1) + ... ) where s_k is the
+// sibling subtree at level k: bit-identical to the full recompute, O(log d) instead of O(d).
+// The wave keeps the siblings in registers:
+//   levels 0..5  (inside the current 64-coordinate block, lane l <-> coordinate 64b+l):
+//       right siblings come from the butterfly U[k] taken at block start (unchanged this pass),
+//       left siblings are the chain intermediates of the coordinate that completed that subtree;
+//   levels 6..   (whole blocks): from the butterfly over the block sums BS (lane b <-> block b).
+// The 64 lanes also pre-evaluate the next 64 raw draws of the replica's counter-based stream.
+// ---------------------------------------------------------------------------------------------
+template <int NLU>
+struct SliceCoord {
+    static constexpr int NL = 6 + NLU;
+    double sib[NL];
+    double nhp, z, w;
+    int lane;
+    __device__ __forceinline__ double evalS(double v) const {
+        double t = v * v;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) t = t + sib[k];
+        return t;
+    }
+    __device__ __forceinline__ double evalS(double v, double (&t)[NL + 1]) const {
+        t[0] = v * v;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) t[k + 1] = t[k] + sib[k];
+        return t[NL];
+    }
+    // slice_accept, SliceSampler.jl:192-237.  Returns accept; `evals` of lp at the bisected endpoints.
+    __device__ __forceinline__ bool accept(double old_position, double new_position, double L, double R,
+                                           double lp_L, double lp_R, double &acc_sum, int64_t &acc_n) const {
+        double Lhat = L, Rhat = R;
+        bool Rstale = false, Lstale = false, D = false;
+        while (Rhat - Lhat > 1.1 * w) {
+            double M = (Lhat + Rhat) / 2.0;
+            if ((old_position < M && new_position >= M) || (old_position >= M && new_position < M)) D = true;
+            if (new_position < M) { Rhat = M; Rstale = true; }
+            else { Lhat = M; Lstale = true; }
+            if (D) {
+                if (Lstale) { lp_L = nhp * evalS(Lhat); Lstale = false; }
+                if (Rstale) { lp_R = nhp * evalS(Rhat); Rstale = false; }
+                if (z >= lp_L && z >= lp_R) { acc_n += 1; return false; }
+            }
+        }
+        acc_sum += 1.0; acc_n += 1;
+        return true;
+    }
+};
+
+__device__ __forceinline__ bool jl_isapprox(double x, double y) {
+    if (x == y) return true;
+    if (!isfinite(x) || !isfinite(y)) return false;
+    double ax = fabs(x), ay = fabs(y);
+    return fabs(x - y) <= 1.4901161193847656e-8 * (ax > ay ? ax : ay);
+}
+
+template <int NLU>
+__global__ __launch_bounds__(64) void k_explore_slice(EngineDev e, SliceParams sp) {
+    constexpr int NL = 6 + NLU;
+    const int lane = lane_id();
+    const int64_t c = blockIdx.x;
+    if (c >= e.N) return;
+    const int slot = e.slot_of_chain[c];
+    if (c == 0 && e.N > 1) {
+        iid_refresh<NLU>(e, slot, e.sd[0], lane);
+        return;
+    }
+    const int64_t d = e.d;
+    double *xrow = e.x + (int64_t)slot * e.ld;
+    const int B = (int)((d + 63) >> 6);
+    SliceCoord<NLU> sc;
+    sc.nhp = e.nhp[c]; sc.w = sp.w; sc.lane = lane;
+
+    // cached_log_potential (SliceSampler.jl:32-41): full evaluation once per step
+    double BS = 0.0;
+    for (int b = 0; b < B; ++b) {
+        int64_t i = 64 * (int64_t)b + lane;
+        double v = (i < d) ? xrow[i] : 0.0;
+        double s = wave_tree_sum64(v * v);
+        if (lane == b) BS = s;
+    }
+    double S = upper_tree_root<NLU>(BS);
+    double lp = sc.nhp * S;
+    if (lp == -INFINITY) { if (lane == 0) set_error(e, ERR_SLICE_SUPPORT, (int)c, -1); return; }
+
+    WaveDraws dr;
+    dr.init(e.rng[2 * slot], e.rng[2 * slot + 1], lane);
+    double steps_sum = 0.0, acc_sum = 0.0;
+    int64_t steps_n = 0, acc_n = 0;
+    bool failed = false;
+
+    for (int pass = 0; pass < sp.n_passes && !failed; ++pass) {
+        for (int b = 0; b < B && !failed; ++b) {
+            const int64_t base = 64 * (int64_t)b;
+            const int nl = (int)min((int64_t)64, d - base);
+            double X = (lane < nl) ? xrow[base + lane] : 0.0;
+            double U[7];
+            butterfly6(X * X, U);
+            {   // siblings above the block: butterfly over the block sums
+                double V = BS;
+#pragma unroll
+                for (int q = 0; q < NLU; ++q) {
+                    sc.sib[6 + q] = readlane_f64(V, b ^ (1 << q));
+                    V = V + shfl_xor_f64(V, 1 << q);
+                }
+            }
+            double tsave[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (int l = 0; l < nl; ++l) {
+                // ---- siblings inside the block for coordinate l
+                if (l == 0) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) sc.sib[k] = readlane_f64(U[k], 1 << k);
+                } else {
+                    const int r = __builtin_ctz((unsigned)l);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        if (k < r) sc.sib[k] = readlane_f64(U[k], l ^ (1 << k));
+                        else if (k == r) sc.sib[k] = tsave[k];
+                    }
+                }
+                const double xold = readlane_f64(X, l);
+                // ---- slice_sample_coord! (SliceSampler.jl:89-95)
+                double E;
+                {
+                    uint64_t raw = dr.next_raw(lane);
+                    uint64_t ri = raw & MASK52;
+                    int idx = (int)(ri & 0xFF);
+                    E = (double)ri * ZIG_WE[idx];
+                    if (!(ri < ZIG_KE[idx])) {
+                        SeqRng s = dr.to_seq();
+                        E = randexp_from_raw(s, raw);
+                        dr.from_seq(s, lane);
+                    }
+                }
+                sc.z = lp - E;
+                // slice_double (:97-126) with initialize_slice_endpoints (:129-133)
+                double L = xold - sp.w * dr.rand(lane);
+                double R = L + sp.w;
+                int K = sp.p;
+                double lp_L = sc.nhp * sc.evalS(L);
+                double lp_R = sc.nhp * sc.evalS(R);
+                while (K > 0 && (sc.z < lp_L || sc.z < lp_R)) {
+                    double V = dr.rand(lane);
+                    if (V <= 0.5) { L = L - (R - L); lp_L = sc.nhp * sc.evalS(L); }
+                    else { R = R + (R - L); lp_R = sc.nhp * sc.evalS(R); }
+                    K -= 1;
+                }
+                steps_sum += (double)(sp.p - K); steps_n += 1;
+                // slice_shrink! (:144-186)
+                double Lbar = L, Rbar = R;
+                double t[NL + 1];
+                double xf = xold;
+                bool done = false;
+                for (int n = 1; n <= sp.max_iter; ++n) {
+                    double newpos = Lbar + dr.rand(lane) * (Rbar - Lbar);
+                    double Snew = sc.evalS(newpos, t);
+                    double newlp = sc.nhp * Snew;
+                    bool consider = sc.z < newlp;
+                    if (consider && sc.accept(xold, newpos, L, R, lp_L, lp_R, acc_sum, acc_n)) {
+                        xf = newpos; S = Snew; lp = newlp;
+                        steps_sum += (double)n; steps_n += 1;
+                        done = true;
+                        break;
+                    }
+                    if (newpos < xold) Lbar = newpos; else Rbar = newpos;
+                    if (jl_isapprox(Lbar, Rbar)) {
+                        S = sc.evalS(xold, t); lp = sc.nhp * S;
+                        steps_sum += (double)n; steps_n += 1;
+                        done = true;
+                        break;
+                    }
+                }
+                if (!done) { if (lane == 0) set_error(e, ERR_SLICE_MAX_ITER, (int)c, (int)(base + l)); failed = true; break; }
+                if (!isfinite(lp)) { if (lane == 0) set_error(e, ERR_SLICE_INVALID_LP, (int)c, (int)(base + l)); failed = true; break; }
+                if (lane == l) X = xf;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) tsave[k] = t[k];
+            }
+            if (lane < nl) xrow[base + lane] = X;
+            if (lane == b) BS = tsave[6];
+        }
+    }
+    if (lane == 0) {
+        e.suff[slot] = S;
+        e.rng[2 * slot] = dr.final_seed();
+        e.expl_steps_sum[c] += steps_sum; e.expl_steps_n[c] += steps_n;
+        e.expl_acc_sum[c] += acc_sum;     e.expl_acc_n[c] += acc_n;
+    }
+    if (c == e.N - 1 && (e.record_flags & 4u)) { __threadfence_block(); record_online(e, slot, lane); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_swap: communicate! (reference src/pt/pigeons.jl:64-69, src/swap/swap.jl:6-39,106-126,
+// src/swap/pair_swapper.jl:42-88, src/swap/OddEven.jl:23-31, src/swap/DEO.jl:12).
+// Thread t handles chain (t + off) mod N with off = 1 on the even graph, so that the two chains
+// of every DEO pair sit in adjacent lanes (t, t^1) of one wavefront: the pair's SwapStats are
+// exchanged with __shfl_xor and both lanes take the same decision.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double dev_logaddexp(double x, double y) {
+    double delta = (x == y) ? 0.0 : fabs(x - y);
+    double m = (x > y) ? x : y;
+    double nd = -delta;
+    double t = (nd <= -37.0) ? exp(nd) : log1p(exp(nd));
+    return m + t;
+}
+
+__global__ __launch_bounds__(256) void k_swap(EngineDev e, int even, int64_t scan_idx) {
+    const int64_t N = e.N;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = t < N;
+    const int off = even ? 1 : 0;
+    const int64_t c = valid ? (t + off) % N : 0;
+    // partner_chain (OddEven.jl:23-31), 0-based
+    int64_t pc = c;
+    if (valid) {
+        const bool chain_even = ((c + 1) % 2 == 0);
+        int64_t proposed = (c + 1) + ((chain_even == (even != 0)) ? 1 : -1);
+        pc = (proposed == 0) ? 0 : (proposed == N + 1 ? N - 1 : proposed - 1);
+    }
+    double lr = 0.0, u = 0.0;
+    int slot = 0;
+    if (valid) {
+        slot = e.slot_of_chain[c];
+        if (e.target != 1) {
+            // log_unnormalized_ratio(lps, partner, mine, state) (log_potentials.jl:43-51)
+            const double S = e.suff[slot];
+            lr = e.nhp[pc] * S - e.nhp[c] * S;
+            if (isnan(lr)) set_error(e, ERR_NAN_RATIO, (int)c, -1);
+        }
+        uint64_t seed = e.rng[2 * slot] + e.rng[2 * slot + 1];    // one rand(replica.rng) per replica
+        e.rng[2 * slot] = seed;
+        u = u52_to_unit(mix64(seed));
+        if (e.record_flags & 2u) e.index_process[scan_idx * N + slot] = (int32_t)c;
+        if (e.record_flags & 1u) {     // RoundTripRecorder.jl:43-54
+            const bool is_ref = (c == 0 && N > 1), is_tgt = (c == N - 1);
+            int64_t st = e.rt_state[slot];
+            if (st == 0 && is_ref) e.rt_state[slot] = 1;
+            else if (st == 1 && is_tgt) { e.rt_state[slot] = 2; e.rt_restarts[slot] += 1; }
+            else if (st == 2 && is_ref) { e.rt_state[slot] = 1; e.rt_trips[slot] += 1; }
+        }
+    }
+    const double lr_p = __shfl_xor(lr, 1, 64);
+    const double u_p = __shfl_xor(u, 1, 64);
+    if (valid && pc != c) {
+        const bool lower = c < pc;
+        const double uu = lower ? u : u_p;
+        bool do_swap;
+        if (e.target == 1) {
+            do_swap = uu < e.test_swapper_pr;                  // TestSwapper, pair_swapper.jl:135-138
+        } else {
+            const double ex = exp(lr + lr_p);
+            const double alpha = ex < 1.0 ? ex : 1.0;         // swap_acceptance_probability :88
+            do_swap = uu < alpha;                               // swap_decision :81-85
+            if (lower) {                                        // record_swap_stats! :59-66
+                e.swap_sum[c] += alpha; e.swap_n[c] += 1;
+                e.lsr_up[c] = dev_logaddexp(e.lsr_up[c], lr);
+                e.lsr_dn[c] = dev_logaddexp(e.lsr_dn[c], lr_p);
+                e.lsr_n[c] += 1;
+            }
+        }
+        if (do_swap) { e.chain_of_slot[slot] = (int32_t)pc; e.slot_of_chain[pc] = slot; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// test kernels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_test_rng(uint64_t *sg, int kind, int64_t n, double *out) {
+    const int lane = lane_id();
+    if (kind == 0) {
+        uint64_t seed = sg[0], gamma = sg[1];
+        for (int64_t i = lane; i < n; i += 64) out[i] = u52_to_unit(mix64(seed + (uint64_t)(i + 1) * gamma));
+        __syncthreads();
+        if (lane == 0) sg[0] = seed + (uint64_t)n * gamma;
+    } else if (kind == 1) {
+        SeqRng r{sg[0], sg[1]};
+        for (int64_t i0 = 0; i0 < n; i0 += 64) {
+            int nl = (int)min((int64_t)64, n - i0);
+            double v = wave_randn_block(r, lane, nl);
+            if (lane < nl) out[i0 + lane] = v;
+        }
+        if (lane == 0) sg[0] = r.seed;
+    } else {
+        WaveDraws dr;
+        dr.init(sg[0], sg[1], lane);
+        for (int64_t i = 0; i < n; ++i) {
+            uint64_t raw = dr.next_raw(lane);
+            uint64_t ri = raw & MASK52;
+            int idx = (int)(ri & 0xFF);
+            double E = (double)ri * ZIG_WE[idx];
+            if (!(ri < ZIG_KE[idx])) {
+                SeqRng s = dr.to_seq();
+                E = randexp_from_raw(s, raw);
+                dr.from_seq(s, lane);
+            }
+            if (lane == 0) out[i] = E;
+        }
+        if (lane == 0) sg[0] = dr.final_seed();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_test_sqr_norm(const double *x, int64_t rows, int64_t d, int nlu, double *out) {
+    const int lane = lane_id();
+    const int64_t r = blockIdx.x;
+    if (r >= rows) return;
+    const double *xrow = x + r * d;
+    const int B = (int)((d + 63) >> 6);
+    double acc = 0.0;   // lane b of chunk g holds block sum (64g + b); supports d up to 64*64*... via chunks of 64 blocks
+    // d <= 4096 here (one register of block sums)
+    for (int b = 0; b < B; ++b) {
+        int64_t i = 64 * (int64_t)b + lane;
+        double v = (i < d) ? xrow[i] : 0.0;
+        double s = wave_tree_sum64(v * v);
+        if (lane == b) acc = s;
+    }
+    double S = upper_tree_root_dyn(acc, nlu);
+    if (lane == 0) out[r] = S;
+}
+
+}  // namespace pte

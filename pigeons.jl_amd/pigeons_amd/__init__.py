@@ -1,0 +1,18 @@
+"""pigeons_amd: host-side mirror of the Pigeons.jl surface for the explore-then-swap hot path,
+driving the MI355X-native engine (libpte.so, C ABI in include/pte.h) through ctypes.
+
+No Julia toolchain exists in the build image, so this Python mirror is the runnable host side;
+the Julia `ccall` glue a Pigeons.jl maintainer would add is in INTEGRATION.md and
+pigeons.jl_amd/julia/PigeonsMI355X.jl.
+"""
+from ._lib import PteError, LIB_PATH
+from .engine import Engine
+from .pt import (Inputs, PT, pigeons, toy_mvn_target, ScaledPrecisionNormalPath, TestSwapper,
+                 SliceSampler, ToyExplorer, record_default, record_online,
+                 log_sum_ratio, swap_acceptance_pr, round_trip, index_process, online,
+                 timing_extrema, allocation_extrema, explorer_acceptance_pr, explorer_n_steps,
+                 stepping_stone, stepping_stone_pair, n_round_trips, n_tempered_restarts,
+                 global_barrier, last_round_max_time, analytic_lognormalization,
+                 analytic_cumulativebarrier, run_one_round, adapt, next_round, n_scans_in_round)
+from .tempering import (Schedule, equally_spaced_schedule, optimal_schedule,
+                        FritschCarlsonMonotonicInterpolation, CommunicationBarriers, rejections)

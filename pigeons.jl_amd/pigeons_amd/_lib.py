@@ -1,0 +1,96 @@
+"""ctypes binding of libpte.so (the C ABI in include/pte.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or no HIP
+device is present, every engine call fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)                       # .../pigeons.jl_amd
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libpte.so")
+
+TARGET_MVN_SCALED_PRECISION, TARGET_TEST_SWAPPER, TARGET_FUNNEL = 0, 1, 2
+EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA = 0, 1, 2, 3
+RECORD_ROUND_TRIP, RECORD_INDEX_PROCESS, RECORD_ONLINE = 1, 2, 4
+ABI_VERSION = 1
+
+
+class PteConfig(C.Structure):
+    """Mirror of `pte_config` (include/pte.h)."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("abi_version", C.c_uint32),
+        ("device", C.c_int32), ("target", C.c_int32), ("explorer", C.c_int32),
+        ("record_flags", C.c_uint32),
+        ("n_chains", C.c_int64), ("dim", C.c_int64), ("seed", C.c_uint64),
+        ("max_scans_per_round", C.c_int64),
+        ("target_params", C.c_double * 4),
+        ("slice_w", C.c_double),
+        ("slice_p", C.c_int32), ("slice_n_passes", C.c_int32), ("slice_max_iter", C.c_int32),
+        ("am_base_n_refresh", C.c_int32),
+        ("am_exponent_n_refresh", C.c_double), ("am_step_size", C.c_double),
+        ("am_p0", C.c_double), ("am_p1", C.c_double),
+        ("am_preconditioner", C.c_int32),
+        ("rank", C.c_int32), ("world_size", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class PteError(RuntimeError):
+    pass
+
+
+EXPORTS = [
+    "pte_default_config", "pte_create", "pte_destroy", "pte_last_error",
+    "pte_set_schedule", "pte_get_schedule", "pte_set_explorer_adaptation",
+    "pte_explore", "pte_swap", "pte_run_scans", "pte_reduce",
+    "pte_get_swap_acceptance", "pte_get_log_sum_ratio", "pte_get_round_trip",
+    "pte_get_index_process", "pte_get_explorer_stats", "pte_get_automala_stats",
+    "pte_get_online", "pte_get_state", "pte_set_state",
+    "pte_timing_reset", "pte_timing_get", "pte_test_rng_fill", "pte_test_sqr_norm",
+]
+
+_lib = None
+
+
+def load():
+    """Load libpte.so; raise PteError (never fall back) if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PteError(
+            "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    dp, ip, up = C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
+    vp = C.c_void_p
+    L.pte_default_config.argtypes = [C.POINTER(PteConfig)]
+    L.pte_create.argtypes = [C.POINTER(PteConfig), C.POINTER(vp)]
+    L.pte_destroy.argtypes = [vp]
+    L.pte_last_error.restype = C.c_char_p
+    L.pte_last_error.argtypes = [vp]
+    L.pte_set_schedule.argtypes = [vp, dp, C.c_int64]
+    L.pte_get_schedule.argtypes = [vp, dp]
+    L.pte_set_explorer_adaptation.argtypes = [vp, C.c_double, dp, C.c_int64]
+    L.pte_explore.argtypes = [vp, C.c_int64]
+    L.pte_swap.argtypes = [vp, C.c_int64]
+    L.pte_run_scans.argtypes = [vp, C.c_int64, C.c_int64]
+    L.pte_reduce.argtypes = [vp]
+    L.pte_get_swap_acceptance.argtypes = [vp, dp, ip]
+    L.pte_get_log_sum_ratio.argtypes = [vp, dp, ip, dp, ip]
+    L.pte_get_round_trip.argtypes = [vp, ip, ip]
+    L.pte_get_index_process.argtypes = [vp, ip, ip]
+    L.pte_get_explorer_stats.argtypes = [vp, dp, ip, dp, ip]
+    L.pte_get_automala_stats.argtypes = [vp, dp, ip, dp, ip]
+    L.pte_get_online.argtypes = [vp, dp, dp, ip]
+    L.pte_get_state.argtypes = [vp, dp, ip, up]
+    L.pte_set_state.argtypes = [vp, dp, ip, up]
+    L.pte_timing_reset.argtypes = [vp, C.c_int]
+    L.pte_timing_get.argtypes = [vp, C.c_int, dp, ip]
+    L.pte_test_rng_fill.argtypes = [C.c_int32, up, C.c_int32, C.c_int64, dp]
+    L.pte_test_sqr_norm.argtypes = [C.c_int32, dp, C.c_int64, C.c_int64, dp]
+    for name in EXPORTS:
+        if name != "pte_last_error":
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L

@@ -1,0 +1,178 @@
+"""Device-resident replicas: thin object wrapper over the C ABI (include/pte.h).
+
+Plays the role of the reference's `replicas` container (src/replicas/replicas.jl:11-40):
+the engine owns every replica's state, chain, rng and recorders in HBM.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import PteConfig, PteError
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def _up(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+class Engine:
+    def __init__(self, **kw):
+        self.L = _lib.load()
+        cfg = PteConfig()
+        self.L.pte_default_config(C.byref(cfg))
+        tp = kw.pop("target_params", None)
+        for k, v in kw.items():
+            if not hasattr(cfg, k):
+                raise AttributeError("pte_config has no field %r" % k)
+            setattr(cfg, k, v)
+        if tp is not None:
+            for i, v in enumerate(tp):
+                cfg.target_params[i] = v
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self.L.pte_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise PteError(self.L.pte_last_error(None).decode())
+        self.h = h
+        self.N = int(cfg.n_chains)
+        self.d = 0 if cfg.target == _lib.TARGET_TEST_SWAPPER else int(cfg.dim)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pte_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PteError(self.L.pte_last_error(self.h).decode())
+
+    # --- schedule / adaptation
+    def set_schedule(self, betas):
+        b = np.ascontiguousarray(betas, dtype=np.float64)
+        self._chk(self.L.pte_set_schedule(self.h, _dp(b), len(b)))
+
+    def schedule(self):
+        b = np.zeros(self.N)
+        self._chk(self.L.pte_get_schedule(self.h, _dp(b)))
+        return b
+
+    def set_explorer_adaptation(self, step_size, target_std=None):
+        if target_std is None:
+            self._chk(self.L.pte_set_explorer_adaptation(self.h, step_size, None, 0))
+        else:
+            s = np.ascontiguousarray(target_std, dtype=np.float64)
+            self._chk(self.L.pte_set_explorer_adaptation(self.h, step_size, _dp(s), len(s)))
+
+    # --- hot path
+    def explore(self, scan):
+        self._chk(self.L.pte_explore(self.h, scan))
+
+    def swap(self, scan):
+        self._chk(self.L.pte_swap(self.h, scan))
+
+    def run_scans(self, first_scan, n_scans):
+        self._chk(self.L.pte_run_scans(self.h, first_scan, n_scans))
+
+    def reduce(self):
+        self._chk(self.L.pte_reduce(self.h))
+
+    # --- reduced recorders
+    def swap_acceptance(self):
+        k = max(self.N - 1, 1)
+        m = np.zeros(k); n = np.zeros(k, dtype=np.int64)
+        self._chk(self.L.pte_get_swap_acceptance(self.h, _dp(m), _ip(n)))
+        return m[:self.N - 1], n[:self.N - 1]
+
+    def log_sum_ratio(self):
+        k = max(self.N - 1, 1)
+        up = np.zeros(k); dn = np.zeros(k)
+        un = np.zeros(k, dtype=np.int64); dnn = np.zeros(k, dtype=np.int64)
+        self._chk(self.L.pte_get_log_sum_ratio(self.h, _dp(up), _ip(un), _dp(dn), _ip(dnn)))
+        return up[:self.N - 1], un[:self.N - 1], dn[:self.N - 1], dnn[:self.N - 1]
+
+    def round_trip(self):
+        a = np.zeros(1, dtype=np.int64); b = np.zeros(1, dtype=np.int64)
+        self._chk(self.L.pte_get_round_trip(self.h, _ip(a), _ip(b)))
+        return int(a[0]), int(b[0])
+
+    def index_process(self):
+        n = np.zeros(1, dtype=np.int64)
+        self._chk(self.L.pte_get_index_process(self.h, None, _ip(n)))
+        out = np.zeros((self.N, int(n[0])), dtype=np.int64)
+        if out.size:
+            self._chk(self.L.pte_get_index_process(self.h, _ip(out), _ip(n)))
+        return out
+
+    def explorer_stats(self):
+        am = np.zeros(self.N); ss = np.zeros(self.N)
+        an = np.zeros(self.N, dtype=np.int64); sn = np.zeros(self.N, dtype=np.int64)
+        self._chk(self.L.pte_get_explorer_stats(self.h, _dp(am), _ip(an), _dp(ss), _ip(sn)))
+        return am, an, ss, sn
+
+    def automala_stats(self):
+        fm = np.zeros(self.N); rm = np.zeros(self.N)
+        fn = np.zeros(self.N, dtype=np.int64); rn = np.zeros(self.N, dtype=np.int64)
+        self._chk(self.L.pte_get_automala_stats(self.h, _dp(fm), _ip(fn), _dp(rm), _ip(rn)))
+        return fm, fn, rm, rn
+
+    def online(self):
+        m = np.zeros(max(self.d, 1)); v = np.zeros(max(self.d, 1)); n = np.zeros(1, dtype=np.int64)
+        self._chk(self.L.pte_get_online(self.h, _dp(m), _dp(v), _ip(n)))
+        return m[:self.d], v[:self.d], int(n[0])
+
+    # --- replica fields
+    def states(self):
+        x = np.zeros((self.N, max(self.d, 1)))
+        chain = np.zeros(self.N, dtype=np.int64)
+        rng = np.zeros((self.N, 2), dtype=np.uint64)
+        self._chk(self.L.pte_get_state(self.h, _dp(x) if self.d > 0 else None, _ip(chain), _up(rng)))
+        return x[:, :self.d], chain, rng
+
+    def set_states(self, x=None, chain=None, rng=None):
+        xa = None if x is None else np.ascontiguousarray(x, dtype=np.float64)
+        ca = None if chain is None else np.ascontiguousarray(chain, dtype=np.int64)
+        ra = None if rng is None else np.ascontiguousarray(rng, dtype=np.uint64)
+        self._chk(self.L.pte_set_state(self.h, None if xa is None else _dp(xa),
+                                       None if ca is None else _ip(ca), None if ra is None else _up(ra)))
+
+    # --- measurement
+    def timing_reset(self, enable=True):
+        self._chk(self.L.pte_timing_reset(self.h, 1 if enable else 0))
+
+    def timing(self, kernel):
+        ms = np.zeros(1); n = np.zeros(1, dtype=np.int64)
+        self._chk(self.L.pte_timing_get(self.h, kernel, _dp(ms), _ip(n)))
+        return float(ms[0]), int(n[0])
+
+
+def test_rng_fill(seed_gamma, kind, n, device=0):
+    """n draws of kind (0 rand, 1 randn, 2 randexp) from stream (seed, gamma), on the device."""
+    L = _lib.load()
+    sg = np.array(seed_gamma, dtype=np.uint64)
+    out = np.zeros(max(n, 1))
+    if L.pte_test_rng_fill(device, _up(sg), kind, n, _dp(out)) != 0:
+        raise PteError(L.pte_last_error(None).decode())
+    return out[:n], (int(sg[0]), int(sg[1]))
+
+
+def test_sqr_norm(x, device=0):
+    L = _lib.load()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros(x.shape[0])
+    if L.pte_test_sqr_norm(device, _dp(x), x.shape[0], x.shape[1], _dp(out)) != 0:
+        raise PteError(L.pte_last_error(None).decode())
+    return out

@@ -1,0 +1,311 @@
+"""pigeons() / Inputs / PT: the reference's top-level surface (src/api.jl:8-19,
+src/pt/Inputs.jl:9-131, src/pt/PT.jl:6-51, src/pt/pigeons.jl:12-55,152-162,
+src/pt/Iterators.jl:9-49) driving the MI355X engine for the explore-then-swap loop.
+
+Everything inside `while next_scan!` runs on the GPU (one C-ABI call per round);
+what the reference runs a logarithmic number of times (adapt, report) stays host-side.
+"""
+import math
+import time
+from dataclasses import dataclass, field
+from typing import Any, List, Optional
+
+import numpy as np
+
+from . import _lib
+from .engine import Engine
+from . import tempering as T
+
+
+# ---- targets (src/targets/toy_mvn_target.jl, src/paths/ScaledPrecisionNormalPath.jl) ---------
+@dataclass
+class ScaledPrecisionNormalPath:
+    precision0: float = 1.0
+    precision1: float = 10.0
+    dim: int = 1
+
+    def precision(self, beta):
+        return (1.0 - beta) * self.precision0 + beta * self.precision1
+
+
+def toy_mvn_target(dim):
+    """src/targets/toy_mvn_target.jl:8"""
+    return ScaledPrecisionNormalPath(1.0, 10.0, dim)
+
+
+def analytic_lognormalization(path):
+    """src/paths/ScaledPrecisionNormalPath.jl:66-71"""
+    return 0.5 * path.dim * (math.log(path.precision0) - math.log(path.precision1))
+
+
+def analytic_cumulativebarrier(path):
+    """src/paths/ScaledPrecisionNormalPath.jl:56-64"""
+    from scipy.special import beta as beta_fn
+    b = beta_fn(path.dim / 2.0, path.dim / 2.0)
+
+    def cumulativebarrier(beta):
+        sigma0 = 1.0 / math.sqrt(path.precision0)
+        sigmab = 1.0 / math.sqrt(path.precision(beta))
+        return 2 ** (2.0 - path.dim) / b * math.log(sigma0 / sigmab)
+    return cumulativebarrier
+
+
+@dataclass
+class TestSwapper:
+    """src/swap/pair_swapper.jl:100-149"""
+    constant_swap_accept_pr: float = 1.0
+    __test__ = False
+
+
+# ---- explorers (src/explorers/*.jl) ------------------------------------------------------------
+@dataclass
+class SliceSampler:
+    """src/explorers/SliceSampler.jl:8-20"""
+    w: float = 10.0
+    p: int = 20
+    n_passes: int = 3
+    max_iter: int = 1024
+
+
+@dataclass
+class ToyExplorer:
+    """src/explorers/ToyExplorer.jl:5"""
+
+
+def default_explorer(target):
+    if isinstance(target, ScaledPrecisionNormalPath):
+        return ToyExplorer()           # src/targets/toy_mvn_target.jl:13
+    if isinstance(target, TestSwapper):
+        return None                    # src/swap/pair_swapper.jl:139
+    return SliceSampler()              # src/targets/target.jl:20
+
+
+# ---- recorder builders (src/recorders/recorder.jl) ----------------------------------------------
+def log_sum_ratio(): return "log_sum_ratio"
+def swap_acceptance_pr(): return "swap_acceptance_pr"
+def round_trip(): return "round_trip"
+def index_process(): return "index_process"
+def online(): return "online"
+def timing_extrema(): return "timing_extrema"
+def allocation_extrema(): return "allocation_extrema"
+def explorer_acceptance_pr(): return "explorer_acceptance_pr"
+def explorer_n_steps(): return "explorer_n_steps"
+
+
+def record_default():
+    """src/pt/Inputs.jl:107-111"""
+    return [log_sum_ratio, timing_extrema, allocation_extrema]
+
+
+def record_online():
+    """src/pt/Inputs.jl:116-123 (energy_ac1 is not provided by the device engine)"""
+    return [log_sum_ratio, timing_extrema, allocation_extrema, round_trip, online]
+
+
+@dataclass
+class Inputs:
+    """src/pt/Inputs.jl:9-102 (fields the hot path reads)."""
+    target: Any = None
+    seed: int = 1
+    n_rounds: int = 10
+    n_chains: int = 10
+    n_chains_variational: int = 0
+    reference: Any = None
+    variational: Any = None
+    checkpoint: bool = False
+    record: List = field(default_factory=record_default)
+    checked_round: int = 0
+    multithreaded: bool = False
+    explorer: Any = None
+    extractor: Any = None
+    show_report: bool = True
+    extended_traces: bool = False
+    device: int = 0                 # HIP device ordinal (not in the reference)
+
+
+@dataclass
+class Iterators:
+    """src/pt/Iterators.jl:9-25"""
+    round: int = 0
+    scan: int = 0
+
+
+def n_scans_in_round(iterators):
+    return 2 ** iterators.round
+
+
+@dataclass
+class ReducedRecorders:
+    """The reduced `recorders` NamedTuple of one round (src/recorders/recorders.jl:88-120)."""
+    swap_acceptance_pr: Any = None      # (mean[N-1], n[N-1]) keyed (c, c+1)
+    log_sum_ratio: Any = None           # (up[N-1], up_n, dn[N-1], dn_n)
+    round_trip: Any = None              # (n_tempered_restarts, n_round_trips)
+    index_process: Any = None           # int64 [replica][scan]
+    explorer_acceptance_pr: Any = None  # (mean[N], n[N]) keyed by chain
+    explorer_n_steps: Any = None        # (sum[N], n[N])
+    online: Any = None                  # (mean[d], var[d], n)
+    timing_extrema: Any = None          # {"round": seconds}
+
+
+@dataclass
+class NonReversiblePT:
+    """src/tempering/NonReversiblePT.jl:7-50"""
+    path: Any
+    schedule: T.Schedule
+    communication_barriers: Optional[T.CommunicationBarriers] = None
+
+
+@dataclass
+class Shared:
+    """src/pt/Shared.jl:12-48"""
+    iterators: Iterators
+    tempering: NonReversiblePT
+    explorer: Any
+    reports: list
+
+
+class PT:
+    """src/pt/PT.jl:6-51.  `replicas` is the device engine."""
+
+    def __init__(self, inputs: Inputs):
+        self.inputs = inputs
+        target = inputs.target
+        explorer = inputs.explorer if inputs.explorer is not None else default_explorer(target)
+        N = inputs.n_chains
+        sched = T.equally_spaced_schedule(N)
+        self.shared = Shared(Iterators(), NonReversiblePT(target, sched), explorer, [])
+        self.reduced_recorders = ReducedRecorders()
+        names = {b() for b in inputs.record}
+        flags = 0
+        if "round_trip" in names:
+            flags |= _lib.RECORD_ROUND_TRIP
+        if "index_process" in names:
+            flags |= _lib.RECORD_INDEX_PROCESS
+        if "online" in names:
+            flags |= _lib.RECORD_ONLINE
+        kw = dict(device=inputs.device, n_chains=N, seed=inputs.seed, record_flags=flags,
+                  max_scans_per_round=2 ** inputs.n_rounds)
+        if isinstance(target, ScaledPrecisionNormalPath):
+            kw.update(target=_lib.TARGET_MVN_SCALED_PRECISION, dim=target.dim,
+                      target_params=[target.precision0, target.precision1])
+        elif isinstance(target, TestSwapper):
+            kw.update(target=_lib.TARGET_TEST_SWAPPER, dim=1, target_params=[target.constant_swap_accept_pr])
+        else:
+            raise NotImplementedError(
+                "target %r has no device log-potential; use the reference CPU path (Pigeons.jl)" % (target,))
+        if explorer is None:
+            kw.update(explorer=_lib.EXPLORER_NONE)
+        elif isinstance(explorer, ToyExplorer):
+            kw.update(explorer=_lib.EXPLORER_TOY)
+        elif isinstance(explorer, SliceSampler):
+            kw.update(explorer=_lib.EXPLORER_SLICE, slice_w=explorer.w, slice_p=explorer.p,
+                      slice_n_passes=explorer.n_passes, slice_max_iter=explorer.max_iter)
+        else:
+            raise NotImplementedError("explorer %r is not available on the device" % (explorer,))
+        self.replicas = Engine(**kw)
+
+
+def next_round(pt):
+    """src/pt/Iterators.jl:27-35"""
+    it = pt.shared.iterators
+    if it.round + 1 <= pt.inputs.n_rounds:
+        it.round += 1
+        return True
+    return False
+
+
+def run_one_round(pt):
+    """src/pt/pigeons.jl:46-55: the scan loop runs fused on the device."""
+    it = pt.shared.iterators
+    eng = pt.replicas
+    n = n_scans_in_round(it)
+    t0 = time.perf_counter()
+    eng.run_scans(1, n)                  # explore!; communicate! for scan = 1..2^round (synchronous)
+    elapsed = time.perf_counter() - t0
+    it.scan = 0
+    return reduce_recorders(pt, elapsed)
+
+
+def reduce_recorders(pt, elapsed=None):
+    """src/recorders/recorders.jl:88-120"""
+    eng = pt.replicas
+    eng.reduce()
+    am, an, ss, sn = eng.explorer_stats()
+    r = ReducedRecorders(
+        swap_acceptance_pr=eng.swap_acceptance(),
+        log_sum_ratio=eng.log_sum_ratio(),
+        round_trip=eng.round_trip(),
+        index_process=eng.index_process(),
+        explorer_acceptance_pr=(am, an),
+        explorer_n_steps=(ss, sn),
+        online=eng.online(),
+        timing_extrema={"round": elapsed},
+    )
+    return r
+
+
+def adapt(pt, reduced):
+    """src/pt/pigeons.jl:152-162 with adapt_tempering (src/tempering/NonReversiblePT.jl:52-66)."""
+    temp = pt.shared.tempering
+    pt.reduced_recorders = reduced
+    if isinstance(pt.inputs.target, TestSwapper) or len(temp.schedule.grids) == 1:
+        return pt
+    mean, n = reduced.swap_acceptance_pr
+    rej = T.rejections(mean, n)
+    old = temp.schedule.grids
+    new_sched = T.Schedule(T.optimal_schedule(rej, old, len(old)))
+    barriers = T.CommunicationBarriers(rej, old)
+    pt.shared.tempering = NonReversiblePT(temp.path, new_sched, barriers)
+    pt.replicas.set_schedule(new_sched.grids)       # discretize(path, schedule) on the device
+    return pt
+
+
+def stepping_stone_pair(pt):
+    up, un, dn, dnn = pt.reduced_recorders.log_sum_ratio
+    return T.stepping_stone_pair(up, un, dn, dnn)
+
+
+def stepping_stone(pt):
+    return T.stepping_stone(stepping_stone_pair(pt))
+
+
+def n_round_trips(pt):
+    return pt.reduced_recorders.round_trip[1]
+
+
+def n_tempered_restarts(pt):
+    return pt.reduced_recorders.round_trip[0]
+
+
+def global_barrier(pt):
+    return pt.shared.tempering.communication_barriers.globalbarrier
+
+
+def last_round_max_time(pt):
+    """src/recorders/recorder.jl:137"""
+    return pt.reduced_recorders.timing_extrema["round"]
+
+
+def report(pt):
+    """One line of the reference's report table (src/pt/report.jl:8-20)."""
+    it = pt.shared.iterators
+    row = {"scans": n_scans_in_round(it), "time(s)": last_round_max_time(pt)}
+    if not isinstance(pt.inputs.target, TestSwapper) and pt.inputs.n_chains > 1:
+        m, n = pt.reduced_recorders.swap_acceptance_pr
+        row.update({"Λ": global_barrier(pt), "log(Z₁/Z₀)": stepping_stone(pt),
+                    "min(α)": float(np.min(m)), "mean(α)": float(np.mean(m))})
+    if pt.reduced_recorders.round_trip is not None:
+        row["restarts"], row["round trips"] = pt.reduced_recorders.round_trip
+    pt.shared.reports.append(row)
+    if pt.inputs.show_report:
+        print("  ".join("%s=%s" % (k, ("%.4g" % v) if isinstance(v, float) else v) for k, v in row.items()))
+
+
+def pigeons(pt_or_none=None, **kwargs):
+    """pigeons(; target, seed, n_rounds, n_chains, explorer, record, ...) -> PT  (src/api.jl:8-19)."""
+    pt = pt_or_none if pt_or_none is not None else PT(Inputs(**kwargs))
+    while next_round(pt):
+        reduced = run_one_round(pt)
+        pt = adapt(pt, reduced)
+        report(pt)
+    return pt

@@ -1,0 +1,253 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle on the same seed.
+
+Bar (BASELINE.json north_star): integer outputs (swap-index sequence, chains, RNG counters,
+round trips, step counts) bit-exact; floating-point recorders / schedule within 1e-6 relative
+(asserted much tighter here: 1e-9).  States are compared at 1e-12 relative: they are bit-identical
+except where a ziggurat slow path went through libm vs ocml log/exp (<= 1 ulp apart).
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pigeons_amd
+    return pigeons_amd
+
+
+def _mk(P, N, d, rounds, explorer, seed=1, record=None):
+    exp = {"toy": P.ToyExplorer(), "slice": P.SliceSampler()}[explorer]
+    record = record or [P.round_trip, P.index_process, P.log_sum_ratio, P.online]
+    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=exp, seed=seed,
+                       record=record, show_report=False))
+    ref = O.OraclePT(n_chains=N, dim=d, seed=seed, record_online=1,
+                     explorer={"toy": O.EXPLORER_TOY, "slice": O.EXPLORER_SLICE}[explorer])
+    return pt, ref
+
+
+def _check_round(P, pt, ref, check_states=True):
+    assert P.next_round(pt)
+    red = P.run_one_round(pt)
+    P.adapt(pt, red)
+    ref.run_round()
+    # integers: exact
+    assert np.array_equal(red.index_process, ref.index_process())
+    assert red.round_trip == ref.round_trip()
+    m, n = red.swap_acceptance_pr
+    mr, nr = ref.swap_pr()
+    assert np.array_equal(n, nr)
+    np.testing.assert_allclose(m, mr, rtol=RTOL)
+    up, un, dn, dnn = red.log_sum_ratio
+    upr, unr, dnr, dnnr = ref.log_sum_ratio()
+    assert np.array_equal(un, unr) and np.array_equal(dnn, dnnr)
+    np.testing.assert_allclose(up, upr, rtol=RTOL)
+    np.testing.assert_allclose(dn, dnr, rtol=RTOL)
+    am, an = red.explorer_acceptance_pr
+    ss, sn = red.explorer_n_steps
+    amr, anr, ssr, snr = ref.explorer_stats()
+    assert np.array_equal(an, anr) and np.array_equal(sn, snr)
+    assert np.array_equal(ss, ssr)                      # integer-valued sums
+    np.testing.assert_allclose(am, amr, rtol=RTOL)
+    # adapted schedule + stepping stone + barrier
+    np.testing.assert_allclose(pt.shared.tempering.schedule.grids, ref.schedule(), rtol=RTOL)
+    np.testing.assert_allclose(P.stepping_stone_pair(pt), ref.stepping_stone_pair(), rtol=RTOL)
+    np.testing.assert_allclose(P.global_barrier(pt), ref.global_barrier(), rtol=RTOL)
+    om, ov, on = red.online
+    omr, ovr, onr = ref.online()
+    assert on == onr
+    np.testing.assert_allclose(om, omr, rtol=1e-7, atol=1e-12)
+    np.testing.assert_allclose(ov, ovr, rtol=1e-7, atol=1e-12)
+    if check_states:
+        x, chain, rng = pt.replicas.states()
+        xr, cr, rr = ref.states()
+        assert np.array_equal(chain, cr)
+        assert np.array_equal(rng, rr)                  # every replica consumed exactly the same draws
+        np.testing.assert_allclose(x, xr, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("kind,n", [(0, 1000), (1, 20000), (2, 20000)])
+@pytest.mark.parametrize("seed", [1, 2, 12345])
+def test_device_rng_matches_oracle(P, kind, n, seed):
+    from pigeons_amd.engine import test_rng_fill
+    master = O.OracleRng(seed)
+    r = master.split()
+    out, st = test_rng_fill(r.state, kind, n)
+    f = [r.rand, r.randn, r.randexp][kind]
+    ref = np.array([f() for _ in range(n)])
+    assert st == r.state                              # same number of raw draws consumed
+    exact = np.mean(out == ref)
+    assert exact > 0.985, exact                        # fast paths are bit-identical
+    np.testing.assert_allclose(out, ref, rtol=1e-14, atol=0)   # slow paths: libm vs ocml, <= 1 ulp
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 10, 63, 64, 65, 100, 128, 1000, 1024, 1025, 4096])
+def test_sqr_norm_tree_matches_oracle(P, d):
+    from pigeons_amd.engine import test_sqr_norm
+    rng = np.random.default_rng(d)
+    x = rng.standard_normal((7, d)) * np.exp(rng.standard_normal((7, 1)) * 3)
+    out = test_sqr_norm(x)
+    L = O.lib()
+    ref = np.array([L.po_sqr_norm(O._dp(np.ascontiguousarray(row)), d) for row in x])
+    assert np.array_equal(out, ref)                   # identical reduction tree: bit-exact
+
+
+@pytest.mark.parametrize("N,d", [(10, 2), (5, 100), (3, 1024)])
+def test_create_replicas_matches_oracle(P, N, d):
+    pt, ref = _mk(P, N, d, 1, "toy")
+    x, chain, rng = pt.replicas.states()
+    xr, cr, rr = ref.states()
+    assert np.array_equal(chain, cr) and np.array_equal(rng, rr)
+    np.testing.assert_allclose(x, xr, rtol=1e-14, atol=0)
+    np.testing.assert_allclose(pt.replicas.schedule(), ref.schedule(), rtol=0, atol=0)
+
+
+def test_config1_quickstart_toy(P):
+    """BASELINE configs[0] with the target's default explorer: toy_mvn_target(2), N=10, 5 rounds."""
+    pt, ref = _mk(P, 10, 2, 5, "toy")
+    for _ in range(5):
+        _check_round(P, pt, ref)
+
+
+def test_config1_quickstart_slice(P):
+    """BASELINE configs[0]: toy_mvn_target(2), n_chains=10, n_rounds=5, SliceSampler."""
+    pt, ref = _mk(P, 10, 2, 5, "slice")
+    for _ in range(5):
+        _check_round(P, pt, ref)
+
+
+@pytest.mark.parametrize("N,d,rounds,seed", [
+    (6, 10, 7, 1),        # reference test_stepping_stone.jl shape
+    (7, 64, 4, 2),        # exactly one block, odd N
+    (4, 65, 4, 3),        # ragged second block
+    (12, 100, 4, 1),
+    (2, 33, 5, 5),        # only reference + target
+    (1, 8, 4, 1),         # single chain: no reference, no swaps
+    (9, 300, 3, 4),
+])
+def test_slice_sampler_parity(P, N, d, rounds, seed):
+    pt, ref = _mk(P, N, d, rounds, "slice", seed=seed)
+    for _ in range(rounds):
+        _check_round(P, pt, ref)
+
+
+def test_slice_sampler_parity_d1024(P):
+    """BASELINE configs[1] dimension (d=1024) at a chain count the O(d^2) oracle finishes in seconds."""
+    pt, ref = _mk(P, 6, 1024, 2, "slice")
+    for _ in range(2):
+        _check_round(P, pt, ref)
+
+
+@pytest.mark.parametrize("N,d,rounds", [(16, 128, 6), (5, 1024, 4), (33, 7, 6)])
+def test_toy_explorer_parity(P, N, d, rounds):
+    pt, ref = _mk(P, N, d, rounds, "toy")
+    for _ in range(rounds):
+        _check_round(P, pt, ref)
+
+
+def test_round_trips_kat_test_swapper(P):
+    """reference test/test_round_trips.jl:1-14: TestSwapper(1.0), N=4, 5 rounds => 13 round trips."""
+    n_chains, n_rounds = 4, 5
+    pt = P.pigeons(target=P.TestSwapper(1.0), record=[P.round_trip, P.index_process], n_chains=n_chains,
+                   n_rounds=n_rounds, show_report=False)
+    truth = sum(math.floor(max(2 ** n_rounds - i, 0) / n_chains / 2) for i in range(n_chains))
+    assert P.n_round_trips(pt) == truth == 13
+    ref = O.OraclePT(target=O.TARGET_TEST_SWAPPER, p0=1.0, n_chains=n_chains, explorer=O.EXPLORER_NONE)
+    for _ in range(n_rounds):
+        ref.run_round()
+    assert np.array_equal(pt.reduced_recorders.index_process, ref.index_process())
+    assert pt.reduced_recorders.round_trip == ref.round_trip()
+
+
+@pytest.mark.parametrize("pr", [0.0, 0.3, 0.7])
+def test_test_swapper_parity(P, pr):
+    pt = P.pigeons(target=P.TestSwapper(pr), record=[P.round_trip, P.index_process], n_chains=9, n_rounds=6,
+                   show_report=False, seed=3)
+    ref = O.OraclePT(target=O.TARGET_TEST_SWAPPER, p0=pr, n_chains=9, explorer=O.EXPLORER_NONE, seed=3)
+    for _ in range(6):
+        ref.run_round()
+    assert np.array_equal(pt.reduced_recorders.index_process, ref.index_process())
+    assert pt.reduced_recorders.round_trip == ref.round_trip()
+
+
+def test_stepping_stone_kat(P):
+    """reference test/test_stepping_stone.jl:15-27: |logZ error| < 0.2 at d=10, N=6, 12 rounds."""
+    pt = P.pigeons(target=P.toy_mvn_target(10), explorer=P.SliceSampler(), n_chains=6, n_rounds=12, show_report=False)
+    p = P.stepping_stone_pair(pt)
+    truth = P.analytic_lognormalization(P.toy_mvn_target(10))
+    assert abs(p[0] - truth) < 0.2 and abs(p[1] - truth) < 0.2
+
+
+def test_set_state_roundtrip_and_explore_swap_split(P):
+    """pte_explore + pte_swap called separately == pte_run_scans; get/set_state round-trips."""
+    a, _ = _mk(P, 8, 40, 3, "slice")
+    b, _ = _mk(P, 8, 40, 3, "slice")
+    a.replicas.run_scans(1, 6)
+    for s in range(1, 7):
+        b.replicas.explore(s)
+        b.replicas.swap(s)
+    xa, ca, ra = a.replicas.states()
+    xb, cb, rb = b.replicas.states()
+    assert np.array_equal(xa, xb) and np.array_equal(ca, cb) and np.array_equal(ra, rb)
+    c, _ = _mk(P, 8, 40, 3, "slice", seed=99)
+    c.replicas.set_states(xa, ca, ra)
+    a.replicas.run_scans(7, 4)
+    c.replicas.run_scans(7, 4)
+    xa, ca, ra = a.replicas.states()
+    xc, cc, rc = c.replicas.states()
+    assert np.array_equal(xa, xc) and np.array_equal(ca, cc) and np.array_equal(ra, rc)
+
+
+def test_errors_are_loud(P):
+    with pytest.raises(P.PteError):
+        P.Engine(n_chains=4, dim=5000)                # beyond the register-resident tree
+    e = P.Engine(n_chains=4, dim=8)
+    with pytest.raises(P.PteError):
+        e.set_schedule([0.0, 0.5, 0.4, 1.0])          # Schedule validity assert
+    with pytest.raises(P.PteError):
+        e.set_schedule([0.0, 1.0])
+
+
+def test_full_size_properties_metric_config(P):
+    """BASELINE metric configuration (d=1024, N=1024, SliceSampler): size-independent properties."""
+    from pigeons_amd.engine import test_sqr_norm
+    N, d = 1024, 1024
+    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=3, explorer=P.SliceSampler(),
+                       record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False))
+    x0, _, rng0 = pt.replicas.states()
+    for r in range(1, 4):
+        assert P.next_round(pt)
+        red = P.run_one_round(pt)
+        P.adapt(pt, red)
+        ip = red.index_process
+        assert ip.shape == (N, 2 ** r)
+        # every scan's chain assignment is a permutation; DEO moves a replica by at most one chain
+        assert np.array_equal(np.sort(ip, axis=0), np.tile(np.arange(N)[:, None], (1, 2 ** r)))
+        assert np.all(np.abs(np.diff(ip, axis=1)) <= 1)
+        m, n = red.swap_acceptance_pr
+        assert np.all((m >= 0) & (m <= 1)) and np.all(n == 2 ** (r - 1))
+        g = pt.shared.tempering.schedule.grids
+        assert g[0] == 0.0 and g[-1] == 1.0 and np.all(np.diff(g) > 0)
+    x, chain, rng = pt.replicas.states()
+    assert np.array_equal(np.sort(chain), np.arange(N))
+    assert np.all(rng[:, 1] == rng0[:, 1]) and np.all(rng[:, 0] != rng0[:, 0])   # gammas fixed, seeds advanced
+    assert np.all(np.isfinite(x))
+    # coordinates are resampled by every slice pass: nothing stuck at its initial value
+    moved = np.mean(x != x0)
+    assert moved > 0.999, moved
+    # the incrementally maintained tree root equals a full recompute (device) and the oracle's tree
+    L = O.lib()
+    full_dev = test_sqr_norm(x)
+    full_ref = np.array([L.po_sqr_norm(O._dp(np.ascontiguousarray(row)), d) for row in x])
+    assert np.array_equal(full_dev, full_ref)
+    # marginal scale sanity: chain c has precision in [1, 10]
+    prec = 1.0 + 9.0 * pt.shared.tempering.schedule.grids
+    v = np.var(x, axis=1)[np.argsort(chain)]
+    assert np.all(v < 2.0 / prec * 1.5) and np.all(v > 0.5 / prec / 1.5)
