@@ -59,7 +59,8 @@ class FritschCarlsonMonotonicInterpolation:
                 m[k] = 0.0; m[k + 1] = 0.0
                 continue
             a = m[k] / D[k]; b = m[k + 1] / D[k]
-            tau = 3.0 / math.sqrt(a * a + b * b)
+            den = math.sqrt(a * a + b * b)
+            tau = 3.0 / den if den != 0.0 else math.inf      # Julia: 3.0/0.0 == Inf
             if tau < 1.0:
                 m[k] = tau * a * D[k]; m[k + 1] = tau * b * D[k]
         c = np.zeros(n - 1); d = np.zeros(n - 1)
