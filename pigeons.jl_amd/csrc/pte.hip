@@ -13,6 +13,8 @@
 
 #include "../../include/pte.h"
 #include "pte_kernels.hpp"
+#include "pte_slice2.hpp"
+#include "pte_slice3.hpp"
 
 using namespace pte;
 
@@ -36,6 +38,7 @@ struct pte_engine {
     EngineDev dev{};
     hipStream_t stream = nullptr;
     int nlu = 0;
+    int slice_impl = 3, slice_m = 4;   // PTE_SLICE_IMPL=1 selects the plain sequential kernel (A/B + bisecting)
     int64_t N = 0, d = 0;
     std::vector<double> betas;
     std::vector<void *> allocs;
@@ -75,6 +78,17 @@ int dev_alloc(pte_engine *h, T **p, size_t n, bool zero = true) {
 }
 
 int next_pow2_log(int64_t n) { int l = 0; while (((int64_t)1 << l) < n) ++l; return l; }
+
+#define DISPATCH_NLU_M(nlu, KERNEL, MM, grid, block, stream, ...)                                 \
+    switch (nlu) {                                                                               \
+    case 0: hipLaunchKernelGGL((KERNEL<0, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    case 1: hipLaunchKernelGGL((KERNEL<1, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    case 2: hipLaunchKernelGGL((KERNEL<2, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    case 3: hipLaunchKernelGGL((KERNEL<3, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    case 4: hipLaunchKernelGGL((KERNEL<4, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    case 5: hipLaunchKernelGGL((KERNEL<5, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    default: hipLaunchKernelGGL((KERNEL<6, MM>), grid, block, 0, stream, __VA_ARGS__); break;    \
+    }
 
 #define DISPATCH_NLU(nlu, KERNEL, grid, block, stream, ...)                                      \
     switch (nlu) {                                                                               \
@@ -182,7 +196,17 @@ int launch_explore(pte_engine *h, int64_t scan) {
     case PTE_EXPLORER_SLICE: {
         SliceParams sp{h->cfg.slice_w, h->cfg.slice_p, h->cfg.slice_n_passes, h->cfg.slice_max_iter};
         time_begin(h, 0);
-        DISPATCH_NLU(h->nlu, k_explore_slice, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
+        if (h->slice_impl == 1) {
+            DISPATCH_NLU(h->nlu, k_explore_slice, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
+        } else if (h->slice_impl == 3) {
+            DISPATCH_NLU(h->nlu, k_explore_slice3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
+        } else if (h->slice_m == 3) {
+            DISPATCH_NLU_M(h->nlu, k_explore_slice2, 3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
+        } else if (h->slice_m == 6) {
+            DISPATCH_NLU_M(h->nlu, k_explore_slice2, 6, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
+        } else {
+            DISPATCH_NLU_M(h->nlu, k_explore_slice2, 4, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
+        }
         time_end(h);
         break;
     }
@@ -263,6 +287,8 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     if (hipStreamCreate(&h->stream) != hipSuccess) { h->err = "hipStreamCreate failed"; return bail(1); }
     const int64_t B = (d + 63) / 64;
     h->nlu = next_pow2_log(B > 0 ? B : 1);
+    if (const char *s = std::getenv("PTE_SLICE_IMPL")) h->slice_impl = std::atoi(s);
+    if (const char *s = std::getenv("PTE_SLICE_M")) h->slice_m = std::atoi(s);
     EngineDev &e = h->dev;
     e.N = N; e.d = d; e.ld = (d + 1) & ~(int64_t)1;
     e.record_flags = cfg->record_flags; e.target = cfg->target; e.test_swapper_pr = cfg->target_params[0];

@@ -1,0 +1,120 @@
+# PigeonsMI355X.jl -- the reference-side binding a Pigeons.jl maintainer would add.
+#
+# INERT IN THE BUILD IMAGE (no Julia toolchain; never executed there).  It shows how the three
+# dispatch hooks that bracket the hot path, plus construction / adaptation, bind to the C ABI of
+# include/pte.h.  Conventions follow the reference's only FFI precedent,
+# ext/PigeonsBridgeStanExt/interface.jl:118-183 (Cint return code, message fetched on error).
+module PigeonsMI355X
+
+using Pigeons
+using Pigeons: Inputs, Shared, Replica, PT, SliceSampler, ToyExplorer, ScaledPrecisionNormalPath
+
+const libpte = "libpte.so"
+
+# mirror of `pte_config` (include/pte.h) -- field order and types must match
+Base.@kwdef mutable struct PteConfig
+    struct_size::UInt32 = 0
+    abi_version::UInt32 = 1
+    device::Int32 = 0
+    target::Int32 = 0
+    explorer::Int32 = 1
+    record_flags::UInt32 = 3
+    n_chains::Int64 = 10
+    dim::Int64 = 1
+    seed::UInt64 = 1
+    max_scans_per_round::Int64 = 1024
+    target_params::NTuple{4,Float64} = (1.0, 10.0, 0.0, 0.0)
+    slice_w::Float64 = 10.0
+    slice_p::Int32 = 20
+    slice_n_passes::Int32 = 3
+    slice_max_iter::Int32 = 1024
+    am_base_n_refresh::Int32 = 3
+    am_exponent_n_refresh::Float64 = 0.35
+    am_step_size::Float64 = 1.0
+    am_p0::Float64 = 1/3
+    am_p1::Float64 = 1/3
+    am_preconditioner::Int32 = 2
+    rank::Int32 = 0
+    world_size::Int32 = 1
+    reserved::Int32 = 0
+end
+
+"""Device-resident `replicas` (informal interface src/replicas/replicas.jl:11-40)."""
+mutable struct DeviceReplicas
+    handle::Ptr{Cvoid}
+    n_chains::Int
+    dim::Int
+end
+
+function check(r::DeviceReplicas, rc::Cint)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:pte_last_error, libpte), Cstring, (Ptr{Cvoid},), r.handle))
+    error(msg)    # same wording class as the reference's exceptions (SliceSampler.jl:52-60,179-185)
+end
+
+# create_replicas(inputs, shared, source)  (src/replicas/replicas.jl:65-98)
+function Pigeons.create_replicas(inputs::Inputs{<:ScaledPrecisionNormalPath}, shared::Shared, ::Val{:mi355x})
+    cfg = PteConfig(n_chains = inputs.n_chains, dim = inputs.target.dim, seed = inputs.seed,
+                    max_scans_per_round = 2^inputs.n_rounds,
+                    target_params = (inputs.target.precision0, inputs.target.precision1, 0.0, 0.0))
+    cfg.struct_size = sizeof(PteConfig)
+    ex = shared.explorer
+    if ex isa SliceSampler
+        cfg.explorer = 2; cfg.slice_w = ex.w; cfg.slice_p = ex.p
+        cfg.slice_n_passes = ex.n_passes; cfg.slice_max_iter = ex.max_iter
+    elseif ex isa ToyExplorer
+        cfg.explorer = 1
+    else
+        error("explorer $(typeof(ex)) has no device kernel; use the CPU path")
+    end
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:pte_create, libpte), Cint, (Ref{PteConfig}, Ref{Ptr{Cvoid}}), cfg, h)
+    rc == 0 || error(unsafe_string(ccall((:pte_last_error, libpte), Cstring, (Ptr{Cvoid},), C_NULL)))
+    r = DeviceReplicas(h[], inputs.n_chains, inputs.target.dim)
+    finalizer(x -> ccall((:pte_destroy, libpte), Cint, (Ptr{Cvoid},), x.handle), r)
+    return r
+end
+
+# explore!(pt, explorer, ::Val)  (src/pt/pigeons.jl:82-97): one ccall for ALL local replicas
+Pigeons.explore!(pt::PT{<:Any,DeviceReplicas}, explorer, ::Val) =
+    check(pt.replicas, ccall((:pte_explore, libpte), Cint, (Ptr{Cvoid}, Int64), pt.replicas.handle, pt.shared.iterators.scan))
+
+# swap!(pair_swapper, replicas, swap_graph)  (src/swap/swap.jl:6): graph parity = iseven(scan)
+Pigeons.swap!(pair_swapper, r::DeviceReplicas, swap_graph::Pigeons.OddEven) =
+    check(r, ccall((:pte_swap, libpte), Cint, (Ptr{Cvoid}, Int64), r.handle, swap_graph.even ? 2 : 1))
+
+# run_one_round!: the fused `while next_scan!` loop (src/pt/pigeons.jl:46-55)
+function Pigeons.run_one_round!(pt::PT{<:Any,DeviceReplicas})
+    n = Pigeons.n_scans_in_round(pt.shared.iterators)
+    timed = @timed check(pt.replicas, ccall((:pte_run_scans, libpte), Cint, (Ptr{Cvoid}, Int64, Int64), pt.replicas.handle, 1, n))
+    pt.shared.iterators.scan = 0
+    return reduce_recorders!(pt, pt.replicas, timed)
+end
+
+# reduce_recorders!(pt, replicas)  (src/recorders/recorders.jl:88-120): rebuild the GroupBy recorders
+function reduce_recorders!(pt, r::DeviceReplicas, timed)
+    check(r, ccall((:pte_reduce, libpte), Cint, (Ptr{Cvoid},), r.handle))
+    N = r.n_chains
+    mean = zeros(N - 1); n = zeros(Int64, N - 1)
+    check(r, ccall((:pte_get_swap_acceptance, libpte), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}), r.handle, mean, n))
+    up = zeros(N - 1); dn = zeros(N - 1); un = zeros(Int64, N - 1); dnn = zeros(Int64, N - 1)
+    check(r, ccall((:pte_get_log_sum_ratio, libpte), Cint,
+                   (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Ptr{Int64}), r.handle, up, un, dn, dnn))
+    recorders = Pigeons.create_recorders(pt.inputs, pt.shared)
+    for i in 1:(N-1)                       # 1-based chains on the Julia side
+        n[i] > 0 || continue
+        recorders.swap_acceptance_pr.value[(i, i + 1)] = Pigeons.Mean(mean[i], Pigeons.EqualWeight(), n[i])
+        recorders.log_sum_ratio.value[(i, i + 1)] = Pigeons.LogSum(up[i], un[i])
+        recorders.log_sum_ratio.value[(i + 1, i)] = Pigeons.LogSum(dn[i], dnn[i])
+    end
+    # round_trip, index_process, explorer_* are filled the same way from pte_get_round_trip,
+    # pte_get_index_process (+1 for 1-based chains), pte_get_explorer_stats.
+    Pigeons.record_timed_if_requested!(recorders, :round, timed)
+    return recorders
+end
+
+# adapt_tempering -> new Schedule -> discretize on the device (src/tempering/NonReversiblePT.jl:46-66)
+set_schedule!(r::DeviceReplicas, schedule::Pigeons.Schedule) =
+    check(r, ccall((:pte_set_schedule, libpte), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), r.handle, schedule.grids, length(schedule.grids)))
+
+end # module
