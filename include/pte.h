@@ -118,7 +118,8 @@ int pte_run_scans(pte_engine *h, int64_t first_scan, int64_t n_scans);
  * device (incl. the round-trip state machines, RoundTripRecorder.jl:30-34). */
 int pte_reduce(pte_engine *h);
 
-/* Reduced recorders of the last pte_reduce. Array lengths in brackets. */
+/* Reduced recorders of the last pte_reduce. Array lengths in brackets (world_size == 1; a sharded
+ * engine returns its local slice: pairs keyed by a local lower chain, chains [c0, c0+K)). */
 int pte_get_swap_acceptance(const pte_engine *h, double *mean /*N-1*/, int64_t *n /*N-1*/);
 int pte_get_log_sum_ratio(const pte_engine *h, double *up /*N-1*/, int64_t *up_n, double *dn /*N-1*/, int64_t *dn_n);
 int pte_get_round_trip(const pte_engine *h, int64_t *n_tempered_restarts, int64_t *n_round_trips);
@@ -133,6 +134,29 @@ int pte_get_online(const pte_engine *h, double *mean /*d*/, double *variance /*d
  * rng [2N] = (seed, gamma) of each SplittableRandom.  NULL pointers are skipped. */
 int pte_get_state(const pte_engine *h, double *state, int64_t *chain, uint64_t *rng);
 int pte_set_state(pte_engine *h, const double *state, const int64_t *chain, const uint64_t *rng);
+
+/* ---- chain-sharded engines (one engine per GPU; rank g owns chains [g*N/G, (g+1)*N/G)) -----------
+ * The reference's distributed swap! (src/swap/swap.jl:79-102) exchanges 16-byte SwapStats with the
+ * partner replica's rank and moves chain labels.  Here the shard boundary is between CHAINS, so only
+ * the G-1 boundary pairs cross GPUs: their SwapStats are exchanged between the two phases below and,
+ * iff the swap is accepted, the two replicas' payloads {state, sum x^2, rng, replica id, round-trip
+ * state} trade places.  The host moves the bytes (RCCL send/recv over xGMI between ranks; a plain
+ * copy between engines of one process).  side: 0 = pair (c0-1, c0), 1 = pair (c0+K-1, c0+K).
+ * With world_size == 1 these calls are valid too (no boundary is ever active) and equal pte_swap. */
+int pte_shard_info(const pte_engine *h, int64_t *first_chain, int64_t *n_local_chains, int64_t *n_local_pairs);
+/* phase 1: swap_stat of every local chain (one rand per replica), index_process / round_trip records.
+ * stats_out[4] = (log_ratio, uniform) of the lowest and of the highest local chain;
+ * active_out[2] = whether the boundary pair on that side is a pair of this scan's DEO graph. */
+int pte_swap_begin(pte_engine *h, int64_t scan, double *stats_out, int32_t *active_out);
+/* phase 2: nbr_stats[4] = SwapStats received from the lower / upper neighbour (ignored where inactive);
+ * decisions, recorders, chain relabelling of local pairs; accepted_out[2] = boundary swap accepted. */
+int pte_swap_finish(pte_engine *h, int64_t scan, const double *nbr_stats, int32_t *accepted_out);
+int64_t pte_boundary_payload_bytes(const pte_engine *h);            /* 8 * (d + 5) */
+int pte_boundary_export(pte_engine *h, int side, void *dst, int dst_is_device);
+int pte_boundary_import(pte_engine *h, int side, const void *src, int src_is_device);
+/* index process of the local slots: replica[scan][K], chain[scan][K] (global ids). */
+int pte_get_index_process_shard(const pte_engine *h, int64_t *replica, int64_t *chain, int64_t *n_scans);
+int pte_get_replica_ids(const pte_engine *h, int64_t *out /*K*/);
 
 /* Measurement hooks (bench.py): per-kernel HIP-event timing accumulated on the engine's stream
  * over pte_run_scans calls since the last reset.  kernel: 0 = explore, 1 = swap. */

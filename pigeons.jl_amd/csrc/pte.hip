@@ -28,7 +28,8 @@ struct Snapshot {   // reduced recorders of the last round, host side
     int64_t restarts = 0, trips = 0;
     std::vector<double> acc_mean, steps_sum; std::vector<int64_t> acc_n, steps_n;
     std::vector<double> on_mean, on_var; int64_t on_n = 0;
-    std::vector<int64_t> index_process; int64_t n_scans = 0;
+    std::vector<int32_t> ip_chain, ip_replica;   // [scan][slot]
+    int64_t n_scans = 0;
 };
 
 }  // namespace
@@ -38,8 +39,13 @@ struct pte_engine {
     EngineDev dev{};
     hipStream_t stream = nullptr;
     int nlu = 0;
-    int slice_impl = 3, slice_m = 4;   // PTE_SLICE_IMPL=1 selects the plain sequential kernel (A/B + bisecting)
-    int64_t N = 0, d = 0;
+    int slice_impl = 2, slice_m = 4;   // PTE_SLICE_IMPL=1 selects the plain sequential kernel (A/B + bisecting)
+    int64_t N = 0, d = 0;          // global chains, state dimension
+    int64_t K = 0, c0 = 0;         // local chains [c0, c0+K)
+    int world = 1, rank = 0;
+    int32_t *slot_map[2] = {nullptr, nullptr};   // ping-pong buffers of slot_of_chain (two-phase swap)
+    int slot_cur = 0;
+    double *d_payload = nullptr;   // staging buffer for boundary export/import
     std::vector<double> betas;
     std::vector<void *> allocs;
     double *d_nhp = nullptr, *d_sd = nullptr;
@@ -123,7 +129,7 @@ int upload_ladder(pte_engine *h) {
 
 int reset_recorders(pte_engine *h) {
     EngineDev &e = h->dev;
-    const int64_t N = h->N, np = N > 1 ? N - 1 : 1;
+    const int64_t N = h->K, np = h->K;       // per-shard sizes: K slots, K pairs keyed by their lower chain
     HIP_OK(h, hipMemsetAsync(e.swap_sum, 0, sizeof(double) * np, h->stream));
     HIP_OK(h, hipMemsetAsync(e.swap_n, 0, sizeof(int64_t) * np, h->stream));
     std::vector<double> ninf(np, -INFINITY);
@@ -185,7 +191,7 @@ void time_collect(pte_engine *h) {
 
 int launch_explore(pte_engine *h, int64_t scan) {
     (void)scan;
-    const int64_t N = h->N;
+    const int64_t N = h->K;
     switch (h->cfg.explorer) {
     case PTE_EXPLORER_NONE: return 0;
     case PTE_EXPLORER_TOY:
@@ -217,10 +223,11 @@ int launch_explore(pte_engine *h, int64_t scan) {
 }
 
 int launch_swap(pte_engine *h, int64_t scan) {
-    const int64_t N = h->N;
+    const int64_t N = h->K;
     if ((h->cfg.record_flags & PTE_RECORD_INDEX_PROCESS) && h->scans_in_round >= h->cfg.max_scans_per_round)
         return fail(h, "index_process buffer full: %lld scans since the last pte_reduce (max_scans_per_round = %lld)",
                     (long long)h->scans_in_round, (long long)h->cfg.max_scans_per_round);
+    if (h->world != 1) return fail(h, "pte_swap / pte_run_scans need world_size == 1; sharded engines use pte_swap_begin / pte_swap_finish");
     const int even = (scan % 2 == 0) ? 1 : 0;          // create_swap_graph(::DEO), DEO.jl:12
     const unsigned block = 256, grid = (unsigned)((N + block - 1) / block);
     time_begin(h, 1);
@@ -229,6 +236,17 @@ int launch_swap(pte_engine *h, int64_t scan) {
     HIP_OK(h, hipGetLastError());
     h->scans_in_round += 1;
     return 0;
+}
+
+// boundary pair activity of this shard on the given graph: side 0 = (c0-1, c0), side 1 = (c0+K-1, c0+K)
+void boundary_active(const pte_engine *h, int even, int32_t active[2]) {
+    auto partner = [&](int64_t c) {
+        const bool chain_even = ((c + 1) % 2 == 0);
+        int64_t proposed = (c + 1) + ((chain_even == (even != 0)) ? 1 : -1);
+        return (proposed == 0) ? (int64_t)0 : (proposed == h->N + 1 ? h->N - 1 : proposed - 1);
+    };
+    active[0] = (h->c0 > 0 && partner(h->c0) == h->c0 - 1) ? 1 : 0;
+    active[1] = (h->c0 + h->K < h->N && partner(h->c0 + h->K - 1) == h->c0 + h->K) ? 1 : 0;
 }
 
 }  // namespace
@@ -263,7 +281,8 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
         return fail(nullptr, "pte_create: ABI mismatch (struct_size %u vs %zu, version %u vs %d)",
                     cfg->struct_size, sizeof(pte_config), cfg->abi_version, PTE_ABI_VERSION);
     if (cfg->n_chains < 1) return fail(nullptr, "pte_create: n_chains must be >= 1");
-    if (cfg->world_size != 1) return fail(nullptr, "pte_create: world_size > 1 is driven by the host-side sharding layer");
+    if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, "pte_create: bad rank / world_size");
+    if (cfg->n_chains % cfg->world_size != 0) return fail(nullptr, "pte_create: n_chains (%lld) must be a multiple of world_size (%d)", (long long)cfg->n_chains, cfg->world_size);
     const bool swapper = cfg->target == PTE_TARGET_TEST_SWAPPER;
     if (!swapper && cfg->target != PTE_TARGET_MVN_SCALED_PRECISION)
         return fail(nullptr, "pte_create: target %d has no device log-potential; use the reference CPU path", cfg->target);
@@ -282,6 +301,9 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     h->cfg = *cfg;
     const int64_t N = h->N = cfg->n_chains;
     const int64_t d = h->d = swapper ? 0 : cfg->dim;
+    h->world = cfg->world_size; h->rank = cfg->rank;
+    const int64_t K = h->K = N / cfg->world_size;
+    h->c0 = K * cfg->rank;
     auto bail = [&](int) { g_create_error = h->err; pte_destroy(h); return 1; };
     if (hipSetDevice(cfg->device) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(1); }
     if (hipStreamCreate(&h->stream) != hipSuccess) { h->err = "hipStreamCreate failed"; return bail(1); }
@@ -290,31 +312,39 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     if (const char *s = std::getenv("PTE_SLICE_IMPL")) h->slice_impl = std::atoi(s);
     if (const char *s = std::getenv("PTE_SLICE_M")) h->slice_m = std::atoi(s);
     EngineDev &e = h->dev;
-    e.N = N; e.d = d; e.ld = (d + 1) & ~(int64_t)1;
+    e.N = N; e.K = K; e.c0 = h->c0; e.d = d; e.ld = (d + 1) & ~(int64_t)1;
     e.record_flags = cfg->record_flags; e.target = cfg->target; e.test_swapper_pr = cfg->target_params[0];
-    const int64_t np = N > 1 ? N - 1 : 1, dd = d > 0 ? d : 1;
+    const int64_t dd = d > 0 ? d : 1;
     int rc = 0;
-    rc |= dev_alloc(h, &e.x, (size_t)(N * (e.ld > 0 ? e.ld : 1)));
-    rc |= dev_alloc(h, &e.rng, (size_t)(2 * N));
-    rc |= dev_alloc(h, &e.chain_of_slot, (size_t)N);
-    rc |= dev_alloc(h, &e.slot_of_chain, (size_t)N);
-    rc |= dev_alloc(h, &e.suff, (size_t)N);
+    rc |= dev_alloc(h, &e.x, (size_t)(K * (e.ld > 0 ? e.ld : 1)));
+    rc |= dev_alloc(h, &e.rng, (size_t)(2 * K));
+    rc |= dev_alloc(h, &e.chain_of_slot, (size_t)K);
+    rc |= dev_alloc(h, &h->slot_map[0], (size_t)K);
+    rc |= dev_alloc(h, &h->slot_map[1], (size_t)K);
+    rc |= dev_alloc(h, &e.replica_id, (size_t)K);
+    rc |= dev_alloc(h, &e.stat, (size_t)(2 * K));
+    rc |= dev_alloc(h, &e.nbr_stat, 4);
+    rc |= dev_alloc(h, &e.bflag, 2);
+    rc |= dev_alloc(h, &h->d_payload, (size_t)(dd + 8));
+    rc |= dev_alloc(h, &e.suff, (size_t)K);
     rc |= dev_alloc(h, &h->d_nhp, (size_t)N);
     rc |= dev_alloc(h, &h->d_sd, (size_t)N);
-    rc |= dev_alloc(h, &e.swap_sum, (size_t)np);  rc |= dev_alloc(h, &e.swap_n, (size_t)np);
-    rc |= dev_alloc(h, &e.lsr_up, (size_t)np);    rc |= dev_alloc(h, &e.lsr_dn, (size_t)np);
-    rc |= dev_alloc(h, &e.lsr_n, (size_t)np);
-    rc |= dev_alloc(h, &e.rt_state, (size_t)N);   rc |= dev_alloc(h, &e.rt_restarts, (size_t)N);
-    rc |= dev_alloc(h, &e.rt_trips, (size_t)N);
-    rc |= dev_alloc(h, &e.expl_acc_sum, (size_t)N);   rc |= dev_alloc(h, &e.expl_acc_n, (size_t)N);
-    rc |= dev_alloc(h, &e.expl_steps_sum, (size_t)N); rc |= dev_alloc(h, &e.expl_steps_n, (size_t)N);
+    rc |= dev_alloc(h, &e.swap_sum, (size_t)K);  rc |= dev_alloc(h, &e.swap_n, (size_t)K);
+    rc |= dev_alloc(h, &e.lsr_up, (size_t)K);    rc |= dev_alloc(h, &e.lsr_dn, (size_t)K);
+    rc |= dev_alloc(h, &e.lsr_n, (size_t)K);
+    rc |= dev_alloc(h, &e.rt_state, (size_t)K);   rc |= dev_alloc(h, &e.rt_restarts, (size_t)K);
+    rc |= dev_alloc(h, &e.rt_trips, (size_t)K);
+    rc |= dev_alloc(h, &e.expl_acc_sum, (size_t)K);   rc |= dev_alloc(h, &e.expl_acc_n, (size_t)K);
+    rc |= dev_alloc(h, &e.expl_steps_sum, (size_t)K); rc |= dev_alloc(h, &e.expl_steps_n, (size_t)K);
     rc |= dev_alloc(h, &e.on_mean, (size_t)dd);   rc |= dev_alloc(h, &e.on_m2, (size_t)dd);
     rc |= dev_alloc(h, &e.on_n, 1);
-    const int64_t ipcap = (cfg->record_flags & PTE_RECORD_INDEX_PROCESS) ? cfg->max_scans_per_round * N : 1;
+    const int64_t ipcap = (cfg->record_flags & PTE_RECORD_INDEX_PROCESS) ? cfg->max_scans_per_round * K : 1;
     rc |= dev_alloc(h, &e.index_process, (size_t)ipcap, false);
+    rc |= dev_alloc(h, &e.ip_replica, (size_t)ipcap, false);
     rc |= dev_alloc(h, &e.error, 4);
     if (rc) return bail(1);
     e.nhp = h->d_nhp; e.sd = h->d_sd;
+    e.slot_of_chain = h->slot_map[0]; e.slot_of_chain_alt = h->slot_map[1]; h->slot_cur = 0;
 
     // equally_spaced_schedule (reference src/schedules/Schedule.jl:36-44)
     h->betas.resize(N);
@@ -323,7 +353,7 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     if (upload_ladder(h)) return bail(1);
     if (reset_recorders(h)) return bail(1);
     const double init_sd = swapper ? 1.0 : std::sqrt(cfg->target_params[1]);   // toy_mvn_target.jl:10-11
-    DISPATCH_NLU(h->nlu, k_init, dim3((unsigned)N), dim3(64), h->stream, e, (uint64_t)cfg->seed, init_sd);
+    DISPATCH_NLU(h->nlu, k_init, dim3((unsigned)K), dim3(64), h->stream, e, (uint64_t)cfg->seed, init_sd);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
         h->err = "k_init launch failed"; return bail(1);
     }
@@ -398,52 +428,61 @@ int pte_run_scans(pte_engine *h, int64_t first_scan, int64_t n_scans) {
 int pte_reduce(pte_engine *h) {
     if (!h) return 1;
     HIP_OK(h, hipSetDevice(h->cfg.device));
-    const int64_t N = h->N, np = N > 1 ? N - 1 : 1, d = h->d;
+    const int64_t K = h->K, d = h->d;
     EngineDev &e = h->dev;
     Snapshot &s = h->snap;
-    std::vector<double> swap_sum(np);
-    s.swap_mean.assign(np, 0.0); s.swap_n.assign(np, 0);
-    s.lsr_up.assign(np, 0.0); s.lsr_dn.assign(np, 0.0); s.lsr_n.assign(np, 0);
-    std::vector<int64_t> rs(N), rr(N);
-    std::vector<double> acc_sum(N);
-    s.acc_mean.assign(N, 0.0); s.acc_n.assign(N, 0); s.steps_sum.assign(N, 0.0); s.steps_n.assign(N, 0);
+    std::vector<double> swap_sum(K);
+    s.swap_mean.assign(K, 0.0); s.swap_n.assign(K, 0);
+    s.lsr_up.assign(K, 0.0); s.lsr_dn.assign(K, 0.0); s.lsr_n.assign(K, 0);
+    std::vector<int64_t> rs(K), rr(K);
+    std::vector<double> acc_sum(K);
+    s.acc_mean.assign(K, 0.0); s.acc_n.assign(K, 0); s.steps_sum.assign(K, 0.0); s.steps_n.assign(K, 0);
     const int64_t dd = d > 0 ? d : 1;
     std::vector<double> m2(dd);
     s.on_mean.assign(dd, 0.0); s.on_var.assign(dd, 0.0);
 #define D2H(dst, src, n) HIP_OK(h, hipMemcpyAsync(dst, src, sizeof(*(dst)) * (n), hipMemcpyDeviceToHost, h->stream))
-    D2H(swap_sum.data(), e.swap_sum, np); D2H(s.swap_n.data(), e.swap_n, np);
-    D2H(s.lsr_up.data(), e.lsr_up, np);   D2H(s.lsr_dn.data(), e.lsr_dn, np);   D2H(s.lsr_n.data(), e.lsr_n, np);
-    D2H(rs.data(), e.rt_restarts, N);     D2H(rr.data(), e.rt_trips, N);
-    D2H(acc_sum.data(), e.expl_acc_sum, N); D2H(s.acc_n.data(), e.expl_acc_n, N);
-    D2H(s.steps_sum.data(), e.expl_steps_sum, N); D2H(s.steps_n.data(), e.expl_steps_n, N);
+    D2H(swap_sum.data(), e.swap_sum, K); D2H(s.swap_n.data(), e.swap_n, K);
+    D2H(s.lsr_up.data(), e.lsr_up, K);   D2H(s.lsr_dn.data(), e.lsr_dn, K);   D2H(s.lsr_n.data(), e.lsr_n, K);
+    D2H(rs.data(), e.rt_restarts, K);     D2H(rr.data(), e.rt_trips, K);
+    D2H(acc_sum.data(), e.expl_acc_sum, K); D2H(s.acc_n.data(), e.expl_acc_n, K);
+    D2H(s.steps_sum.data(), e.expl_steps_sum, K); D2H(s.steps_n.data(), e.expl_steps_n, K);
     D2H(s.on_mean.data(), e.on_mean, dd); D2H(m2.data(), e.on_m2, dd); D2H(&s.on_n, e.on_n, 1);
     s.n_scans = h->scans_in_round;
-    std::vector<int32_t> ip;
+    s.ip_chain.clear(); s.ip_replica.clear();
     if (h->cfg.record_flags & PTE_RECORD_INDEX_PROCESS) {
-        ip.resize((size_t)(s.n_scans * N));
-        if (!ip.empty()) D2H(ip.data(), e.index_process, (size_t)(s.n_scans * N));
+        s.ip_chain.resize((size_t)(s.n_scans * K)); s.ip_replica.resize((size_t)(s.n_scans * K));
+        if (!s.ip_chain.empty()) {
+            D2H(s.ip_chain.data(), e.index_process, (size_t)(s.n_scans * K));
+            D2H(s.ip_replica.data(), e.ip_replica, (size_t)(s.n_scans * K));
+        }
     }
 #undef D2H
     HIP_OK(h, hipStreamSynchronize(h->stream));
-    for (int64_t i = 0; i < np; ++i) s.swap_mean[i] = s.swap_n[i] > 0 ? swap_sum[i] / (double)s.swap_n[i] : 0.0;
+    for (int64_t i = 0; i < K; ++i) s.swap_mean[i] = s.swap_n[i] > 0 ? swap_sum[i] / (double)s.swap_n[i] : 0.0;
     s.restarts = 0; s.trips = 0;
-    for (int64_t i = 0; i < N; ++i) { s.restarts += rs[i]; s.trips += rr[i]; }
-    for (int64_t i = 0; i < N; ++i) s.acc_mean[i] = s.acc_n[i] > 0 ? acc_sum[i] / (double)s.acc_n[i] : 0.0;
+    for (int64_t i = 0; i < K; ++i) { s.restarts += rs[i]; s.trips += rr[i]; }
+    for (int64_t i = 0; i < K; ++i) s.acc_mean[i] = s.acc_n[i] > 0 ? acc_sum[i] / (double)s.acc_n[i] : 0.0;
     for (int64_t i = 0; i < dd; ++i) s.on_var[i] = s.on_n > 1 ? m2[i] / (double)(s.on_n - 1) : 1.0;
-    s.index_process.assign((size_t)(s.n_scans * N), 0);
-    for (int64_t t = 0; t < s.n_scans && !ip.empty(); ++t)
-        for (int64_t r = 0; r < N; ++r) s.index_process[(size_t)(r * s.n_scans + t)] = ip[(size_t)(t * N + r)];
     return reset_recorders(h);
 }
 
+static int64_t local_pairs(const pte_engine *h) { return (h->c0 + h->K < h->N) ? h->K : h->K - 1; }
+
+int pte_shard_info(const pte_engine *h, int64_t *c0, int64_t *K, int64_t *n_pairs) {
+    if (!h) return 1;
+    if (c0) *c0 = h->c0;
+    if (K) *K = h->K;
+    if (n_pairs) *n_pairs = local_pairs(h);
+    return 0;
+}
 int pte_get_swap_acceptance(const pte_engine *h, double *mean, int64_t *n) {
     if (!h) return 1;
-    for (int64_t i = 0; i + 1 < h->N; ++i) { mean[i] = h->snap.swap_mean[i]; n[i] = h->snap.swap_n[i]; }
+    for (int64_t i = 0; i < local_pairs(h); ++i) { mean[i] = h->snap.swap_mean[i]; n[i] = h->snap.swap_n[i]; }
     return 0;
 }
 int pte_get_log_sum_ratio(const pte_engine *h, double *up, int64_t *up_n, double *dn, int64_t *dn_n) {
     if (!h) return 1;
-    for (int64_t i = 0; i + 1 < h->N; ++i) {
+    for (int64_t i = 0; i < local_pairs(h); ++i) {
         up[i] = h->snap.lsr_up[i]; dn[i] = h->snap.lsr_dn[i];
         up_n[i] = h->snap.lsr_n[i]; dn_n[i] = h->snap.lsr_n[i];
     }
@@ -456,14 +495,28 @@ int pte_get_round_trip(const pte_engine *h, int64_t *restarts, int64_t *trips) {
 }
 int pte_get_index_process(const pte_engine *h, int64_t *out, int64_t *n_scans) {
     if (!h) return 1;
+    if (h->world != 1) return fail(const_cast<pte_engine *>(h), "pte_get_index_process: sharded engines use pte_get_index_process_shard");
+    const int64_t T = h->snap.n_scans, N = h->N;
+    if (n_scans) *n_scans = T;
+    if (out && !h->snap.ip_chain.empty())
+        for (int64_t t = 0; t < T; ++t)
+            for (int64_t sl = 0; sl < N; ++sl)
+                out[(size_t)(h->snap.ip_replica[(size_t)(t * N + sl)] * T + t)] = h->snap.ip_chain[(size_t)(t * N + sl)];
+    return 0;
+}
+int pte_get_index_process_shard(const pte_engine *h, int64_t *replica, int64_t *chain, int64_t *n_scans) {
+    if (!h) return 1;
     if (n_scans) *n_scans = h->snap.n_scans;
-    if (out && !h->snap.index_process.empty())
-        std::memcpy(out, h->snap.index_process.data(), sizeof(int64_t) * h->snap.index_process.size());
+    const size_t n = h->snap.ip_chain.size();
+    for (size_t i = 0; i < n; ++i) {
+        if (replica) replica[i] = h->snap.ip_replica[i];
+        if (chain) chain[i] = h->snap.ip_chain[i];
+    }
     return 0;
 }
 int pte_get_explorer_stats(const pte_engine *h, double *am, int64_t *an, double *ss, int64_t *sn) {
     if (!h) return 1;
-    for (int64_t i = 0; i < h->N; ++i) {
+    for (int64_t i = 0; i < h->K; ++i) {
         am[i] = h->snap.acc_mean[i]; an[i] = h->snap.acc_n[i];
         ss[i] = h->snap.steps_sum[i]; sn[i] = h->snap.steps_n[i];
     }
@@ -471,7 +524,7 @@ int pte_get_explorer_stats(const pte_engine *h, double *am, int64_t *an, double 
 }
 int pte_get_automala_stats(const pte_engine *h, double *fm, int64_t *fn, double *rm, int64_t *rn) {
     if (!h) return 1;
-    for (int64_t i = 0; i < h->N; ++i) { fm[i] = 0; fn[i] = 0; rm[i] = 0; rn[i] = 0; }
+    for (int64_t i = 0; i < h->K; ++i) { fm[i] = 0; fn[i] = 0; rm[i] = 0; rn[i] = 0; }
     return 0;
 }
 int pte_get_online(const pte_engine *h, double *mean, double *variance, int64_t *n) {
@@ -480,12 +533,86 @@ int pte_get_online(const pte_engine *h, double *mean, double *variance, int64_t 
     if (n) *n = h->snap.on_n;
     return 0;
 }
+int pte_get_replica_ids(const pte_engine *hc, int64_t *out) {
+    pte_engine *h = const_cast<pte_engine *>(hc);
+    if (!h || !out) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    HIP_OK(h, hipMemcpyAsync(out, h->dev.replica_id, sizeof(int64_t) * h->K, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- two-phase swap of chain-sharded engines ---------------------------------------------------
+int pte_swap_begin(pte_engine *h, int64_t scan, double *stats_out, int32_t *active_out) {
+    if (!h || !stats_out || !active_out) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    const int64_t K = h->K;
+    if ((h->cfg.record_flags & PTE_RECORD_INDEX_PROCESS) && h->scans_in_round >= h->cfg.max_scans_per_round)
+        return fail(h, "index_process buffer full (max_scans_per_round = %lld)", (long long)h->cfg.max_scans_per_round);
+    const int even = (scan % 2 == 0) ? 1 : 0;
+    const unsigned block = 256, grid = (unsigned)((K + block - 1) / block);
+    time_begin(h, 1);
+    hipLaunchKernelGGL(k_swap_stats, dim3(grid), dim3(block), 0, h->stream, h->dev, even, h->scans_in_round);
+    time_end(h);
+    HIP_OK(h, hipGetLastError());
+    boundary_active(h, even, active_out);
+    HIP_OK(h, hipMemcpyAsync(stats_out, h->dev.stat, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipMemcpyAsync(stats_out + 2, h->dev.stat + 2 * (K - 1), 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+int pte_swap_finish(pte_engine *h, int64_t scan, const double *nbr_stats, int32_t *accepted_out) {
+    if (!h || !nbr_stats || !accepted_out) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    const int64_t K = h->K;
+    const int even = (scan % 2 == 0) ? 1 : 0;
+    HIP_OK(h, hipMemcpyAsync(h->dev.nbr_stat, nbr_stats, 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipMemsetAsync(h->dev.bflag, 0, 2 * sizeof(int32_t), h->stream));
+    const unsigned block = 256, grid = (unsigned)((K + block - 1) / block);
+    time_begin(h, 1);
+    hipLaunchKernelGGL(k_swap_decide, dim3(grid), dim3(block), 0, h->stream, h->dev, even);
+    time_end(h);
+    HIP_OK(h, hipGetLastError());
+    h->slot_cur ^= 1;                                   // the decide kernel wrote the new chain -> slot map
+    h->dev.slot_of_chain = h->slot_map[h->slot_cur];
+    h->dev.slot_of_chain_alt = h->slot_map[h->slot_cur ^ 1];
+    HIP_OK(h, hipMemcpyAsync(accepted_out, h->dev.bflag, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    h->scans_in_round += 1;
+    int rc = check_device_error(h);                     // synchronises
+    time_collect(h);
+    return rc;
+}
+int64_t pte_boundary_payload_bytes(const pte_engine *h) { return h ? (int64_t)sizeof(double) * (h->d + 5) : 0; }
+int pte_boundary_export(pte_engine *h, int side, void *dst, int dst_is_device) {
+    if (!h || !dst || side < 0 || side > 1) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    double *buf = dst_is_device ? (double *)dst : h->d_payload;
+    hipLaunchKernelGGL(k_boundary_export, dim3(1), dim3(256), 0, h->stream, h->dev, side, buf);
+    HIP_OK(h, hipGetLastError());
+    if (!dst_is_device)
+        HIP_OK(h, hipMemcpyAsync(dst, h->d_payload, (size_t)pte_boundary_payload_bytes(h), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+int pte_boundary_import(pte_engine *h, int side, const void *src, int src_is_device) {
+    if (!h || !src || side < 0 || side > 1) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    const double *buf = (const double *)src;
+    if (!src_is_device) {
+        HIP_OK(h, hipMemcpyAsync(h->d_payload, src, (size_t)pte_boundary_payload_bytes(h), hipMemcpyHostToDevice, h->stream));
+        buf = h->d_payload;
+    }
+    hipLaunchKernelGGL(k_boundary_import, dim3(1), dim3(256), 0, h->stream, h->dev, side, buf);
+    HIP_OK(h, hipGetLastError());
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
 
 int pte_get_state(const pte_engine *hc, double *state, int64_t *chain, uint64_t *rng) {
     pte_engine *h = const_cast<pte_engine *>(hc);
     if (!h) return 1;
     HIP_OK(h, hipSetDevice(h->cfg.device));
-    const int64_t N = h->N, d = h->d;
+    const int64_t N = h->K, d = h->d;
     if (state && d > 0)
         HIP_OK(h, hipMemcpy2DAsync(state, sizeof(double) * d, h->dev.x, sizeof(double) * h->dev.ld,
                                    sizeof(double) * d, N, hipMemcpyDeviceToHost, h->stream));
@@ -500,15 +627,16 @@ int pte_get_state(const pte_engine *hc, double *state, int64_t *chain, uint64_t 
 int pte_set_state(pte_engine *h, const double *state, const int64_t *chain, const uint64_t *rng) {
     if (!h) return 1;
     HIP_OK(h, hipSetDevice(h->cfg.device));
-    const int64_t N = h->N, d = h->d;
+    const int64_t N = h->K, d = h->d;
     if (state && d > 0)
         HIP_OK(h, hipMemcpy2DAsync(h->dev.x, sizeof(double) * h->dev.ld, state, sizeof(double) * d,
                                    sizeof(double) * d, N, hipMemcpyHostToDevice, h->stream));
     std::vector<int32_t> ch(N), inv(N, -1);
     if (chain) {
         for (int64_t i = 0; i < N; ++i) {
-            if (chain[i] < 0 || chain[i] >= N || inv[chain[i]] != -1) return fail(h, "pte_set_state: chain is not a permutation");
-            ch[i] = (int32_t)chain[i]; inv[chain[i]] = (int32_t)i;
+            const int64_t cl = chain[i] - h->c0;
+            if (cl < 0 || cl >= N || inv[cl] != -1) return fail(h, "pte_set_state: chain is not a permutation of the local chains");
+            ch[i] = (int32_t)chain[i]; inv[cl] = (int32_t)i;
         }
         HIP_OK(h, hipMemcpyAsync(h->dev.chain_of_slot, ch.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice, h->stream));
         HIP_OK(h, hipMemcpyAsync(h->dev.slot_of_chain, inv.data(), sizeof(int32_t) * N, hipMemcpyHostToDevice, h->stream));

@@ -18,7 +18,14 @@ namespace pte {
 enum { ERR_NONE = 0, ERR_NAN_RATIO = 1, ERR_SLICE_SUPPORT = 2, ERR_SLICE_INVALID_LP = 3, ERR_SLICE_MAX_ITER = 4 };
 
 struct EngineDev {
-    int64_t N, d, ld;
+    int64_t N, d, ld;          // N: GLOBAL number of chains
+    int64_t K, c0;             // this engine owns chains [c0, c0+K) and K replica slots
+    int64_t *replica_id;       // [slot] global replica index (travels with the replica across shards)
+    double *stat;              // [2K] SwapStat (log_ratio, uniform) of every local chain (two-phase swap)
+    double *nbr_stat;          // [4]  SwapStats received from the neighbour shards: low (lr,u), high (lr,u)
+    int32_t *bflag;            // [2]  boundary swap accepted: low, high
+    int32_t *slot_of_chain_alt;// [K]  ping-pong target of the two-phase swap
+    int32_t *ip_replica;       // [scan][slot] replica id of the slot at that scan
     double *x;
     uint64_t *rng;
     int32_t *chain_of_slot;
@@ -54,14 +61,15 @@ __device__ __forceinline__ void set_error(const EngineDev &e, int code, int chai
 template <int NLU>
 __global__ __launch_bounds__(64) void k_init(EngineDev e, uint64_t master_seed, double init_sd) {
     const int lane = lane_id();
-    const int64_t i = blockIdx.x;
-    if (i >= e.N) return;
+    const int64_t il = blockIdx.x;            // local slot
+    if (il >= e.K) return;
+    const int64_t i = e.c0 + il;              // global replica index == initial chain
     const uint64_t G = 0x9e3779b97f4a7c15ULL;
     SeqRng r;
     r.seed = mix64(master_seed + (uint64_t)(2 * i + 1) * G);
     r.gamma = mix_gamma(master_seed + (uint64_t)(2 * i + 2) * G);
     if (e.d > 0) {
-        double *xrow = e.x + i * e.ld;
+        double *xrow = e.x + il * e.ld;
         const int B = (int)((e.d + 63) >> 6);
         double BS = 0.0;
         for (int b = 0; b < B; ++b) {
@@ -72,11 +80,12 @@ __global__ __launch_bounds__(64) void k_init(EngineDev e, uint64_t master_seed, 
             if (lane == b) BS = s;
         }
         double S = upper_tree_root<NLU>(BS);
-        if (lane == 0) e.suff[i] = S;
+        if (lane == 0) e.suff[il] = S;
     }
     if (lane == 0) {
-        e.rng[2 * i] = r.seed; e.rng[2 * i + 1] = r.gamma;
-        e.chain_of_slot[i] = (int32_t)i; e.slot_of_chain[i] = (int32_t)i;
+        e.rng[2 * il] = r.seed; e.rng[2 * il + 1] = r.gamma;
+        e.chain_of_slot[il] = (int32_t)i; e.slot_of_chain[il] = (int32_t)il;
+        e.replica_id[il] = i;
     }
 }
 
@@ -121,9 +130,10 @@ __device__ __forceinline__ void record_online(const EngineDev &e, int slot, int 
 template <int NLU>
 __global__ __launch_bounds__(64) void k_explore_toy(EngineDev e) {
     const int lane = lane_id();
-    const int64_t c = blockIdx.x;
-    if (c >= e.N) return;
-    const int slot = e.slot_of_chain[c];
+    const int64_t cl = blockIdx.x;
+    if (cl >= e.K) return;
+    const int64_t c = e.c0 + cl;
+    const int slot = e.slot_of_chain[cl];
     iid_refresh<NLU>(e, slot, e.sd[c], lane);
     if (c == e.N - 1 && (e.record_flags & 4u)) { __threadfence_block(); record_online(e, slot, lane); }
 }
@@ -193,9 +203,10 @@ template <int NLU>
 __global__ __launch_bounds__(64) void k_explore_slice(EngineDev e, SliceParams sp) {
     constexpr int NL = 6 + NLU;
     const int lane = lane_id();
-    const int64_t c = blockIdx.x;
-    if (c >= e.N) return;
-    const int slot = e.slot_of_chain[c];
+    const int64_t cl = blockIdx.x;
+    if (cl >= e.K) return;
+    const int64_t c = e.c0 + cl;
+    const int slot = e.slot_of_chain[cl];
     if (c == 0 && e.N > 1) {
         iid_refresh<NLU>(e, slot, e.sd[0], lane);
         return;
@@ -318,8 +329,8 @@ __global__ __launch_bounds__(64) void k_explore_slice(EngineDev e, SliceParams s
     if (lane == 0) {
         e.suff[slot] = S;
         e.rng[2 * slot] = dr.final_seed();
-        e.expl_steps_sum[c] += steps_sum; e.expl_steps_n[c] += steps_n;
-        e.expl_acc_sum[c] += acc_sum;     e.expl_acc_n[c] += acc_n;
+        e.expl_steps_sum[cl] += steps_sum; e.expl_steps_n[cl] += steps_n;
+        e.expl_acc_sum[cl] += acc_sum;     e.expl_acc_n[cl] += acc_n;
     }
     if (c == e.N - 1 && (e.record_flags & 4u)) { __threadfence_block(); record_online(e, slot, lane); }
 }
@@ -365,7 +376,10 @@ __global__ __launch_bounds__(256) void k_swap(EngineDev e, int even, int64_t sca
         uint64_t seed = e.rng[2 * slot] + e.rng[2 * slot + 1];    // one rand(replica.rng) per replica
         e.rng[2 * slot] = seed;
         u = u52_to_unit(mix64(seed));
-        if (e.record_flags & 2u) e.index_process[scan_idx * N + slot] = (int32_t)c;
+        if (e.record_flags & 2u) {
+            e.index_process[scan_idx * N + slot] = (int32_t)c;
+            e.ip_replica[scan_idx * N + slot] = (int32_t)e.replica_id[slot];
+        }
         if (e.record_flags & 1u) {     // RoundTripRecorder.jl:43-54
             const bool is_ref = (c == 0 && N > 1), is_tgt = (c == N - 1);
             int64_t st = e.rt_state[slot];
@@ -394,6 +408,112 @@ __global__ __launch_bounds__(256) void k_swap(EngineDev e, int even, int64_t sca
             }
         }
         if (do_swap) { e.chain_of_slot[slot] = (int32_t)pc; e.slot_of_chain[pc] = slot; }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Two-phase swap for chain-sharded engines (rank g owns chains [c0, c0+K)): the pair (c0-1, c0) /
+// (c0+K-1, c0+K) has its two replicas on different GPUs, so the SwapStats of the boundary chains
+// are exchanged between the phases (16 B each way), and -- iff the swap is accepted -- the two
+// replicas' payloads {state, sum x^2, rng, replica id, round-trip state} trade places.
+// Same per-replica arithmetic and the same single rand() per replica as k_swap.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t deo_partner(int64_t N, int even, int64_t c) {
+    const bool chain_even = ((c + 1) % 2 == 0);
+    int64_t proposed = (c + 1) + ((chain_even == (even != 0)) ? 1 : -1);
+    return (proposed == 0) ? 0 : (proposed == N + 1 ? N - 1 : proposed - 1);
+}
+
+__global__ __launch_bounds__(256) void k_swap_stats(EngineDev e, int even, int64_t scan_idx) {
+    const int64_t cl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cl >= e.K) return;
+    const int64_t N = e.N, c = e.c0 + cl;
+    const int64_t pc = deo_partner(N, even, c);
+    const int slot = e.slot_of_chain[cl];
+    double lr = 0.0;
+    if (e.target != 1) {
+        const double S = e.suff[slot];
+        lr = e.nhp[pc] * S - e.nhp[c] * S;
+        if (isnan(lr)) set_error(e, ERR_NAN_RATIO, (int)c, -1);
+    }
+    uint64_t seed = e.rng[2 * slot] + e.rng[2 * slot + 1];
+    e.rng[2 * slot] = seed;
+    e.stat[2 * cl] = lr;
+    e.stat[2 * cl + 1] = u52_to_unit(mix64(seed));
+    if (e.record_flags & 2u) {
+        e.index_process[scan_idx * e.K + slot] = (int32_t)c;
+        e.ip_replica[scan_idx * e.K + slot] = (int32_t)e.replica_id[slot];
+    }
+    if (e.record_flags & 1u) {
+        const bool is_ref = (c == 0 && N > 1), is_tgt = (c == N - 1);
+        int64_t st = e.rt_state[slot];
+        if (st == 0 && is_ref) e.rt_state[slot] = 1;
+        else if (st == 1 && is_tgt) { e.rt_state[slot] = 2; e.rt_restarts[slot] += 1; }
+        else if (st == 2 && is_ref) { e.rt_state[slot] = 1; e.rt_trips[slot] += 1; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_swap_decide(EngineDev e, int even) {
+    const int64_t cl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cl >= e.K) return;
+    const int64_t N = e.N, c = e.c0 + cl;
+    const int64_t pc = deo_partner(N, even, c);
+    const int slot = e.slot_of_chain[cl];
+    int64_t new_cl = cl;
+    if (pc != c) {
+        const bool local = (pc >= e.c0 && pc < e.c0 + e.K);
+        const int side = pc < c ? 0 : 1;
+        const double lr = e.stat[2 * cl], u = e.stat[2 * cl + 1];
+        const double lr_p = local ? e.stat[2 * (pc - e.c0)] : e.nbr_stat[2 * side];
+        const double u_p = local ? e.stat[2 * (pc - e.c0) + 1] : e.nbr_stat[2 * side + 1];
+        const bool lower = c < pc;
+        const double uu = lower ? u : u_p;
+        bool do_swap;
+        if (e.target == 1) {
+            do_swap = uu < e.test_swapper_pr;
+        } else {
+            const double ex = exp(lr + lr_p);
+            const double alpha = ex < 1.0 ? ex : 1.0;
+            do_swap = uu < alpha;
+            if (lower) {
+                e.swap_sum[cl] += alpha; e.swap_n[cl] += 1;
+                e.lsr_up[cl] = dev_logaddexp(e.lsr_up[cl], lr);
+                e.lsr_dn[cl] = dev_logaddexp(e.lsr_dn[cl], lr_p);
+                e.lsr_n[cl] += 1;
+            }
+        }
+        if (do_swap) {
+            if (local) { e.chain_of_slot[slot] = (int32_t)pc; new_cl = pc - e.c0; }
+            else e.bflag[side] = 1;        // the slot keeps its chain; its contents are traded
+        }
+    }
+    e.slot_of_chain_alt[new_cl] = slot;
+}
+
+// payload layout (8-byte words): [0..d) state, d: sum x^2, d+1,d+2: rng, d+3: replica id, d+4: round-trip state
+__global__ __launch_bounds__(256) void k_boundary_export(EngineDev e, int side, double *buf) {
+    const int slot = e.slot_of_chain[side == 0 ? 0 : e.K - 1];
+    const double *xrow = e.x + (int64_t)slot * e.ld;
+    for (int64_t i = threadIdx.x; i < e.d; i += blockDim.x) buf[i] = xrow[i];
+    if (threadIdx.x == 0) {
+        buf[e.d] = e.suff[slot];
+        unsigned long long *w = reinterpret_cast<unsigned long long *>(buf + e.d + 1);
+        w[0] = e.rng[2 * slot]; w[1] = e.rng[2 * slot + 1];
+        w[2] = (unsigned long long)e.replica_id[slot];
+        w[3] = (unsigned long long)e.rt_state[slot];
+    }
+}
+__global__ __launch_bounds__(256) void k_boundary_import(EngineDev e, int side, const double *buf) {
+    const int slot = e.slot_of_chain[side == 0 ? 0 : e.K - 1];
+    double *xrow = e.x + (int64_t)slot * e.ld;
+    for (int64_t i = threadIdx.x; i < e.d; i += blockDim.x) xrow[i] = buf[i];
+    if (threadIdx.x == 0) {
+        e.suff[slot] = buf[e.d];
+        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(buf + e.d + 1);
+        e.rng[2 * slot] = w[0]; e.rng[2 * slot + 1] = w[1];
+        e.replica_id[slot] = (int64_t)w[2];
+        e.rt_state[slot] = (int64_t)w[3];
     }
 }
 

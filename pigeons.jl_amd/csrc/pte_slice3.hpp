@@ -28,9 +28,10 @@ __global__ __launch_bounds__(64) void k_explore_slice3(EngineDev e, SliceParams 
     const int lane = lane_id();
     for (int i = lane; i < 256; i += 64) { s_we[i] = ZIG_WE[i]; s_ke[i] = ZIG_KE[i]; }
     __syncthreads();
-    const int64_t c = blockIdx.x;
-    if (c >= e.N) return;
-    const int slot = e.slot_of_chain[c];
+    const int64_t cl = blockIdx.x;
+    if (cl >= e.K) return;
+    const int64_t c = e.c0 + cl;
+    const int slot = e.slot_of_chain[cl];
     if (c == 0 && e.N > 1) {
         iid_refresh<NLU>(e, slot, e.sd[0], lane);
         return;
@@ -197,8 +198,8 @@ __global__ __launch_bounds__(64) void k_explore_slice3(EngineDev e, SliceParams 
     if (lane == 0) {
         e.suff[slot] = S;
         e.rng[2 * slot] = dr.final_seed();
-        e.expl_steps_sum[c] += (double)steps_sum; e.expl_steps_n[c] += steps_n;
-        e.expl_acc_sum[c] += (double)acc_sum;     e.expl_acc_n[c] += acc_n;
+        e.expl_steps_sum[cl] += (double)steps_sum; e.expl_steps_n[cl] += steps_n;
+        e.expl_acc_sum[cl] += (double)acc_sum;     e.expl_acc_n[cl] += acc_n;
     }
     if (c == e.N - 1 && (e.record_flags & 4u)) { __threadfence_block(); record_online(e, slot, lane); }
 }

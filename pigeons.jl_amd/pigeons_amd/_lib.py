@@ -47,6 +47,8 @@ EXPORTS = [
     "pte_get_index_process", "pte_get_explorer_stats", "pte_get_automala_stats",
     "pte_get_online", "pte_get_state", "pte_set_state",
     "pte_timing_reset", "pte_timing_get", "pte_test_rng_fill", "pte_test_sqr_norm",
+    "pte_shard_info", "pte_swap_begin", "pte_swap_finish", "pte_boundary_payload_bytes",
+    "pte_boundary_export", "pte_boundary_import", "pte_get_index_process_shard", "pte_get_replica_ids",
 ]
 
 _lib = None
@@ -89,8 +91,18 @@ def load():
     L.pte_timing_get.argtypes = [vp, C.c_int, dp, ip]
     L.pte_test_rng_fill.argtypes = [C.c_int32, up, C.c_int32, C.c_int64, dp]
     L.pte_test_sqr_norm.argtypes = [C.c_int32, dp, C.c_int64, C.c_int64, dp]
+    i32p = C.POINTER(C.c_int32)
+    L.pte_shard_info.argtypes = [vp, ip, ip, ip]
+    L.pte_swap_begin.argtypes = [vp, C.c_int64, dp, i32p]
+    L.pte_swap_finish.argtypes = [vp, C.c_int64, dp, i32p]
+    L.pte_boundary_payload_bytes.argtypes = [vp]
+    L.pte_boundary_export.argtypes = [vp, C.c_int, C.c_void_p, C.c_int]
+    L.pte_boundary_import.argtypes = [vp, C.c_int, C.c_void_p, C.c_int]
+    L.pte_get_index_process_shard.argtypes = [vp, ip, ip, ip]
+    L.pte_get_replica_ids.argtypes = [vp, ip]
+    L.pte_boundary_payload_bytes.restype = C.c_int64
     for name in EXPORTS:
-        if name != "pte_last_error":
+        if name not in ("pte_last_error", "pte_boundary_payload_bytes"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -44,6 +44,9 @@ class Engine:
         self.h = h
         self.N = int(cfg.n_chains)
         self.d = 0 if cfg.target == _lib.TARGET_TEST_SWAPPER else int(cfg.dim)
+        a = np.zeros(3, dtype=np.int64)
+        self.L.pte_shard_info(h, _ip(a[0:1]), _ip(a[1:2]), _ip(a[2:3]))
+        self.c0, self.K, self.n_pairs = int(a[0]), int(a[1]), int(a[2])
 
     def close(self):
         if getattr(self, "h", None):
@@ -92,17 +95,17 @@ class Engine:
 
     # --- reduced recorders
     def swap_acceptance(self):
-        k = max(self.N - 1, 1)
+        k = max(self.n_pairs, 1)
         m = np.zeros(k); n = np.zeros(k, dtype=np.int64)
         self._chk(self.L.pte_get_swap_acceptance(self.h, _dp(m), _ip(n)))
-        return m[:self.N - 1], n[:self.N - 1]
+        return m[:self.n_pairs], n[:self.n_pairs]
 
     def log_sum_ratio(self):
-        k = max(self.N - 1, 1)
+        k = max(self.n_pairs, 1)
         up = np.zeros(k); dn = np.zeros(k)
         un = np.zeros(k, dtype=np.int64); dnn = np.zeros(k, dtype=np.int64)
         self._chk(self.L.pte_get_log_sum_ratio(self.h, _dp(up), _ip(un), _dp(dn), _ip(dnn)))
-        return up[:self.N - 1], un[:self.N - 1], dn[:self.N - 1], dnn[:self.N - 1]
+        return up[:self.n_pairs], un[:self.n_pairs], dn[:self.n_pairs], dnn[:self.n_pairs]
 
     def round_trip(self):
         a = np.zeros(1, dtype=np.int64); b = np.zeros(1, dtype=np.int64)
@@ -117,15 +120,50 @@ class Engine:
             self._chk(self.L.pte_get_index_process(self.h, _ip(out), _ip(n)))
         return out
 
+    def index_process_shard(self):
+        """(replica[scan][K], chain[scan][K]) of the local slots."""
+        n = np.zeros(1, dtype=np.int64)
+        self._chk(self.L.pte_get_index_process_shard(self.h, None, None, _ip(n)))
+        rep = np.zeros((int(n[0]), self.K), dtype=np.int64); ch = np.zeros((int(n[0]), self.K), dtype=np.int64)
+        if rep.size:
+            self._chk(self.L.pte_get_index_process_shard(self.h, _ip(rep), _ip(ch), _ip(n)))
+        return rep, ch
+
+    def replica_ids(self):
+        out = np.zeros(self.K, dtype=np.int64)
+        self._chk(self.L.pte_get_replica_ids(self.h, _ip(out)))
+        return out
+
+    # --- two-phase swap of chain-sharded engines
+    def swap_begin(self, scan):
+        stats = np.zeros(4); active = np.zeros(2, dtype=np.int32)
+        self._chk(self.L.pte_swap_begin(self.h, scan, _dp(stats), active.ctypes.data_as(C.POINTER(C.c_int32))))
+        return stats, active
+
+    def swap_finish(self, scan, nbr_stats):
+        nbr = np.ascontiguousarray(nbr_stats, dtype=np.float64)
+        acc = np.zeros(2, dtype=np.int32)
+        self._chk(self.L.pte_swap_finish(self.h, scan, _dp(nbr), acc.ctypes.data_as(C.POINTER(C.c_int32))))
+        return acc
+
+    def payload_words(self):
+        return int(self.L.pte_boundary_payload_bytes(self.h)) // 8
+
+    def boundary_export(self, side, ptr, is_device):
+        self._chk(self.L.pte_boundary_export(self.h, side, C.c_void_p(ptr), 1 if is_device else 0))
+
+    def boundary_import(self, side, ptr, is_device):
+        self._chk(self.L.pte_boundary_import(self.h, side, C.c_void_p(ptr), 1 if is_device else 0))
+
     def explorer_stats(self):
-        am = np.zeros(self.N); ss = np.zeros(self.N)
-        an = np.zeros(self.N, dtype=np.int64); sn = np.zeros(self.N, dtype=np.int64)
+        am = np.zeros(self.K); ss = np.zeros(self.K)
+        an = np.zeros(self.K, dtype=np.int64); sn = np.zeros(self.K, dtype=np.int64)
         self._chk(self.L.pte_get_explorer_stats(self.h, _dp(am), _ip(an), _dp(ss), _ip(sn)))
         return am, an, ss, sn
 
     def automala_stats(self):
-        fm = np.zeros(self.N); rm = np.zeros(self.N)
-        fn = np.zeros(self.N, dtype=np.int64); rn = np.zeros(self.N, dtype=np.int64)
+        fm = np.zeros(self.K); rm = np.zeros(self.K)
+        fn = np.zeros(self.K, dtype=np.int64); rn = np.zeros(self.K, dtype=np.int64)
         self._chk(self.L.pte_get_automala_stats(self.h, _dp(fm), _ip(fn), _dp(rm), _ip(rn)))
         return fm, fn, rm, rn
 
@@ -136,9 +174,9 @@ class Engine:
 
     # --- replica fields
     def states(self):
-        x = np.zeros((self.N, max(self.d, 1)))
-        chain = np.zeros(self.N, dtype=np.int64)
-        rng = np.zeros((self.N, 2), dtype=np.uint64)
+        x = np.zeros((self.K, max(self.d, 1)))
+        chain = np.zeros(self.K, dtype=np.int64)
+        rng = np.zeros((self.K, 2), dtype=np.uint64)
         self._chk(self.L.pte_get_state(self.h, _dp(x) if self.d > 0 else None, _ip(chain), _up(rng)))
         return x[:, :self.d], chain, rng
 

@@ -165,9 +165,14 @@ class Shared:
 
 
 class PT:
-    """src/pt/PT.jl:6-51.  `replicas` is the device engine."""
+    """src/pt/PT.jl:6-51.  `replicas` is the device engine.
 
-    def __init__(self, inputs: Inputs):
+    Sharding (not in the reference's PT; replaces its MPI `EntangledReplicas`):
+      n_shards=G           G chain-shards driven from this process (LoopbackShards; single-GPU tests)
+      rank=r, world=G      this process owns shard r of G (DistShard over torch.distributed)
+    """
+
+    def __init__(self, inputs: Inputs, n_shards=1, rank=0, world=1, dist_device=None, engine_factory=None):
         self.inputs = inputs
         target = inputs.target
         explorer = inputs.explorer if inputs.explorer is not None else default_explorer(target)
@@ -202,7 +207,18 @@ class PT:
                       slice_n_passes=explorer.n_passes, slice_max_iter=explorer.max_iter)
         else:
             raise NotImplementedError("explorer %r is not available on the device" % (explorer,))
-        self.replicas = Engine(**kw)
+        make = engine_factory or Engine
+        self.shards = None
+        if n_shards > 1:
+            from .sharded import LoopbackShards
+            self.shards = LoopbackShards([make(rank=g, world_size=n_shards, **kw) for g in range(n_shards)])
+            self.replicas = self.shards.engines[0]
+        elif world > 1:
+            from .sharded import DistShard
+            self.replicas = make(rank=rank, world_size=world, **kw)
+            self.shards = DistShard(self.replicas, rank, world, device=dist_device)
+        else:
+            self.replicas = make(**kw)
 
 
 def next_round(pt):
@@ -217,7 +233,7 @@ def next_round(pt):
 def run_one_round(pt):
     """src/pt/pigeons.jl:46-55: the scan loop runs fused on the device."""
     it = pt.shared.iterators
-    eng = pt.replicas
+    eng = pt.shards if pt.shards is not None else pt.replicas
     n = n_scans_in_round(it)
     t0 = time.perf_counter()
     eng.run_scans(1, n)                  # explore!; communicate! for scan = 1..2^round (synchronous)
@@ -228,6 +244,10 @@ def run_one_round(pt):
 
 def reduce_recorders(pt, elapsed=None):
     """src/recorders/recorders.jl:88-120"""
+    if pt.shards is not None:
+        r = pt.shards.reduce()
+        r.timing_extrema = {"round": elapsed}
+        return r
     eng = pt.replicas
     eng.reduce()
     am, an, ss, sn = eng.explorer_stats()
@@ -256,7 +276,7 @@ def adapt(pt, reduced):
     new_sched = T.Schedule(T.optimal_schedule(rej, old, len(old)))
     barriers = T.CommunicationBarriers(rej, old)
     pt.shared.tempering = NonReversiblePT(temp.path, new_sched, barriers)
-    pt.replicas.set_schedule(new_sched.grids)       # discretize(path, schedule) on the device
+    (pt.shards if pt.shards is not None else pt.replicas).set_schedule(new_sched.grids)   # discretize on the device
     return pt
 
 

@@ -252,3 +252,45 @@ def test_full_size_properties_metric_config(P):
     prec = 1.0 + 9.0 * pt.shared.tempering.schedule.grids
     v = np.var(x, axis=1)[np.argsort(chain)]
     assert np.all(v < 2.0 / prec * 1.5) and np.all(v > 0.5 / prec / 1.5)
+
+
+# ---------------------------------------------------------------------------------------------
+# chain sharding: G shard engines on ONE GPU, boundary bytes moved by the host.
+# The output must be identical to the single-engine run for any G (parallelism invariance).
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,d,G,explorer,rounds", [
+    (8, 40, 2, "slice", 5),
+    (12, 100, 4, "slice", 4),
+    (12, 7, 3, "toy", 6),       # K = 4
+    (9, 5, 3, "toy", 6),        # K = 3 (odd): boundary pairs active on both graph parities
+    (16, 130, 8, "slice", 4),   # K = 2
+    (6, 3, 6, "toy", 5),        # K = 1: every pair is a boundary pair
+])
+def test_sharded_engines_equal_single_engine(P, N, d, G, explorer, rounds):
+    exp = {"toy": P.ToyExplorer, "slice": P.SliceSampler}[explorer]
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.online]
+    mk = lambda: P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=exp(), record=rec, show_report=False)
+    one = P.PT(mk())
+    many = P.PT(mk(), n_shards=G)
+    for _ in range(rounds):
+        assert P.next_round(one) and P.next_round(many)
+        ra = P.run_one_round(one); P.adapt(one, ra)
+        rb = P.run_one_round(many); P.adapt(many, rb)
+        assert np.array_equal(ra.index_process, rb.index_process)
+        assert ra.round_trip == rb.round_trip
+        for a, b in zip(ra.swap_acceptance_pr + ra.log_sum_ratio + ra.explorer_acceptance_pr + ra.explorer_n_steps,
+                        rb.swap_acceptance_pr + rb.log_sum_ratio + rb.explorer_acceptance_pr + rb.explorer_n_steps):
+            assert np.array_equal(a, b)                 # same arithmetic in the same order: bit-identical
+        assert np.array_equal(one.shared.tempering.schedule.grids, many.shared.tempering.schedule.grids)
+        assert np.array_equal(ra.online[0], rb.online[0]) and np.array_equal(ra.online[1], rb.online[1])
+    xa, ca, ga = one.replicas.states()
+    xb, cb, gb = many.shards.states()
+    assert np.array_equal(xa, xb) and np.array_equal(ca, cb) and np.array_equal(ga, gb)
+    assert many.shards.n_boundary_swaps > 0           # the exchange path was exercised
+
+
+def test_sharded_test_swapper_round_trips(P):
+    pt = P.PT(P.Inputs(target=P.TestSwapper(1.0), n_chains=4, n_rounds=5, record=[P.round_trip, P.index_process],
+                       show_report=False), n_shards=2)
+    P.pigeons(pt)
+    assert P.n_round_trips(pt) == 13
