@@ -64,20 +64,31 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        backend = os.environ.get("PTE_BENCH_BACKEND", "nccl")          # nccl == RCCL on ROCm
+        if os.environ.get("PTE_BENCH_SINGLE_DEVICE") == "1":           # smoke-testing N ranks on a 1-GPU box (gloo only)
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import numpy as np
     import pigeons_amd as P
 
     d, K, W = args.dim, args.steps, args.warmup
-    n_chains = args.chains
+    n_chains = args.chains                      # chains per GPU; the ladder has n_chains * world chains
     explorer = P.SliceSampler() if args.explorer == "slice" else P.ToyExplorer()
-    # The path shards by chain with no data-path collective inside a shard's explore step; until the
-    # xGMI boundary exchange lands each rank runs an independent ladder of `n_chains` chains (replicas only).
-    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=n_chains, n_rounds=30, explorer=explorer,
-                       seed=1 + rank, record=[P.round_trip, P.log_sum_ratio], show_report=False,
-                       device=local_rank))
+    # The path shards by chain: rank g owns chains [g*n_chains, (g+1)*n_chains); only the
+    # boundary pair of neighbouring ranks is exchanged (RCCL send/recv), no data-path collective.
+    inputs = P.Inputs(target=P.toy_mvn_target(d), n_chains=n_chains * world, n_rounds=30, explorer=explorer, seed=1,
+                      record=[P.round_trip, P.log_sum_ratio], show_report=False, device=local_rank)
+    if world > 1:
+        pt = P.PT(inputs, rank=rank, world=world, dist_device=torch.device("cuda", local_rank))
+        runner = pt.shards
+    else:
+        pt = P.PT(inputs)
+        runner = pt.replicas
     eng = pt.replicas
 
     def sync():
@@ -85,18 +96,15 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # warmup: W scans, then one reduce + schedule adaptation (as at a round boundary)
-    eng.run_scans(1, W)
-    red = P.reduce_recorders(pt) if hasattr(P, "reduce_recorders") else None
     from pigeons_amd.pt import reduce_recorders, adapt
-    if red is None:
-        red = reduce_recorders(pt)
-    adapt(pt, red)
+    # warmup: W scans, then one reduce + schedule adaptation (as at a round boundary)
+    runner.run_scans(1, W)
+    adapt(pt, reduce_recorders(pt))
 
     eng.timing_reset(True)
     sync()
     t0 = time.perf_counter()
-    eng.run_scans(1, K)                 # exactly K explore+swap scans, synchronous at return
+    runner.run_scans(1, K)              # exactly K explore+swap scans, synchronous at return
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -127,10 +135,11 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "toy_mvn_target(%d), n_chains=%d per GPU x %d GPU, %s, seed=1, DEO swaps every scan"
                                % (d, n_chains, world, "SliceSampler(w=10,p=20,n_passes=3)" if args.explorer == "slice" else "ToyExplorer"),
-                   "sharding": "replicas only (independent ladder per rank)" if world > 1 else "single GPU"},
+                   "sharding": ("chains sharded over %d GPUs, boundary replicas exchanged by RCCL send/recv" % world) if world > 1 else "single GPU",
+                   "boundary_swaps_rank0": getattr(runner, "n_boundary_swaps", 0)},
         "round_trip_rate": trips / K, "n_round_trips": trips, "n_tempered_restarts": restarts,
-        "lp_evals_per_replica_step": float(np.sum(ss_sum) / max(K * (n_chains - 1), 1)) + 2.0 * 3 * d if args.explorer == "slice" else 0.0,
-        "roofline": {"bound": "hbm", "kernel": "k_explore_slice" if args.explorer == "slice" else "k_explore_toy",
+        "lp_evals_per_replica_step": float(np.sum(ss_sum) / max(K * (total_chains - 1), 1)) + 2.0 * 3 * d if args.explorer == "slice" else 0.0,
+        "roofline": {"bound": "hbm", "kernel": "k_explore_slice2" if args.explorer == "slice" else "k_explore_toy",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "avg_launch_ms": ex_avg_ms, "launches": ex_n,
                      "algorithmic_bytes_per_launch": alg_bytes,

@@ -308,6 +308,7 @@ static void rec_merge(po_recorders *a, const po_recorders *b, int64_t N, int64_t
 /* ========================================================================== */
 /* PT structures                                                              */
 /* ========================================================================== */
+typedef struct { double log_ratio, uniform; } swap_stat_t_fwd;
 /* src/replicas/Replica.jl:5-30 */
 typedef struct {
     double  *state;
@@ -322,7 +323,10 @@ typedef struct {
 struct po_pt {
     po_config cfg;
     int64_t N, d;
-    po_replica *replicas;        /* by replica_index                              */
+    int64_t K, c0;               /* shard: local chains [c0, c0+K); K == N, c0 == 0 when unsharded */
+    swap_stat_t_fwd *shard_stat; /* [K] SwapStats of the local chains between the two swap phases   */
+    int64_t *shard_ip_replica, *shard_ip_chain; int64_t shard_ip_len, shard_ip_cap;  /* [scan][K]   */
+    po_replica *replicas;        /* by replica_index (by local slot for shards)   */
     int64_t *replica_of_chain;   /* the sorted Vector{Replica} view (swap.jl:7)   */
     double  *betas;              /* Schedule.grids                                */
     int64_t round, scan;         /* Iterators (src/pt/Iterators.jl:9-25)          */
@@ -355,6 +359,7 @@ void po_default_config(po_config *c) {
     c->am_preconditioner = 2; c->am_p0 = 1.0 / 3.0; c->am_p1 = 1.0 / 3.0;
     c->record_round_trip = 1; c->record_index_process = 1; c->record_online = 0;
     c->n_threads = 1;
+    c->rank = 0; c->world_size = 1;
 }
 
 /* ---- the path: log potentials along the ladder ---------------------------- */
@@ -614,6 +619,10 @@ po_pt *po_create(const po_config *cfg) {
     pt->cfg = *cfg;
     const int64_t N = pt->N = cfg->n_chains;
     const int64_t d = pt->d = (cfg->target == PO_TARGET_TEST_SWAPPER) ? 0 : cfg->dim;
+    const int world = cfg->world_size > 0 ? cfg->world_size : 1;
+    const int64_t K = pt->K = N / world;
+    pt->c0 = K * cfg->rank;
+    pt->shard_stat = (swap_stat_t_fwd *)calloc((size_t)K, sizeof(swap_stat_t_fwd));
     pt->replicas = (po_replica *)calloc((size_t)N, sizeof(po_replica));
     pt->replica_of_chain = (int64_t *)calloc((size_t)N, sizeof(int64_t));
     pt->betas = (double *)calloc((size_t)N, sizeof(double));
@@ -623,10 +632,11 @@ po_pt *po_create(const po_config *cfg) {
     pt->step_size = cfg->am_step_size;
     /* _create_locals, src/replicas/replicas.jl:87-98; split_slice, src/utils/misc.jl:21-31 */
     po_rng master = po_rng_new(cfg->seed);
-    for (int64_t i = 0; i < N; i++) {
+    for (int64_t g = 0; g < pt->c0; g++) (void)po_rng_split(&master);   /* split_slice burns the streams left of the slice */
+    for (int64_t i = 0; i < K; i++) {
         po_replica *r = &pt->replicas[i];
         r->rng = po_rng_split(&master);
-        r->chain = i; r->replica_index = i;
+        r->chain = pt->c0 + i; r->replica_index = pt->c0 + i;
         pt->replica_of_chain[i] = i;
         r->state = (double *)calloc((size_t)(d > 0 ? d : 1), sizeof(double));
         r->buf = (double *)calloc((size_t)(8 * (d > 0 ? d : 1)), sizeof(double));
@@ -647,7 +657,8 @@ po_pt *po_create(const po_config *cfg) {
 }
 void po_destroy(po_pt *pt) {
     if (!pt) return;
-    for (int64_t i = 0; i < pt->N; i++) { free(pt->replicas[i].state); free(pt->replicas[i].buf); rec_free(&pt->replicas[i].rec); }
+    for (int64_t i = 0; i < pt->K; i++) { free(pt->replicas[i].state); free(pt->replicas[i].buf); rec_free(&pt->replicas[i].rec); }
+    free(pt->shard_stat); free(pt->shard_ip_replica); free(pt->shard_ip_chain);
     rec_free(&pt->reduced);
     free(pt->replicas); free(pt->replica_of_chain); free(pt->betas); free(pt->target_std);
     free(pt->reduced_ip); free(pt->cb_x);
@@ -774,7 +785,7 @@ int po_run_round(po_pt *pt) {
 /* getters                                                                    */
 /* ========================================================================== */
 void po_get_states(const po_pt *pt, double *x, int64_t *chain, uint64_t *rng) {
-    for (int64_t r = 0; r < pt->N; r++) {
+    for (int64_t r = 0; r < pt->K; r++) {
         if (x && pt->d > 0) memcpy(x + r * pt->d, pt->replicas[r].state, sizeof(double) * (size_t)pt->d);
         if (chain) chain[r] = pt->replicas[r].chain;
         if (rng) { rng[2 * r] = pt->replicas[r].rng.seed; rng[2 * r + 1] = pt->replicas[r].rng.gamma; }
@@ -821,3 +832,108 @@ double po_cumulative_barrier(const po_pt *pt, double beta) {
     return po_fc_eval(pt->cb_x, pt->cb_y, pt->cb_m, pt->cb_c, pt->cb_d, pt->N, beta);
 }
 double po_get_step_size(const po_pt *pt) { return pt->step_size; }
+
+/* ========================================================================== */
+/* chain-sharded operation: test-only restatement of the multi-GPU protocol    */
+/* (DESIGN.md 9).  Recorders stay with the slot (rank-local accumulators, as in */
+/* the HIP engine); state, rng, replica index and round-trip state travel.      */
+/* ========================================================================== */
+static void shard_active(const po_pt *pt, int even, int32_t *active) {
+    active[0] = (pt->c0 > 0 && partner_chain(pt->N, even, pt->c0) == pt->c0 - 1) ? 1 : 0;
+    active[1] = (pt->c0 + pt->K < pt->N && partner_chain(pt->N, even, pt->c0 + pt->K - 1) == pt->c0 + pt->K) ? 1 : 0;
+}
+void po_shard_info(const po_pt *pt, int64_t *c0, int64_t *K, int64_t *n_pairs) {
+    *c0 = pt->c0; *K = pt->K; *n_pairs = (pt->c0 + pt->K < pt->N) ? pt->K : pt->K - 1;
+}
+int po_shard_explore(po_pt *pt, int64_t scan) {
+    pt->scan = scan;
+    for (int64_t cl = 0; cl < pt->K; cl++)
+        if (explore_replica(pt, &pt->replicas[pt->replica_of_chain[cl]])) return 1;
+    return 0;
+}
+int po_shard_swap_begin(po_pt *pt, int64_t scan, double *stats_out, int32_t *active_out) {
+    const int64_t N = pt->N, K = pt->K;
+    int even = (scan % 2 == 0);
+    pt->scan = scan;
+    if (pt->shard_ip_len + K > pt->shard_ip_cap) {
+        pt->shard_ip_cap = pt->shard_ip_cap ? 2 * pt->shard_ip_cap : 64 * K;
+        pt->shard_ip_replica = (int64_t *)realloc(pt->shard_ip_replica, sizeof(int64_t) * (size_t)pt->shard_ip_cap);
+        pt->shard_ip_chain = (int64_t *)realloc(pt->shard_ip_chain, sizeof(int64_t) * (size_t)pt->shard_ip_cap);
+    }
+    for (int64_t cl = 0; cl < K; cl++) {
+        int64_t slot = pt->replica_of_chain[cl];
+        po_replica *r = &pt->replicas[slot];
+        swap_stat_t st;
+        if (swap_stat(pt, r, partner_chain(N, even, pt->c0 + cl), &st)) return 1;
+        pt->shard_stat[cl].log_ratio = st.log_ratio; pt->shard_stat[cl].uniform = st.uniform;
+        pt->shard_ip_replica[pt->shard_ip_len + slot] = r->replica_index;
+        pt->shard_ip_chain[pt->shard_ip_len + slot] = r->chain;
+        if (pt->cfg.record_round_trip) round_trip_record(&r->rec.rt, is_reference(N, r->chain), is_target(N, r->chain));
+    }
+    pt->shard_ip_len += K;
+    stats_out[0] = pt->shard_stat[0].log_ratio; stats_out[1] = pt->shard_stat[0].uniform;
+    stats_out[2] = pt->shard_stat[K - 1].log_ratio; stats_out[3] = pt->shard_stat[K - 1].uniform;
+    shard_active(pt, even, active_out);
+    return 0;
+}
+int po_shard_swap_finish(po_pt *pt, int64_t scan, const double *nbr, int32_t *accepted) {
+    const int64_t N = pt->N, K = pt->K;
+    int even = (scan % 2 == 0);
+    accepted[0] = accepted[1] = 0;
+    for (int64_t cl = 0; cl < K; cl++) {
+        int64_t c = pt->c0 + cl, pc = partner_chain(N, even, c);
+        if (pc == c) continue;
+        po_replica *r = &pt->replicas[pt->replica_of_chain[cl]];
+        int local = (pc >= pt->c0 && pc < pt->c0 + K);
+        int side = pc < c ? 0 : 1;
+        swap_stat_t mine = { pt->shard_stat[cl].log_ratio, pt->shard_stat[cl].uniform }, theirs;
+        if (local) { theirs.log_ratio = pt->shard_stat[pc - pt->c0].log_ratio; theirs.uniform = pt->shard_stat[pc - pt->c0].uniform; }
+        else { theirs.log_ratio = nbr[2 * side]; theirs.uniform = nbr[2 * side + 1]; }
+        int do_swap = swap_decision(pt, c, &mine, pc, &theirs);
+        if (c < pc && pt->cfg.target != PO_TARGET_TEST_SWAPPER) {
+            double acc = swap_acceptance_probability(&mine, &theirs);
+            mean_fit(&r->rec.swap_pr[c], acc);
+            logsum_fit(&r->rec.lsr_up[c], mine.log_ratio);
+            logsum_fit(&r->rec.lsr_dn[c], theirs.log_ratio);
+        }
+        if (do_swap) { if (local) r->chain = pc; else accepted[side] = 1; }
+    }
+    for (int64_t s = 0; s < K; s++) pt->replica_of_chain[pt->replicas[s].chain - pt->c0] = s;
+    return 0;
+}
+int64_t po_shard_payload_words(const po_pt *pt) { return pt->d + 5; }
+/* payload: [0..d) state, d: (unused: the HIP engine ships sum x^2 here), d+1,d+2: rng, d+3: replica id, d+4: round-trip state */
+void po_shard_export(po_pt *pt, int side, double *buf) {
+    po_replica *r = &pt->replicas[pt->replica_of_chain[side == 0 ? 0 : pt->K - 1]];
+    memcpy(buf, r->state, sizeof(double) * (size_t)pt->d);
+    buf[pt->d] = pt->d > 0 ? po_sqr_norm(r->state, pt->d) : 0.0;
+    uint64_t w[4] = { r->rng.seed, r->rng.gamma, (uint64_t)r->replica_index, (uint64_t)r->rec.rt.state };
+    memcpy(buf + pt->d + 1, w, sizeof w);
+}
+void po_shard_import(po_pt *pt, int side, const double *buf) {
+    po_replica *r = &pt->replicas[pt->replica_of_chain[side == 0 ? 0 : pt->K - 1]];
+    memcpy(r->state, buf, sizeof(double) * (size_t)pt->d);
+    uint64_t w[4];
+    memcpy(w, buf + pt->d + 1, sizeof w);
+    r->rng.seed = w[0]; r->rng.gamma = w[1]; r->replica_index = (int64_t)w[2]; r->rec.rt.state = (int64_t)w[3];
+}
+int po_shard_reduce(po_pt *pt) {
+    const int64_t N = pt->N, d = pt->d;
+    rec_empty(&pt->reduced, N, d);
+    for (int64_t s = 0; s < pt->K; s++) rec_merge(&pt->reduced, &pt->replicas[s].rec, N, d);
+    for (int64_t s = 0; s < pt->K; s++) {
+        int64_t st = pt->replicas[s].rec.rt.state;          /* the state machine resets every round ...  */
+        rec_empty(&pt->replicas[s].rec, N, d);
+        (void)st;                                           /* ... including its state (RoundTripRecorder.jl:30-34) */
+    }
+    pt->reduced_n_scans = pt->shard_ip_len / pt->K;
+    return 0;
+}
+void po_shard_replica_ids(const po_pt *pt, int64_t *out) { for (int64_t s = 0; s < pt->K; s++) out[s] = pt->replicas[s].replica_index; }
+int64_t po_shard_index_process(const po_pt *pt, int64_t *replica, int64_t *chain) {
+    int64_t n = pt->reduced_n_scans;
+    if (replica) memcpy(replica, pt->shard_ip_replica, sizeof(int64_t) * (size_t)(n * pt->K));
+    if (chain) memcpy(chain, pt->shard_ip_chain, sizeof(int64_t) * (size_t)(n * pt->K));
+    ((po_pt *)pt)->shard_ip_len = 0;
+    return n;
+}

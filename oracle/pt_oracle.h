@@ -66,6 +66,9 @@ typedef struct po_config {
     /* recorders */
     int32_t  record_round_trip, record_index_process, record_online;
     int32_t  n_threads;          /* OpenMP threads over replicas in explore!       */
+    /* chain sharding (test-only restatement of the build's multi-GPU protocol):
+       this instance owns chains [rank*N/world, (rank+1)*N/world) and the replicas at them */
+    int32_t  rank, world_size;
 } po_config;
 
 typedef struct po_pt po_pt;
@@ -83,7 +86,19 @@ int         po_run_scans(po_pt *pt, int64_t n_scans);  /* explore!+communicate! 
 int         po_end_round(po_pt *pt);                   /* reduce_recorders!, adapt */
 int64_t     po_round(const po_pt *pt);
 
-/* State (replica order). rng: 2 words per replica (seed, gamma). */
+/* ---- chain-sharded operation (world_size >= 1): same calls as include/pte.h's two-phase swap ---- */
+int     po_shard_explore(po_pt *pt, int64_t scan);
+int     po_shard_swap_begin(po_pt *pt, int64_t scan, double *stats_out /*4*/, int32_t *active_out /*2*/);
+int     po_shard_swap_finish(po_pt *pt, int64_t scan, const double *nbr_stats /*4*/, int32_t *accepted_out /*2*/);
+int64_t po_shard_payload_words(const po_pt *pt);                 /* d + 5 */
+void    po_shard_export(po_pt *pt, int side, double *buf);
+void    po_shard_import(po_pt *pt, int side, const double *buf);
+int     po_shard_reduce(po_pt *pt);                              /* merge local recorders, reset */
+void    po_shard_info(const po_pt *pt, int64_t *c0, int64_t *K, int64_t *n_pairs);
+void    po_shard_replica_ids(const po_pt *pt, int64_t *out /*K*/);
+int64_t po_shard_index_process(const po_pt *pt, int64_t *replica, int64_t *chain);   /* [scan][K]; returns n_scans */
+
+/* State (replica order; local slot order for shards). rng: 2 words per replica (seed, gamma). */
 void po_get_states(const po_pt *pt, double *x, int64_t *chain, uint64_t *rng);
 void po_get_schedule(const po_pt *pt, double *betas);
 void po_set_schedule(po_pt *pt, const double *betas);

@@ -496,7 +496,7 @@ int pte_get_round_trip(const pte_engine *h, int64_t *restarts, int64_t *trips) {
 int pte_get_index_process(const pte_engine *h, int64_t *out, int64_t *n_scans) {
     if (!h) return 1;
     if (h->world != 1) return fail(const_cast<pte_engine *>(h), "pte_get_index_process: sharded engines use pte_get_index_process_shard");
-    const int64_t T = h->snap.n_scans, N = h->N;
+    const int64_t T = h->snap.ip_chain.empty() ? 0 : h->snap.n_scans, N = h->N;
     if (n_scans) *n_scans = T;
     if (out && !h->snap.ip_chain.empty())
         for (int64_t t = 0; t < T; ++t)
@@ -506,7 +506,7 @@ int pte_get_index_process(const pte_engine *h, int64_t *out, int64_t *n_scans) {
 }
 int pte_get_index_process_shard(const pte_engine *h, int64_t *replica, int64_t *chain, int64_t *n_scans) {
     if (!h) return 1;
-    if (n_scans) *n_scans = h->snap.n_scans;
+    if (n_scans) *n_scans = h->snap.ip_chain.empty() ? 0 : h->snap.n_scans;
     const size_t n = h->snap.ip_chain.size();
     for (size_t i = 0; i < n; ++i) {
         if (replica) replica[i] = h->snap.ip_replica[i];

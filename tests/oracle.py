@@ -29,6 +29,7 @@ class Config(C.Structure):
         ("am_p0", C.c_double), ("am_p1", C.c_double),
         ("record_round_trip", C.c_int32), ("record_index_process", C.c_int32),
         ("record_online", C.c_int32), ("n_threads", C.c_int32),
+        ("rank", C.c_int32), ("world_size", C.c_int32),
     ]
 
 
@@ -103,6 +104,23 @@ def lib():
     L.po_cumulative_barrier.argtypes = [C.c_void_p, C.c_double]
     L.po_get_step_size.restype = C.c_double
     L.po_get_step_size.argtypes = [C.c_void_p]
+    i32p = C.POINTER(C.c_int32)
+    L.po_shard_explore.restype = C.c_int
+    L.po_shard_explore.argtypes = [C.c_void_p, C.c_int64]
+    L.po_shard_swap_begin.restype = C.c_int
+    L.po_shard_swap_begin.argtypes = [C.c_void_p, C.c_int64, dp, i32p]
+    L.po_shard_swap_finish.restype = C.c_int
+    L.po_shard_swap_finish.argtypes = [C.c_void_p, C.c_int64, dp, i32p]
+    L.po_shard_payload_words.restype = C.c_int64
+    L.po_shard_payload_words.argtypes = [C.c_void_p]
+    L.po_shard_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.po_shard_import.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.po_shard_reduce.restype = C.c_int
+    L.po_shard_reduce.argtypes = [C.c_void_p]
+    L.po_shard_info.argtypes = [C.c_void_p, ip, ip, ip]
+    L.po_shard_replica_ids.argtypes = [C.c_void_p, ip]
+    L.po_shard_index_process.restype = C.c_int64
+    L.po_shard_index_process.argtypes = [C.c_void_p, ip, ip]
     _lib = L
     return L
 
@@ -256,3 +274,82 @@ class OraclePT:
 
     def step_size(self):
         return float(self.L.po_get_step_size(self.h))
+
+
+class OracleShard(OraclePT):
+    """Oracle-backed chain shard with the Engine methods the sharded drivers use (CPU tests of the
+    multi-rank protocol; pigeons_amd.sharded.LoopbackShards / DistShard)."""
+
+    def __init__(self, rank=0, world_size=1, **kw):
+        kw = dict(kw)
+        # accept the pte_config spelling used by pigeons_amd.PT
+        tp = kw.pop("target_params", None)
+        if tp is not None:
+            kw["p0"], kw["p1"] = tp[0], (tp[1] if len(tp) > 1 else 0.0)
+        flags = kw.pop("record_flags", None)
+        if flags is not None:
+            kw["record_round_trip"] = 1 if flags & 1 else 0
+            kw["record_index_process"] = 1 if flags & 2 else 0
+            kw["record_online"] = 1 if flags & 4 else 0
+        kw.pop("device", None); kw.pop("max_scans_per_round", None)
+        super().__init__(rank=rank, world_size=world_size, **kw)
+        a = np.zeros(3, dtype=np.int64)
+        self.L.po_shard_info(self.h, _ip(a[0:1]), _ip(a[1:2]), _ip(a[2:3]))
+        self.c0, self.K, self.n_pairs = int(a[0]), int(a[1]), int(a[2])
+
+    def explore(self, scan):
+        self._chk(self.L.po_shard_explore(self.h, scan))
+
+    def swap_begin(self, scan):
+        stats = np.zeros(4); active = np.zeros(2, dtype=np.int32)
+        self._chk(self.L.po_shard_swap_begin(self.h, scan, _dp(stats), active.ctypes.data_as(C.POINTER(C.c_int32))))
+        return stats, active
+
+    def swap_finish(self, scan, nbr):
+        nbr = np.ascontiguousarray(nbr, dtype=np.float64); acc = np.zeros(2, dtype=np.int32)
+        self._chk(self.L.po_shard_swap_finish(self.h, scan, _dp(nbr), acc.ctypes.data_as(C.POINTER(C.c_int32))))
+        return acc
+
+    def payload_words(self):
+        return int(self.L.po_shard_payload_words(self.h))
+
+    def boundary_export(self, side, ptr, is_device):
+        assert not is_device
+        self.L.po_shard_export(self.h, side, C.c_void_p(ptr))
+
+    def boundary_import(self, side, ptr, is_device):
+        assert not is_device
+        self.L.po_shard_import(self.h, side, C.c_void_p(ptr))
+
+    def reduce(self):
+        self._chk(self.L.po_shard_reduce(self.h))
+
+    def swap_acceptance(self):
+        m, n = self.swap_pr()
+        return m[self.c0:self.c0 + self.n_pairs], n[self.c0:self.c0 + self.n_pairs]
+
+    def log_sum_ratio(self):
+        sl = slice(self.c0, self.c0 + self.n_pairs)
+        return tuple(a[sl] for a in super().log_sum_ratio())
+
+    def explorer_stats(self):
+        sl = slice(self.c0, self.c0 + self.K)
+        return tuple(a[sl] for a in super().explorer_stats())
+
+    def index_process_shard(self):
+        n = int(self.L.po_shard_index_process(self.h, None, None)) if False else None
+        # sizes: query via a first call that does not reset (replica=None keeps the buffer)
+        rep = np.zeros((4096, self.K), dtype=np.int64); ch = np.zeros((4096, self.K), dtype=np.int64)
+        n = int(self.L.po_shard_index_process(self.h, _ip(rep), _ip(ch)))
+        return rep[:n].copy(), ch[:n].copy()
+
+    def replica_ids(self):
+        out = np.zeros(self.K, dtype=np.int64)
+        self.L.po_shard_replica_ids(self.h, _ip(out))
+        return out
+
+    def states(self):
+        x = np.zeros((self.K, max(self.d, 1))); chain = np.zeros(self.K, dtype=np.int64)
+        rng = np.zeros((self.K, 2), dtype=np.uint64)
+        self.L.po_get_states(self.h, _dp(x), _ip(chain), _up(rng))
+        return x[:, :self.d], chain, rng

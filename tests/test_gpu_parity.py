@@ -294,3 +294,48 @@ def test_sharded_test_swapper_round_trips(P):
                        show_report=False), n_shards=2)
     P.pigeons(pt)
     assert P.n_round_trips(pt) == 13
+
+
+DIST_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path[:0] = [%(root)r, %(root)r + "/pigeons.jl_amd", %(root)r + "/tests"]
+import torch, torch.distributed as dist
+import pigeons_amd as P
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks share cuda:0 (nccl refuses that)
+mk = lambda: P.Inputs(target=P.toy_mvn_target(70), n_chains=8, n_rounds=5, explorer=P.SliceSampler(), show_report=False,
+                      record=[P.round_trip, P.index_process, P.log_sum_ratio])
+pt = P.PT(mk(), rank=rank, world=world, dist_device=torch.device("cuda", 0))   # device payload buffers
+one = P.PT(mk()) if rank == 0 else None
+ok = True
+for _ in range(5):
+    P.next_round(pt); red = P.run_one_round(pt); P.adapt(pt, red)
+    if rank == 0:
+        P.next_round(one); ra = P.run_one_round(one); P.adapt(one, ra)
+        ok &= bool(np.array_equal(ra.index_process, red.index_process)) and ra.round_trip == red.round_trip
+        ok &= bool(np.array_equal(ra.swap_acceptance_pr[0], red.swap_acceptance_pr[0]))
+        ok &= bool(np.array_equal(one.shared.tempering.schedule.grids, pt.shared.tempering.schedule.grids))
+x, chain, rng = pt.shards.states()
+if rank == 0:
+    xa, ca, ga = one.replicas.states()
+    ok &= bool(np.array_equal(x, xa) and np.array_equal(chain, ca) and np.array_equal(rng, ga))
+    print(json.dumps({"ok": ok, "boundary_swaps": pt.shards.n_boundary_swaps}))
+dist.destroy_process_group()
+'''
+
+
+def test_dist_shard_two_ranks_device_payloads(P, tmp_path):
+    """DistShard (the multi-GPU driver) with device-resident payload buffers, two ranks over gloo on one GPU."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(DIST_WORKER % {"root": root})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    res = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert res["ok"] and res["boundary_swaps"] > 0, res
