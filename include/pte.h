@@ -151,7 +151,7 @@ int pte_swap_begin(pte_engine *h, int64_t scan, double *stats_out, int32_t *acti
 /* phase 2: nbr_stats[4] = SwapStats received from the lower / upper neighbour (ignored where inactive);
  * decisions, recorders, chain relabelling of local pairs; accepted_out[2] = boundary swap accepted. */
 int pte_swap_finish(pte_engine *h, int64_t scan, const double *nbr_stats, int32_t *accepted_out);
-int64_t pte_boundary_payload_bytes(const pte_engine *h);            /* 8 * (d + 5) */
+int64_t pte_boundary_payload_bytes(const pte_engine *h);            /* 8 * (d + 6) */
 int pte_boundary_export(pte_engine *h, int side, void *dst, int dst_is_device);
 int pte_boundary_import(pte_engine *h, int side, const void *src, int src_is_device);
 /* index process of the local slots: replica[scan][K], chain[scan][K] (global ids). */

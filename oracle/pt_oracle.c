@@ -371,12 +371,109 @@ static inline double mvn_precision(const po_pt *pt, double beta) {
 static inline double mvn_lp(double prec, const double *x, int64_t d) {
     return (-0.5 * prec) * po_sqr_norm(x, d);
 }
-/* log_potentials[chain](x) (src/tempering/NonReversiblePT.jl:72, src/schedules/discretize.jl:6-7) */
-static double lp_at_chain(const po_pt *pt, int64_t chain, const double *x) {
+/* tree_sum: the build's fixed association (balanced binary tree, natural order, zero padded) for
+ * any vector of terms; po_sqr_norm is tree_sum of the squares. */
+static double tree_sum(const double *t, int64_t d) {
+    if (d <= 0) return 0.0;
+    int64_t P = next_pow2(d);
+    if (P == 1) return t[0];
+    double stackbuf[1024];
+    double *a = (P / 2 <= 1024) ? stackbuf : (double *)malloc(sizeof(double) * (size_t)(P / 2));
+    for (int64_t i = 0; i < P / 2; i++) {
+        double l = (2 * i < d) ? t[2 * i] : 0.0;
+        double r = (2 * i + 1 < d) ? t[2 * i + 1] : 0.0;
+        a[i] = l + r;
+    }
+    for (int64_t len = P / 2; len > 1; len /= 2)
+        for (int64_t i = 0; i < len / 2; i++) a[i] = a[2 * i] + a[2 * i + 1];
+    double s = a[0];
+    if (a != stackbuf) free(a);
+    return s;
+}
+
+/* Neal's funnel (reference test/supporting/dimensional-analysis.jl:33-48):
+ *   z[1] ~ Normal(0, 3), z[i] ~ Normal(0, exp(z[1]/2)),  logpdf(Normal(mu,sigma), x) = -(zval^2 + log2pi)/2 - log(sigma)
+ * (Distributions.jl / StatsFuns normlogpdf).  The reference accumulates the d terms sequentially;
+ * the build sums them with the fixed tree (rounding-level difference).  If `g` != NULL the analytic
+ * gradient is written (the reference differentiates the same expression with ForwardDiff). */
+#define PO_LOG2PI 1.8378770664093453
+static double funnel_lp_grad(const double *z, int64_t d, double *g, double *terms) {
+    const double y = z[0];
+    const double zv = y / 3.0;
+    terms[0] = -(zv * zv + PO_LOG2PI) / 2.0 - log(3.0);
+    const double sigma = exp(y / 2.0);
+    const double logsigma = log(sigma);
+    for (int64_t i = 1; i < d; i++) {
+        double zi = z[i] / sigma;
+        terms[i] = -(zi * zi + PO_LOG2PI) / 2.0 - logsigma;
+    }
+    double lp = tree_sum(terms, d);
+    if (g) {
+        /* d/dz_i = -z_i / sigma^2 ;  d/dy = -y/9 + sum_i ((z_i/sigma)^2 - 1) / 2 */
+        for (int64_t i = 1; i < d; i++) { double zi = z[i] / sigma; g[i] = -(zi / sigma); terms[i] = (zi * zi - 1.0) / 2.0; }
+        terms[0] = -(y / 9.0);
+        g[0] = tree_sum(terms, d);
+    }
+    return lp;
+}
+
+/* The two end points of the path for chain evaluation.
+ * MVN: ScaledPrecisionNormalPath is its own path (no interpolation).
+ * FUNNEL: InterpolatingPath(ScaledPrecisionNormalLogPotential(p0, d), Funnel(d)) with the
+ * LinearInterpolator (src/paths/InterpolatingPath.jl:25-27). */
+static double lp_at_chain_buf(const po_pt *pt, int64_t chain, const double *x, double *scratch) {
+    const double beta = pt->betas[chain];
     switch (pt->cfg.target) {
-    case PO_TARGET_MVN: return mvn_lp(mvn_precision(pt, pt->betas[chain]), x, pt->d);
+    case PO_TARGET_MVN: return mvn_lp(mvn_precision(pt, beta), x, pt->d);
+    case PO_TARGET_FUNNEL: {
+        /* InterpolatedLogPotential(x), src/paths/InterpolatedLogPotential.jl:9-16 */
+        if (beta == 0.0) return mvn_lp(pt->cfg.p0, x, pt->d);
+        if (beta == 1.0) return funnel_lp_grad(x, pt->d, NULL, scratch);
+        double ref = mvn_lp(pt->cfg.p0, x, pt->d), tgt = funnel_lp_grad(x, pt->d, NULL, scratch);
+        return (1.0 - beta) * ref + beta * tgt;
+    }
     default: return NAN;
     }
+}
+/* log_potentials[chain](x) (src/tempering/NonReversiblePT.jl:72, src/schedules/discretize.jl:6-7) */
+static double lp_at_chain(const po_pt *pt, int64_t chain, const double *x) {
+    if (pt->cfg.target == PO_TARGET_FUNNEL) {
+        double stackbuf[1024];
+        double *t = pt->d <= 1024 ? stackbuf : (double *)malloc(sizeof(double) * (size_t)pt->d);
+        double v = lp_at_chain_buf(pt, chain, x, t);
+        if (t != stackbuf) free(t);
+        return v;
+    }
+    return lp_at_chain_buf(pt, chain, x, NULL);
+}
+/* LogDensityProblems.logdensity_and_gradient on the chain's log potential:
+ * MVN: src/paths/ScaledPrecisionNormalPath.jl:30-34; interpolated: InterpolatedAD,
+ * src/explorers/BufferedAD.jl:98-112 (no beta == 0 / 1 short-circuit there). */
+static double lp_grad_at_chain(const po_pt *pt, int64_t chain, const double *x, double *grad, double *scratch) {
+    const int64_t d = pt->d;
+    const double beta = pt->betas[chain];
+    if (pt->cfg.target == PO_TARGET_MVN) {
+        double prec = mvn_precision(pt, beta);
+        double logdens = mvn_lp(prec, x, d);
+        for (int64_t i = 0; i < d; i++) grad[i] = (-prec) * x[i];
+        return logdens;
+    }
+    double logdens = 0.0;
+    double l = mvn_lp(pt->cfg.p0, x, d);
+    logdens += l * (1.0 - beta);
+    for (int64_t i = 0; i < d; i++) grad[i] = ((-pt->cfg.p0) * x[i]) * (1.0 - beta);
+    double *g2 = scratch, *terms = scratch + d;
+    l = funnel_lp_grad(x, d, g2, terms);
+    logdens += l * beta;
+    for (int64_t i = 0; i < d; i++) grad[i] = grad[i] + g2[i] * beta;
+    return logdens;
+}
+/* LogDensityProblems.logdensity(::InterpolatedAD) BufferedAD.jl:89-94 == (1-beta)*l1 + beta*l2, no short-circuit */
+static double lp_ad_at_chain(const po_pt *pt, int64_t chain, const double *x, double *scratch) {
+    if (pt->cfg.target == PO_TARGET_MVN) return mvn_lp(mvn_precision(pt, pt->betas[chain]), x, pt->d);
+    const double beta = pt->betas[chain];
+    double l1 = mvn_lp(pt->cfg.p0, x, pt->d), l2 = funnel_lp_grad(x, pt->d, NULL, scratch);
+    return (1.0 - beta) * l1 + beta * l2;
 }
 
 /* ---- DEO swap graph -------------------------------------------------------- */
@@ -404,7 +501,8 @@ static void fail(po_pt *pt, const char *msg) {
 /* rand!(rng, x, lp) / sample_iid! / ToyExplorer.step!
  * (src/targets/toy_mvn_target.jl:15-21, src/explorers/ToyExplorer.jl:7-12) */
 static void mvn_sample_iid(po_pt *pt, po_replica *r) {
-    double prec = mvn_precision(pt, pt->betas[r->chain]);
+    /* funnel path: sample_iid!(::InterpolatedLogPotential) -> the reference end point (src/targets/target.jl:93-98) */
+    double prec = pt->cfg.target == PO_TARGET_FUNNEL ? pt->cfg.p0 : mvn_precision(pt, pt->betas[r->chain]);
     double sd = sqrt(prec);
     for (int64_t i = 0; i < pt->d; i++) r->state[i] = po_randn(&r->rng) / sd;
 }
@@ -515,6 +613,124 @@ static int slice_step(po_pt *pt, po_replica *r) {
     return 0;
 }
 
+
+/* ---- AutoMALA (src/explorers/AutoMALA.jl, src/explorers/hamiltonian_dynamics.jl) -------------- */
+typedef struct {
+    po_pt *pt; po_replica *r; int64_t chain;
+    double *momentum, *precond, *start, *state_before, *momentum_before, *grad, *scratch;
+} am_ctx;
+
+static inline double am_log_joint(am_ctx *a) {          /* log_joint(target, state, momentum) :48-49 */
+    return lp_ad_at_chain(a->pt, a->chain, a->r->state, a->scratch) - 0.5 * po_sqr_norm(a->momentum, a->pt->d);
+}
+/* hamiltonian_dynamics! with n_steps = 1 (:59-102) */
+static int am_leap_frog(am_ctx *a, double step_size) {
+    const int64_t d = a->pt->d;
+    double *x = a->r->state, *p = a->momentum, *M = a->precond, *g = a->grad;
+    double logp = lp_grad_at_chain(a->pt, a->chain, x, g, a->scratch);
+    for (int64_t i = 0; i < d; i++) g[i] = g[i] / M[i];
+    (void)logp;
+    const double half = step_size / 2;
+    for (int64_t i = 0; i < d; i++) p[i] = p[i] + half * g[i];
+    for (int64_t i = 0; i < d; i++) x[i] = x[i] + step_size * (p[i] / M[i]);
+    logp = lp_grad_at_chain(a->pt, a->chain, x, g, a->scratch);
+    for (int64_t i = 0; i < d; i++) g[i] = g[i] / M[i];
+    double current = logp - 0.5 * po_sqr_norm(p, d);
+    if (!isfinite(current)) return 0;
+    for (int64_t i = 0; i < d; i++) p[i] = p[i] + half * g[i];
+    if (!isfinite(po_sqr_norm(p, d))) return 0;
+    return 1;
+}
+/* auto_step_size (:184-214) with log_joint_difference_function (:250-275), grow/shrink (:216-248) */
+static int am_auto_step_size(am_ctx *a, double step_size, double lower, double upper, int *exponent_out) {
+    const int64_t d = a->pt->d;
+    memcpy(a->state_before, a->r->state, sizeof(double) * (size_t)d);
+    memcpy(a->momentum_before, a->momentum, sizeof(double) * (size_t)d);
+    const double h_before = am_log_joint(a);
+#define AM_DIFF(eps, out) do { am_leap_frog(a, (eps)); double h_after_ = am_log_joint(a);                 \
+        memcpy(a->r->state, a->state_before, sizeof(double) * (size_t)d);                                 \
+        memcpy(a->momentum, a->momentum_before, sizeof(double) * (size_t)d); (out) = h_after_ - h_before; } while (0)
+    double diff;
+    AM_DIFF(step_size, diff);
+    int n_steps = 0, exponent = 0;
+    if (!isfinite(diff) || diff < lower) {
+        int n = 1;
+        for (;;) {
+            step_size /= 2.0;
+            AM_DIFF(step_size, diff);
+            if (step_size == 0.0) { fail(a->pt, "AutoMALA: could not find a positive step size"); return 1; }
+            if (diff > lower) { n_steps = n; exponent = -n; break; }
+            n++;
+        }
+    } else if (diff > upper) {
+        int n = 1;
+        for (;;) {
+            step_size *= 2.0;
+            AM_DIFF(step_size, diff);
+            if (!isfinite(diff) || diff < upper) { n_steps = n; exponent = n - 1; break; }
+            n++;
+        }
+    }
+#undef AM_DIFF
+    sum_fit(&a->r->rec.expl_steps[a->chain], (double)(1 + n_steps));
+    mean_fit(&a->r->rec.am_factors[a->chain], ldexp(1.0, exponent));
+    *exponent_out = exponent;
+    return 0;
+}
+/* step! -> _extract_commons_and_run! (:84-104) -> auto_mala! (:106-182) */
+static int automala_step(po_pt *pt, po_replica *r) {
+    const int64_t d = pt->d;
+    const po_config *cfg = &pt->cfg;
+    am_ctx a = { pt, r, r->chain, r->buf, r->buf + d, r->buf + 2 * d, r->buf + 3 * d, r->buf + 4 * d, r->buf + 5 * d, r->buf + 6 * d };
+    const int use_mh = (pt->scan != 1);
+    /* build_preconditioner! (src/explorers/Preconditioner.jl:57-77) */
+    if (pt->target_std == NULL || cfg->am_preconditioner == 0) {
+        for (int64_t i = 0; i < d; i++) a.precond[i] = 1.0;
+    } else if (cfg->am_preconditioner == 1) {
+        for (int64_t i = 0; i < d; i++) a.precond[i] = pt->target_std[i] == 0.0 ? 1.0 : 1.0 / pt->target_std[i];
+    } else {
+        double u = po_rand(&r->rng);
+        if (u <= cfg->am_p0) {
+            for (int64_t i = 0; i < d; i++) a.precond[i] = pt->target_std[i] == 0.0 ? 1.0 : 1.0 / pt->target_std[i];
+        } else if (u <= cfg->am_p0 + cfg->am_p1) {
+            for (int64_t i = 0; i < d; i++) a.precond[i] = 1.0;
+        } else {
+            double mix = po_rand(&r->rng), rmix = 1.0 - mix;
+            for (int64_t i = 0; i < d; i++) a.precond[i] = pt->target_std[i] == 0.0 ? 1.0 : mix + rmix / pt->target_std[i];
+        }
+    }
+    const int n_refresh = cfg->am_base_n_refresh * (int)ceil(pow((double)d, cfg->am_exponent_n_refresh));
+    for (int it = 0; it < n_refresh; it++) {
+        memcpy(a.start, r->state, sizeof(double) * (size_t)d);
+        for (int64_t i = 0; i < d; i++) a.momentum[i] = po_randn(&r->rng);
+        const double init_joint_log = am_log_joint(&a);
+        if (!isfinite(init_joint_log)) { fail(pt, "AutoMALA can only be called on a configuration of positive density."); return 1; }
+        double ua = po_rand(&r->rng), ub = po_rand(&r->rng);
+        double lower = log(ua < ub ? ua : ub), upper = log(ua < ub ? ub : ua);
+        int proposed_exponent, reversed_exponent;
+        if (am_auto_step_size(&a, pt->step_size, lower, upper, &proposed_exponent)) return 1;
+        const double proposed_step_size = pt->step_size * ldexp(1.0, proposed_exponent);
+        am_leap_frog(&a, proposed_step_size);
+        if (use_mh) {
+            for (int64_t i = 0; i < d; i++) a.momentum[i] = a.momentum[i] * -1.0;
+            if (am_auto_step_size(&a, pt->step_size, lower, upper, &reversed_exponent)) return 1;
+            int passed = (reversed_exponent == proposed_exponent);
+            mean_fit(&r->rec.rev_rate[a.chain], passed ? 1.0 : 0.0);
+            double probability = 0.0;
+            if (passed) {
+                double final_joint_log = am_log_joint(&a);
+                double e = exp(final_joint_log - init_joint_log);
+                probability = e < 1.0 ? e : 1.0;      /* min(1.0, NaN) is NaN in Julia; rand < NaN is false either way */
+                if (isnan(e)) probability = e;
+            }
+            mean_fit(&r->rec.expl_acc[a.chain], probability);
+            if (po_rand(&r->rng) < probability) { /* accept */ }
+            else memcpy(r->state, a.start, sizeof(double) * (size_t)d);
+        }
+    }
+    return 0;
+}
+
 /* explore!(pt, replica, explorer), src/pt/pigeons.jl:101-132 */
 static int explore_replica(po_pt *pt, po_replica *r) {
     const int64_t N = pt->N;
@@ -525,11 +741,12 @@ static int explore_replica(po_pt *pt, po_replica *r) {
         switch (pt->cfg.explorer) {
         case PO_EXPLORER_TOY:   mvn_sample_iid(pt, r); break;
         case PO_EXPLORER_SLICE: if (slice_step(pt, r)) return 1; break;
+        case PO_EXPLORER_AUTOMALA: if (automala_step(pt, r)) return 1; break;
         case PO_EXPLORER_NONE:  break;
         default: fail(pt, "oracle: explorer not implemented"); return 1;
         }
     }
-    if (is_target(N, r->chain) && pt->cfg.record_online) {
+    if (is_target(N, r->chain) && (pt->cfg.record_online || (pt->cfg.explorer == PO_EXPLORER_AUTOMALA && pt->cfg.am_preconditioner != 0))) {
         for (int64_t i = 0; i < pt->d; i++) {       /* OnlineStateRecorder.jl:87-96 */
             mean_fit(&r->rec.on_mean[i], r->state[i]);
             var_fit(&r->rec.on_var[i], r->state[i]);
@@ -642,6 +859,7 @@ po_pt *po_create(const po_config *cfg) {
         r->buf = (double *)calloc((size_t)(8 * (d > 0 ? d : 1)), sizeof(double));
         rec_alloc(&r->rec, N, d);
         rec_empty(&r->rec, N, d);
+        /* funnel: initialization = zeros(dim) (test/supporting/dimensional-analysis.jl:24) -- calloc above */
         if (cfg->target == PO_TARGET_MVN) {
             /* initialization, src/targets/toy_mvn_target.jl:10-11 */
             double s = sqrt(cfg->p1);
@@ -772,6 +990,16 @@ int po_end_round(po_pt *pt) {
         stepping_stone(pt);                                 /* report uses pre-adapt recorders */
         if (adapt_tempering(pt)) return 1;
     }
+    if (pt->cfg.explorer == PO_EXPLORER_AUTOMALA) {
+        /* adapt_explorer(::AutoMALA), src/explorers/AutoMALA.jl:70-79 */
+        if (pt->cfg.am_preconditioner != 0) {               /* adapt_preconditioner, Preconditioner.jl:54-55 */
+            if (!pt->target_std) pt->target_std = (double *)calloc((size_t)(d > 0 ? d : 1), sizeof(double));
+            for (int64_t i = 0; i < d; i++) pt->target_std[i] = sqrt(var_value(&pt->reduced.on_var[i]));
+        }
+        double acc = 0.0; int64_t cnt = 0;
+        for (int64_t c = 0; c < N; c++) if (pt->reduced.am_factors[c].n > 0) { acc += pt->reduced.am_factors[c].mu; cnt++; }
+        if (cnt > 0) pt->step_size = pt->step_size * (acc / (double)cnt);
+    }
     return 0;
 }
 
@@ -832,6 +1060,18 @@ double po_cumulative_barrier(const po_pt *pt, double beta) {
     return po_fc_eval(pt->cb_x, pt->cb_y, pt->cb_m, pt->cb_c, pt->cb_d, pt->N, beta);
 }
 double po_get_step_size(const po_pt *pt) { return pt->step_size; }
+int64_t po_get_target_std(const po_pt *pt, double *out) {
+    if (!pt->target_std) return 0;
+    memcpy(out, pt->target_std, sizeof(double) * (size_t)pt->d);
+    return pt->d;
+}
+void po_set_explorer_adaptation(po_pt *pt, double step_size, const double *target_std) {
+    pt->step_size = step_size;
+    if (target_std) {
+        if (!pt->target_std) pt->target_std = (double *)calloc((size_t)(pt->d > 0 ? pt->d : 1), sizeof(double));
+        memcpy(pt->target_std, target_std, sizeof(double) * (size_t)pt->d);
+    }
+}
 
 /* ========================================================================== */
 /* chain-sharded operation: test-only restatement of the multi-GPU protocol    */
@@ -901,7 +1141,7 @@ int po_shard_swap_finish(po_pt *pt, int64_t scan, const double *nbr, int32_t *ac
     for (int64_t s = 0; s < K; s++) pt->replica_of_chain[pt->replicas[s].chain - pt->c0] = s;
     return 0;
 }
-int64_t po_shard_payload_words(const po_pt *pt) { return pt->d + 5; }
+int64_t po_shard_payload_words(const po_pt *pt) { return pt->d + 6; }
 /* payload: [0..d) state, d: (unused: the HIP engine ships sum x^2 here), d+1,d+2: rng, d+3: replica id, d+4: round-trip state */
 void po_shard_export(po_pt *pt, int side, double *buf) {
     po_replica *r = &pt->replicas[pt->replica_of_chain[side == 0 ? 0 : pt->K - 1]];

@@ -118,6 +118,8 @@ void    po_get_stepping_stone(const po_pt *pt, double *pair);                   
 double  po_get_global_barrier(const po_pt *pt);
 double  po_cumulative_barrier(const po_pt *pt, double beta);
 double  po_get_step_size(const po_pt *pt);
+int64_t po_get_target_std(const po_pt *pt, double *out);                         /* d; returns 0 if `nothing` */
+void    po_set_explorer_adaptation(po_pt *pt, double step_size, const double *target_std);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@
 #include "pte_kernels.hpp"
 #include "pte_slice2.hpp"
 #include "pte_slice3.hpp"
+#include "pte_automala.hpp"
 
 using namespace pte;
 
@@ -48,7 +49,11 @@ struct pte_engine {
     double *d_payload = nullptr;   // staging buffer for boundary export/import
     std::vector<double> betas;
     std::vector<void *> allocs;
-    double *d_nhp = nullptr, *d_sd = nullptr;
+    double *d_nhp = nullptr, *d_sd = nullptr, *d_nprec = nullptr, *d_beta = nullptr, *d_target_std = nullptr;
+    bool have_target_std = false;
+    double step_size = 1.0;
+    int am_n_refresh = 0;
+    std::vector<double> fac_mean, rev_mean; std::vector<int64_t> fac_n, rev_n;
     int64_t scans_in_round = 0;      // scans run since the last pte_reduce
     Snapshot snap;
     std::string err;
@@ -111,18 +116,23 @@ int next_pow2_log(int64_t n) { int l = 0; while (((int64_t)1 << l) < n) ++l; ret
 // (reference src/paths/ScaledPrecisionNormalPath.jl:45-48, src/schedules/discretize.jl:6-7).
 int upload_ladder(pte_engine *h) {
     const int64_t N = h->N;
-    std::vector<double> nhp(N, 0.0), sd(N, 1.0);
+    std::vector<double> nhp(N, 0.0), sd(N, 1.0), nprec(N, 0.0);
     if (h->cfg.target == PTE_TARGET_MVN_SCALED_PRECISION) {
         const double p0 = h->cfg.target_params[0], p1 = h->cfg.target_params[1];
         for (int64_t c = 0; c < N; ++c) {
             const double beta = h->betas[c];
             const double prec = (1.0 - beta) * p0 + beta * p1;
             nhp[c] = -0.5 * prec;
+            nprec[c] = -prec;
             sd[c] = std::sqrt(prec);
         }
+    } else if (h->cfg.target == PTE_TARGET_FUNNEL) {
+        for (int64_t c = 0; c < N; ++c) sd[c] = std::sqrt(h->cfg.target_params[0]);   // reference end point
     }
     HIP_OK(h, hipMemcpyAsync(h->d_nhp, nhp.data(), sizeof(double) * N, hipMemcpyHostToDevice, h->stream));
     HIP_OK(h, hipMemcpyAsync(h->d_sd, sd.data(), sizeof(double) * N, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipMemcpyAsync(h->d_nprec, nprec.data(), sizeof(double) * N, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipMemcpyAsync(h->d_beta, h->betas.data(), sizeof(double) * N, hipMemcpyHostToDevice, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
@@ -143,6 +153,10 @@ int reset_recorders(pte_engine *h) {
     HIP_OK(h, hipMemsetAsync(e.expl_acc_n, 0, sizeof(int64_t) * N, h->stream));
     HIP_OK(h, hipMemsetAsync(e.expl_steps_sum, 0, sizeof(double) * N, h->stream));
     HIP_OK(h, hipMemsetAsync(e.expl_steps_n, 0, sizeof(int64_t) * N, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.am_fac_sum, 0, sizeof(double) * N, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.am_fac_n, 0, sizeof(int64_t) * N, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.am_rev_sum, 0, sizeof(double) * N, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.am_rev_n, 0, sizeof(int64_t) * N, h->stream));
     const int64_t dd = h->d > 0 ? h->d : 1;
     HIP_OK(h, hipMemsetAsync(e.on_mean, 0, sizeof(double) * dd, h->stream));
     HIP_OK(h, hipMemsetAsync(e.on_m2, 0, sizeof(double) * dd, h->stream));
@@ -163,6 +177,8 @@ int check_device_error(pte_engine *h) {
     case ERR_SLICE_SUPPORT: return fail(h, "SliceSampler supports contrained target, but the sampler should be initialized in the support (chain %d)", err[1]);
     case ERR_SLICE_INVALID_LP: return fail(h, "Got an invalid log density after updating state at index %d (chain %d)", err[2], err[1]);
     case ERR_SLICE_MAX_ITER: return fail(h, "Maximum number of iterations reached in slice_shrink! (chain %d, index %d)", err[1], err[2]);
+    case ERR_AM_DENSITY: return fail(h, "AutoMALA can only be called on a configuration of positive density. (chain %d)", err[1]);
+    case ERR_AM_STEP: return fail(h, "Could not find a positive step size (chain %d)", err[1]);
     default: return fail(h, "device error %d", err[0]);
     }
 }
@@ -213,6 +229,25 @@ int launch_explore(pte_engine *h, int64_t scan) {
         } else {
             DISPATCH_NLU_M(h->nlu, k_explore_slice2, 4, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         }
+        time_end(h);
+        break;
+    }
+    case PTE_EXPLORER_AUTOMALA: {
+        AmParams ap{};
+        ap.step_size = h->step_size; ap.n_refresh = h->am_n_refresh; ap.precond = h->cfg.am_preconditioner;
+        ap.p0 = h->cfg.am_p0; ap.p1 = h->cfg.am_p1;
+        ap.target_std = h->have_target_std ? h->d_target_std : nullptr;
+        ap.use_mh = (scan != 1) ? 1 : 0;                 // AutoMALA.jl:87,96-102
+        ap.ref_prec = h->cfg.target_params[0]; ap.log3 = std::log(3.0);
+        const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
+        const bool fun = h->cfg.target == PTE_TARGET_FUNNEL;
+        time_begin(h, 0);
+#define AM_LAUNCH(EE)                                                                                         \
+        if (fun) hipLaunchKernelGGL((k_explore_automala<EE, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
+        else hipLaunchKernelGGL((k_explore_automala<EE, TGT_MVN>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap);
+        switch (E) { case 1: AM_LAUNCH(1) break; case 2: AM_LAUNCH(2) break; case 4: AM_LAUNCH(4) break;
+                     case 8: AM_LAUNCH(8) break; default: AM_LAUNCH(16) break; }
+#undef AM_LAUNCH
         time_end(h);
         break;
     }
@@ -284,13 +319,18 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, "pte_create: bad rank / world_size");
     if (cfg->n_chains % cfg->world_size != 0) return fail(nullptr, "pte_create: n_chains (%lld) must be a multiple of world_size (%d)", (long long)cfg->n_chains, cfg->world_size);
     const bool swapper = cfg->target == PTE_TARGET_TEST_SWAPPER;
-    if (!swapper && cfg->target != PTE_TARGET_MVN_SCALED_PRECISION)
+    const bool funnel = cfg->target == PTE_TARGET_FUNNEL;
+    if (!swapper && !funnel && cfg->target != PTE_TARGET_MVN_SCALED_PRECISION)
         return fail(nullptr, "pte_create: target %d has no device log-potential; use the reference CPU path", cfg->target);
+    if (funnel && cfg->explorer != PTE_EXPLORER_AUTOMALA)
+        return fail(nullptr, "pte_create: the funnel path is implemented for AutoMALA only; use the reference CPU path");
+    if (cfg->explorer == PTE_EXPLORER_AUTOMALA && (cfg->dim < 1 || cfg->dim > 1024))
+        return fail(nullptr, "pte_create: AutoMALA keeps the replica in registers, dim must be in 1..1024 (got %lld)", (long long)cfg->dim);
     if (!swapper && (cfg->dim < 1 || cfg->dim > 4096))
         return fail(nullptr, "pte_create: dim must be in 1..4096 (got %lld)", (long long)cfg->dim);
     if (swapper && cfg->explorer != PTE_EXPLORER_NONE)
         return fail(nullptr, "pte_create: TestSwapper has no explorer");
-    if (!swapper && cfg->explorer != PTE_EXPLORER_TOY && cfg->explorer != PTE_EXPLORER_SLICE)
+    if (!swapper && cfg->explorer != PTE_EXPLORER_TOY && cfg->explorer != PTE_EXPLORER_SLICE && cfg->explorer != PTE_EXPLORER_AUTOMALA)
         return fail(nullptr, "pte_create: explorer %d is not implemented on the device", cfg->explorer);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -329,6 +369,12 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.suff, (size_t)K);
     rc |= dev_alloc(h, &h->d_nhp, (size_t)N);
     rc |= dev_alloc(h, &h->d_sd, (size_t)N);
+    rc |= dev_alloc(h, &h->d_nprec, (size_t)N);
+    rc |= dev_alloc(h, &h->d_beta, (size_t)N);
+    rc |= dev_alloc(h, &h->d_target_std, (size_t)dd);
+    rc |= dev_alloc(h, &e.suff2, (size_t)K);
+    rc |= dev_alloc(h, &e.am_fac_sum, (size_t)K); rc |= dev_alloc(h, &e.am_fac_n, (size_t)K);
+    rc |= dev_alloc(h, &e.am_rev_sum, (size_t)K); rc |= dev_alloc(h, &e.am_rev_n, (size_t)K);
     rc |= dev_alloc(h, &e.swap_sum, (size_t)K);  rc |= dev_alloc(h, &e.swap_n, (size_t)K);
     rc |= dev_alloc(h, &e.lsr_up, (size_t)K);    rc |= dev_alloc(h, &e.lsr_dn, (size_t)K);
     rc |= dev_alloc(h, &e.lsr_n, (size_t)K);
@@ -343,7 +389,12 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.ip_replica, (size_t)ipcap, false);
     rc |= dev_alloc(h, &e.error, 4);
     if (rc) return bail(1);
-    e.nhp = h->d_nhp; e.sd = h->d_sd;
+    e.nhp = h->d_nhp; e.sd = h->d_sd; e.nprec = h->d_nprec; e.beta = h->d_beta;
+    e.ref_nhp = -0.5 * cfg->target_params[0];
+    h->step_size = cfg->am_step_size;
+    // n_refresh = base_n_refresh * ceil(Int, dim^exponent_n_refresh)  (AutoMALA.jl:120)
+    h->am_n_refresh = cfg->am_base_n_refresh * (int)std::ceil(std::pow((double)(d > 0 ? d : 1), cfg->am_exponent_n_refresh));
+    if (cfg->explorer == PTE_EXPLORER_AUTOMALA && cfg->am_preconditioner != 0) e.record_flags |= PTE_RECORD_ONLINE;   // _transformed_online (GradientBasedSampler.jl:19-25)
     e.slot_of_chain = h->slot_map[0]; e.slot_of_chain_alt = h->slot_map[1]; h->slot_cur = 0;
 
     // equally_spaced_schedule (reference src/schedules/Schedule.jl:36-44)
@@ -356,6 +407,34 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     DISPATCH_NLU(h->nlu, k_init, dim3((unsigned)K), dim3(64), h->stream, e, (uint64_t)cfg->seed, init_sd);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
         h->err = "k_init launch failed"; return bail(1);
+    }
+    if (funnel) {
+        // initialization(::LogDensity, rng, i) = zeros(dim) (test/supporting/dimensional-analysis.jl:24): the streams
+        // stay untouched; suff2 = funnel(0) = d terms evaluated on the host exactly like the kernels' tree of equal terms
+        std::vector<uint64_t> rngs((size_t)(2 * K));
+        const uint64_t G = 0x9e3779b97f4a7c15ULL;
+        auto mix64h = [](uint64_t z) { z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; return z ^ (z >> 31); };
+        auto mixg = [](uint64_t z) { z = (z ^ (z >> 33)) * 0xff51afd7ed558ccdULL; z = (z ^ (z >> 33)) * 0xc4ceb9fe1a85ec53ULL; z = (z ^ (z >> 33)) | 1ULL;
+                                     return (__builtin_popcountll(z ^ (z >> 1)) < 24) ? (z ^ 0xaaaaaaaaaaaaaaaaULL) : z; };
+        for (int64_t il = 0; il < K; ++il) {
+            const uint64_t i = (uint64_t)(h->c0 + il);
+            rngs[2 * il] = mix64h(cfg->seed + (2 * i + 1) * G); rngs[2 * il + 1] = mixg(cfg->seed + (2 * i + 2) * G);
+        }
+        hipMemcpyAsync(e.rng, rngs.data(), sizeof(uint64_t) * 2 * K, hipMemcpyHostToDevice, h->stream);
+        hipMemsetAsync(e.x, 0, sizeof(double) * K * e.ld, h->stream);
+        hipMemsetAsync(e.suff, 0, sizeof(double) * K, h->stream);
+        // funnel(0): terms[0] = -(log2pi)/2 - log 3 ; terms[i] = -(log2pi)/2 - log(exp(0)) ; summed with the fixed tree
+        std::vector<double> terms((size_t)d);
+        const double LOG2PI = 1.8378770664093453;
+        const double sigma = std::exp(0.0 / 2.0), ls = std::log(sigma);
+        for (int64_t i = 0; i < d; ++i) terms[i] = -(0.0 * 0.0 + LOG2PI) / 2.0 - (i == 0 ? std::log(3.0) : ls);
+        int64_t P = 1; while (P < d) P <<= 1;
+        std::vector<double> a((size_t)P, 0.0);
+        for (int64_t i = 0; i < d; ++i) a[i] = terms[i];
+        for (int64_t len = P; len > 1; len /= 2) for (int64_t i = 0; i < len / 2; ++i) a[i] = a[2 * i] + a[2 * i + 1];
+        std::vector<double> s2((size_t)K, a[0]);
+        hipMemcpyAsync(e.suff2, s2.data(), sizeof(double) * K, hipMemcpyHostToDevice, h->stream);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "funnel init failed"; return bail(1); }
     }
     *out = h;
     return 0;
@@ -393,10 +472,18 @@ int pte_get_schedule(const pte_engine *h, double *betas) {
 }
 
 int pte_set_explorer_adaptation(pte_engine *h, double step_size, const double *target_std, int64_t dim) {
-    (void)step_size; (void)target_std; (void)dim;
     if (!h) return 1;
     if (h->cfg.explorer != PTE_EXPLORER_AUTOMALA) return 0;   // nothing to adapt for SliceSampler / ToyExplorer
-    return fail(h, "AutoMALA is not implemented on the device yet");
+    if (!(step_size > 0)) return fail(h, "pte_set_explorer_adaptation: step_size must be > 0");
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    h->step_size = step_size;
+    if (target_std) {
+        if (dim != h->d) return fail(h, "pte_set_explorer_adaptation: expected %lld std deviations", (long long)h->d);
+        HIP_OK(h, hipMemcpyAsync(h->d_target_std, target_std, sizeof(double) * dim, hipMemcpyHostToDevice, h->stream));
+        HIP_OK(h, hipStreamSynchronize(h->stream));
+        h->have_target_std = true;
+    }
+    return 0;
 }
 
 int pte_explore(pte_engine *h, int64_t scan) {
@@ -447,6 +534,10 @@ int pte_reduce(pte_engine *h) {
     D2H(acc_sum.data(), e.expl_acc_sum, K); D2H(s.acc_n.data(), e.expl_acc_n, K);
     D2H(s.steps_sum.data(), e.expl_steps_sum, K); D2H(s.steps_n.data(), e.expl_steps_n, K);
     D2H(s.on_mean.data(), e.on_mean, dd); D2H(m2.data(), e.on_m2, dd); D2H(&s.on_n, e.on_n, 1);
+    std::vector<double> fsum(K), rsum(K);
+    h->fac_mean.assign(K, 0.0); h->rev_mean.assign(K, 0.0); h->fac_n.assign(K, 0); h->rev_n.assign(K, 0);
+    D2H(fsum.data(), e.am_fac_sum, K); D2H(h->fac_n.data(), e.am_fac_n, K);
+    D2H(rsum.data(), e.am_rev_sum, K); D2H(h->rev_n.data(), e.am_rev_n, K);
     s.n_scans = h->scans_in_round;
     s.ip_chain.clear(); s.ip_replica.clear();
     if (h->cfg.record_flags & PTE_RECORD_INDEX_PROCESS) {
@@ -463,6 +554,10 @@ int pte_reduce(pte_engine *h) {
     for (int64_t i = 0; i < K; ++i) { s.restarts += rs[i]; s.trips += rr[i]; }
     for (int64_t i = 0; i < K; ++i) s.acc_mean[i] = s.acc_n[i] > 0 ? acc_sum[i] / (double)s.acc_n[i] : 0.0;
     for (int64_t i = 0; i < dd; ++i) s.on_var[i] = s.on_n > 1 ? m2[i] / (double)(s.on_n - 1) : 1.0;
+    for (int64_t i = 0; i < K; ++i) {
+        h->fac_mean[i] = h->fac_n[i] > 0 ? fsum[i] / (double)h->fac_n[i] : 0.0;
+        h->rev_mean[i] = h->rev_n[i] > 0 ? rsum[i] / (double)h->rev_n[i] : 0.0;
+    }
     return reset_recorders(h);
 }
 
@@ -524,7 +619,11 @@ int pte_get_explorer_stats(const pte_engine *h, double *am, int64_t *an, double 
 }
 int pte_get_automala_stats(const pte_engine *h, double *fm, int64_t *fn, double *rm, int64_t *rn) {
     if (!h) return 1;
-    for (int64_t i = 0; i < h->K; ++i) { fm[i] = 0; fn[i] = 0; rm[i] = 0; rn[i] = 0; }
+    for (int64_t i = 0; i < h->K; ++i) {
+        const bool have = (int64_t)h->fac_mean.size() == h->K;
+        fm[i] = have ? h->fac_mean[i] : 0; fn[i] = have ? h->fac_n[i] : 0;
+        rm[i] = have ? h->rev_mean[i] : 0; rn[i] = have ? h->rev_n[i] : 0;
+    }
     return 0;
 }
 int pte_get_online(const pte_engine *h, double *mean, double *variance, int64_t *n) {
@@ -582,7 +681,7 @@ int pte_swap_finish(pte_engine *h, int64_t scan, const double *nbr_stats, int32_
     time_collect(h);
     return rc;
 }
-int64_t pte_boundary_payload_bytes(const pte_engine *h) { return h ? (int64_t)sizeof(double) * (h->d + 5) : 0; }
+int64_t pte_boundary_payload_bytes(const pte_engine *h) { return h ? (int64_t)sizeof(double) * (h->d + 6) : 0; }
 int pte_boundary_export(pte_engine *h, int side, void *dst, int dst_is_device) {
     if (!h || !dst || side < 0 || side > 1) return 1;
     HIP_OK(h, hipSetDevice(h->cfg.device));

@@ -1,0 +1,303 @@
+// pte_automala.hpp -- k_explore_automala: AutoMALA (reference src/explorers/AutoMALA.jl:84-275,
+// src/explorers/hamiltonian_dynamics.jl:48-102, src/explorers/Preconditioner.jl:57-77) on the
+// device log-potential families, one wavefront per replica.
+//
+// Every vector of the algorithm (state, momentum, preconditioner, start state, the two "before"
+// copies, gradient) lives in registers: lane l holds elements 64j + l, j < E.  A log-density / norm
+// evaluation is E DPP wave reductions (the fixed tree of pte_device.hpp) -- no LDS, no HBM traffic
+// between the initial load and the final store of the state.  Log potentials:
+//   TGT_MVN    ScaledPrecisionNormalLogPotential, analytic gradient (src/paths/ScaledPrecisionNormalPath.jl:19-34)
+//   TGT_FUNNEL InterpolatedAD of {ScaledPrecisionNormal(p0) reference, Neal's funnel}
+//              (src/explorers/BufferedAD.jl:89-112; funnel test/supporting/dimensional-analysis.jl:36-48)
+#pragma once
+#include "pte_kernels.hpp"
+
+namespace pte {
+
+enum { TGT_MVN = 0, TGT_FUNNEL = 2 };
+enum { ERR_AM_DENSITY = 5, ERR_AM_STEP = 6 };
+
+struct AmParams {
+    double step_size;
+    int n_refresh;
+    int precond;            // 0 identity, 1 diagonal, 2 mix-diagonal
+    double p0, p1;          // mix proportions
+    const double *target_std;   // [d] or nullptr (== `nothing`: identity, no draw)
+    int use_mh;             // scan != 1
+    double ref_prec;        // funnel: precision of the normal reference
+    double log3;            // log(3.0) from the host libm
+};
+
+// ---- DPP wave reduction with the association of the fixed tree; result uniform -----------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_step(double v) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v = dpp_add_step<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]  : lanes l, l^1
+    v = dpp_add_step<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]  : l, l^2
+    v = dpp_add_step<0x141, 0xF>(v);    // row_half_mirror      : other group of 4 (uniform inside groups)
+    v = dpp_add_step<0x140, 0xF>(v);    // row_mirror           : other group of 8
+    v = dpp_add_step<0x142, 0xA>(v);    // row_bcast15 -> rows 1,3 (disabled rows add +0.0)
+    v = dpp_add_step<0x143, 0xC>(v);    // row_bcast31 -> rows 2,3
+    return readlane_f64(v, 63);
+}
+// tree over the E block sums (uniform values), E a power of two
+template <int E>
+__device__ __forceinline__ double block_tree(double (&s)[E]) {
+#pragma unroll
+    for (int w = E; w > 1; w >>= 1)
+#pragma unroll
+        for (int i = 0; i < w / 2; ++i) s[i] = s[2 * i] + s[2 * i + 1];
+    return s[0];
+}
+template <int E>
+__device__ __forceinline__ double tree_sum_regs(const double (&t)[E]) {
+    double s[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) s[j] = wave_sum_dpp(t[j]);
+    return block_tree<E>(s);
+}
+template <int E>
+__device__ __forceinline__ double sqr_norm_regs(const double (&v)[E]) {
+    double t[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) t[j] = v[j] * v[j];
+    return tree_sum_regs<E>(t);
+}
+
+template <int E, int TGT>
+struct AmTarget {
+    int64_t d; int lane;
+    double nhp, nprec;          // MVN: -0.5*prec, -prec of this chain
+    double beta, omb, ref_nhp, ref_nprec, log3;   // funnel path
+    __device__ __forceinline__ bool valid(int j) const { return 64 * (int64_t)j + lane < d; }
+
+    // funnel: log density and (optionally) gradient; S = sum x^2 supplied by the caller
+    __device__ __forceinline__ double funnel(const double (&x)[E], double (*g)[E]) const {
+        const double y = readlane_f64(x[0], 0);
+        const double sigma = exp(y / 2.0);
+        const double logsigma = log(sigma);
+        const double LOG2PI = 1.8378770664093453;
+        double t[E], zi[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            zi[j] = x[j] / sigma;
+            t[j] = valid(j) ? (-(zi[j] * zi[j] + LOG2PI) / 2.0 - logsigma) : 0.0;
+        }
+        const double zv = y / 3.0;
+        if (lane == 0) t[0] = -(zv * zv + LOG2PI) / 2.0 - log3;
+        const double lp = tree_sum_regs<E>(t);
+        if (g) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                (*g)[j] = valid(j) ? -(zi[j] / sigma) : 0.0;
+                t[j] = valid(j) ? (zi[j] * zi[j] - 1.0) / 2.0 : 0.0;
+            }
+            if (lane == 0) t[0] = -(y / 9.0);
+            const double gy = tree_sum_regs<E>(t);
+            if (lane == 0) (*g)[0] = gy;
+        }
+        return lp;
+    }
+    // LogDensityProblems.logdensity
+    __device__ __forceinline__ double logdensity(const double (&x)[E]) const {
+        const double S = sqr_norm_regs<E>(x);
+        if (TGT == TGT_MVN) return nhp * S;
+        const double l1 = ref_nhp * S;
+        const double l2 = funnel(x, nullptr);
+        return omb * l1 + beta * l2;
+    }
+    // LogDensityProblems.logdensity_and_gradient
+    __device__ __forceinline__ double logdensity_and_gradient(const double (&x)[E], double (&g)[E]) const {
+        const double S = sqr_norm_regs<E>(x);
+        if (TGT == TGT_MVN) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) g[j] = nprec * x[j];
+            return nhp * S;
+        }
+        double logdens = 0.0;
+        const double l1 = ref_nhp * S;
+        logdens += l1 * omb;
+        double g2[E];
+        const double l2 = funnel(x, &g2);
+        logdens += l2 * beta;
+#pragma unroll
+        for (int j = 0; j < E; ++j) g[j] = (ref_nprec * x[j]) * omb + g2[j] * beta;
+        return logdens;
+    }
+};
+
+template <int E, int TGT>
+__global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams ap) {
+    constexpr int NLU = (E == 1 ? 0 : E == 2 ? 1 : E == 4 ? 2 : E == 8 ? 3 : 4);
+    const int lane = lane_id();
+    const int64_t cl = blockIdx.x;
+    if (cl >= e.K) return;
+    const int64_t c = e.c0 + cl;
+    const int slot = e.slot_of_chain[cl];
+    const int64_t d = e.d;
+    double *xrow = e.x + (int64_t)slot * e.ld;
+    AmTarget<E, TGT> T;
+    T.d = d; T.lane = lane;
+    T.nhp = e.nhp[c]; T.nprec = e.nprec[c];
+    T.beta = e.beta[c]; T.omb = 1.0 - T.beta;
+    T.ref_nhp = -0.5 * ap.ref_prec; T.ref_nprec = -ap.ref_prec; T.log3 = ap.log3;
+
+    double x[E];
+    if (c == 0 && e.N > 1) {
+        iid_refresh<NLU>(e, slot, e.sd[0], lane);        // sample_iid! at the reference (pigeons.jl:104-105)
+        __threadfence_block();
+        if (TGT == TGT_FUNNEL) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) x[j] = T.valid(j) ? xrow[64 * j + lane] : 0.0;
+            const double l2 = T.funnel(x, nullptr);
+            if (lane == 0) e.suff2[slot] = l2;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) x[j] = T.valid(j) ? xrow[64 * j + lane] : 0.0;
+
+    SeqRng r{e.rng[2 * slot], e.rng[2 * slot + 1]};
+    // build_preconditioner! (Preconditioner.jl:57-77)
+    double M[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) M[j] = 1.0;
+    if (ap.target_std != nullptr && ap.precond != 0) {
+        double sdv[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) sdv[j] = T.valid(j) ? ap.target_std[64 * j + lane] : 1.0;
+        if (ap.precond == 1) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) M[j] = sdv[j] == 0.0 ? 1.0 : 1.0 / sdv[j];
+        } else {
+            const double u = r.rand();
+            if (u <= ap.p0) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) M[j] = sdv[j] == 0.0 ? 1.0 : 1.0 / sdv[j];
+            } else if (u <= ap.p0 + ap.p1) {
+                // ones
+            } else {
+                const double mix = r.rand(), rmix = 1.0 - mix;
+#pragma unroll
+                for (int j = 0; j < E; ++j) M[j] = sdv[j] == 0.0 ? 1.0 : mix + rmix / sdv[j];
+            }
+        }
+    }
+
+    double p[E], g[E], xs[E], xb[E], pb[E];
+    long long steps_sum = 0; int steps_n = 0;
+    double fac_sum = 0.0; int fac_n = 0;
+    int rev_sum = 0, rev_n = 0;
+    double acc_sum = 0.0; int acc_n = 0;
+    int err = 0;
+
+    auto log_joint = [&]() -> double { return T.logdensity(x) - 0.5 * sqr_norm_regs<E>(p); };
+    // hamiltonian_dynamics! with n_steps = 1
+    auto leap_frog = [&](double eps) -> bool {
+        T.logdensity_and_gradient(x, g);
+        const double half = eps / 2;
+#pragma unroll
+        for (int j = 0; j < E; ++j) { g[j] = g[j] / M[j]; p[j] = p[j] + half * g[j]; }
+#pragma unroll
+        for (int j = 0; j < E; ++j) x[j] = x[j] + eps * (p[j] / M[j]);
+        const double logp = T.logdensity_and_gradient(x, g);
+#pragma unroll
+        for (int j = 0; j < E; ++j) g[j] = g[j] / M[j];
+        const double cur = logp - 0.5 * sqr_norm_regs<E>(p);
+        if (!isfinite(cur)) return false;
+#pragma unroll
+        for (int j = 0; j < E; ++j) p[j] = p[j] + half * g[j];
+        if (!isfinite(sqr_norm_regs<E>(p))) return false;
+        return true;
+    };
+    // auto_step_size (:184-214): returns the exponent
+    auto auto_step_size = [&](double lower, double upper) -> int {
+#pragma unroll
+        for (int j = 0; j < E; ++j) { xb[j] = x[j]; pb[j] = p[j]; }
+        const double h_before = log_joint();
+        double eps = ap.step_size;
+        auto diff_at = [&](double ee) -> double {
+            leap_frog(ee);
+            const double h_after = log_joint();
+#pragma unroll
+            for (int j = 0; j < E; ++j) { x[j] = xb[j]; p[j] = pb[j]; }
+            return h_after - h_before;
+        };
+        double diff = diff_at(eps);
+        int n_steps = 0, exponent = 0;
+        if (!isfinite(diff) || diff < lower) {
+            for (int n = 1;; ++n) {
+                eps /= 2.0;
+                diff = diff_at(eps);
+                if (eps == 0.0) { err = ERR_AM_STEP; break; }
+                if (diff > lower) { n_steps = n; exponent = -n; break; }
+            }
+        } else if (diff > upper) {
+            for (int n = 1;; ++n) {
+                eps *= 2.0;
+                diff = diff_at(eps);
+                if (!isfinite(diff) || diff < upper) { n_steps = n; exponent = n - 1; break; }
+            }
+        }
+        steps_sum += 1 + n_steps; steps_n += 1;
+        fac_sum += ldexp(1.0, exponent); fac_n += 1;
+        return exponent;
+    };
+
+    for (int it = 0; it < ap.n_refresh && !err; ++it) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            xs[j] = x[j];
+            const int nl = (int)max((int64_t)0, min((int64_t)64, d - 64 * (int64_t)j));
+            p[j] = 0.0;
+            if (nl > 0) { const double v = wave_randn_block(r, lane, nl); p[j] = lane < nl ? v : 0.0; }
+        }
+        const double init_joint = log_joint();
+        if (!isfinite(init_joint)) { err = ERR_AM_DENSITY; break; }
+        const double ua = r.rand(), ub = r.rand();
+        const double lower = log(ua < ub ? ua : ub), upper = log(ua < ub ? ub : ua);
+        const int proposed = auto_step_size(lower, upper);
+        if (err) break;
+        leap_frog(ap.step_size * ldexp(1.0, proposed));
+        if (ap.use_mh) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) p[j] = p[j] * -1.0;
+            const int reversed = auto_step_size(lower, upper);
+            if (err) break;
+            const bool passed = reversed == proposed;
+            rev_sum += passed ? 1 : 0; rev_n += 1;
+            double probability = 0.0;
+            if (passed) {
+                const double ex = exp(log_joint() - init_joint);
+                probability = ex < 1.0 ? ex : (isnan(ex) ? ex : 1.0);
+            }
+            acc_sum += probability; acc_n += 1;
+            if (!(r.rand() < probability)) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) x[j] = xs[j];
+            }
+        }
+    }
+    if (err) { if (lane == 0) set_error(e, err, (int)c, -1); return; }
+#pragma unroll
+    for (int j = 0; j < E; ++j) if (T.valid(j)) xrow[64 * j + lane] = x[j];
+    const double S = sqr_norm_regs<E>(x);
+    double l2 = 0.0;
+    if (TGT == TGT_FUNNEL) l2 = T.funnel(x, nullptr);
+    if (lane == 0) {
+        e.suff[slot] = S;
+        if (TGT == TGT_FUNNEL) e.suff2[slot] = l2;
+        e.rng[2 * slot] = r.seed;
+        e.expl_steps_sum[cl] += (double)steps_sum; e.expl_steps_n[cl] += steps_n;
+        e.expl_acc_sum[cl] += acc_sum;             e.expl_acc_n[cl] += acc_n;
+        e.am_fac_sum[cl] += fac_sum;               e.am_fac_n[cl] += fac_n;
+        e.am_rev_sum[cl] += (double)rev_sum;       e.am_rev_n[cl] += rev_n;
+    }
+    if (c == e.N - 1 && (e.record_flags & 4u)) { __threadfence_block(); record_online(e, slot, lane); }
+}
+
+}  // namespace pte

@@ -33,6 +33,12 @@ struct EngineDev {
     double *suff;
     const double *nhp;
     const double *sd;
+    const double *nprec;       // [chain] -precision(beta_chain)            (AutoMALA gradient)
+    const double *beta;        // [chain] Schedule.grids                     (interpolated paths)
+    double *suff2;             // [slot]  second swap statistic: target log density (interpolated paths)
+    double ref_nhp;            // -0.5 * precision of the normal reference of an interpolated path
+    double *am_fac_sum; int64_t *am_fac_n;     // [chain] am_factors          (AutoMALA.jl:277)
+    double *am_rev_sum; int64_t *am_rev_n;     // [chain] reversibility_rate  (AutoMALA.jl:294)
     // recorders (reset every round)
     double *swap_sum;  int64_t *swap_n;                    // [N-1] swap_acceptance_pr
     double *lsr_up;    double *lsr_dn;   int64_t *lsr_n;   // [N-1] log_sum_ratio (c,c+1) / (c+1,c)
@@ -342,6 +348,21 @@ __global__ __launch_bounds__(64) void k_explore_slice(EngineDev e, SliceParams s
 // of every DEO pair sit in adjacent lanes (t, t^1) of one wavefront: the pair's SwapStats are
 // exchanged with __shfl_xor and both lanes take the same decision.
 // ---------------------------------------------------------------------------------------------
+// log_unnormalized_ratio(log_potentials, partner, mine, state) (src/log_potentials/log_potentials.jl:43-51)
+// from the swap statistics the explorer left behind.  target 0: ScaledPrecisionNormalPath;
+// target 2: InterpolatedLogPotential with its beta == 0 / 1 short-circuits (InterpolatedLogPotential.jl:9-16).
+__device__ __forceinline__ double swap_log_ratio(const EngineDev &e, int slot, int64_t c, int64_t pc) {
+    const double S = e.suff[slot];
+    if (e.target == 2) {
+        const double ref = e.ref_nhp * S, tgt = e.suff2[slot];
+        const double bn = e.beta[pc], bd = e.beta[c];
+        const double num = bn == 0.0 ? ref : (bn == 1.0 ? tgt : (1.0 - bn) * ref + bn * tgt);
+        const double den = bd == 0.0 ? ref : (bd == 1.0 ? tgt : (1.0 - bd) * ref + bd * tgt);
+        return num - den;
+    }
+    return e.nhp[pc] * S - e.nhp[c] * S;
+}
+
 __device__ __forceinline__ double dev_logaddexp(double x, double y) {
     double delta = (x == y) ? 0.0 : fabs(x - y);
     double m = (x > y) ? x : y;
@@ -368,9 +389,7 @@ __global__ __launch_bounds__(256) void k_swap(EngineDev e, int even, int64_t sca
     if (valid) {
         slot = e.slot_of_chain[c];
         if (e.target != 1) {
-            // log_unnormalized_ratio(lps, partner, mine, state) (log_potentials.jl:43-51)
-            const double S = e.suff[slot];
-            lr = e.nhp[pc] * S - e.nhp[c] * S;
+            lr = swap_log_ratio(e, slot, c, pc);
             if (isnan(lr)) set_error(e, ERR_NAN_RATIO, (int)c, -1);
         }
         uint64_t seed = e.rng[2 * slot] + e.rng[2 * slot + 1];    // one rand(replica.rng) per replica
@@ -433,8 +452,7 @@ __global__ __launch_bounds__(256) void k_swap_stats(EngineDev e, int even, int64
     const int slot = e.slot_of_chain[cl];
     double lr = 0.0;
     if (e.target != 1) {
-        const double S = e.suff[slot];
-        lr = e.nhp[pc] * S - e.nhp[c] * S;
+        lr = swap_log_ratio(e, slot, c, pc);
         if (isnan(lr)) set_error(e, ERR_NAN_RATIO, (int)c, -1);
     }
     uint64_t seed = e.rng[2 * slot] + e.rng[2 * slot + 1];
@@ -491,7 +509,7 @@ __global__ __launch_bounds__(256) void k_swap_decide(EngineDev e, int even) {
     e.slot_of_chain_alt[new_cl] = slot;
 }
 
-// payload layout (8-byte words): [0..d) state, d: sum x^2, d+1,d+2: rng, d+3: replica id, d+4: round-trip state
+// payload layout (8-byte words): [0..d) state, d: sum x^2, d+1,d+2: rng, d+3: replica id, d+4: round-trip state, d+5: suff2
 __global__ __launch_bounds__(256) void k_boundary_export(EngineDev e, int side, double *buf) {
     const int slot = e.slot_of_chain[side == 0 ? 0 : e.K - 1];
     const double *xrow = e.x + (int64_t)slot * e.ld;
@@ -502,6 +520,7 @@ __global__ __launch_bounds__(256) void k_boundary_export(EngineDev e, int side, 
         w[0] = e.rng[2 * slot]; w[1] = e.rng[2 * slot + 1];
         w[2] = (unsigned long long)e.replica_id[slot];
         w[3] = (unsigned long long)e.rt_state[slot];
+        buf[e.d + 5] = e.suff2[slot];
     }
 }
 __global__ __launch_bounds__(256) void k_boundary_import(EngineDev e, int side, const double *buf) {
@@ -514,6 +533,7 @@ __global__ __launch_bounds__(256) void k_boundary_import(EngineDev e, int side, 
         e.rng[2 * slot] = w[0]; e.rng[2 * slot + 1] = w[1];
         e.replica_id[slot] = (int64_t)w[2];
         e.rt_state[slot] = (int64_t)w[3];
+        e.suff2[slot] = buf[e.d + 5];
     }
 }
 

@@ -8,7 +8,9 @@ pigeons.jl_amd/julia/PigeonsMI355X.jl.
 from ._lib import PteError, LIB_PATH
 from .engine import Engine
 from .pt import (Inputs, PT, pigeons, toy_mvn_target, ScaledPrecisionNormalPath, TestSwapper,
-                 SliceSampler, ToyExplorer, record_default, record_online,
+                 SliceSampler, ToyExplorer, AutoMALA, Funnel, ScaledPrecisionNormalLogPotential,
+                 IdentityPreconditioner, DiagonalPreconditioner, MixDiagonalPreconditioner,
+                 record_default, record_online,
                  log_sum_ratio, swap_acceptance_pr, round_trip, index_process, online,
                  timing_extrema, allocation_extrema, explorer_acceptance_pr, explorer_n_steps,
                  stepping_stone, stepping_stone_pair, n_round_trips, n_tempered_restarts,

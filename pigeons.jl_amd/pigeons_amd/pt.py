@@ -51,6 +51,21 @@ def analytic_cumulativebarrier(path):
 
 
 @dataclass
+class ScaledPrecisionNormalLogPotential:
+    """src/paths/ScaledPrecisionNormalPath.jl:14-20 (used as a `reference`)"""
+    precision: float = 1.0
+    dim: int = 1
+
+
+@dataclass
+class Funnel:
+    """Neal's funnel as a LogDensityProblems target (reference test/supporting/dimensional-analysis.jl:33-48):
+    z[1] ~ Normal(0, 3), z[i] ~ Normal(0, exp(z[1]/2)); initialization = zeros(dim).  Tempered through the
+    default InterpolatingPath(reference, target) (src/targets/target.jl:72-75)."""
+    dim: int = 2
+
+
+@dataclass
 class TestSwapper:
     """src/swap/pair_swapper.jl:100-149"""
     constant_swap_accept_pr: float = 1.0
@@ -70,6 +85,33 @@ class SliceSampler:
 @dataclass
 class ToyExplorer:
     """src/explorers/ToyExplorer.jl:5"""
+
+
+@dataclass
+class IdentityPreconditioner:
+    """src/explorers/Preconditioner.jl:14"""
+
+
+@dataclass
+class DiagonalPreconditioner:
+    """src/explorers/Preconditioner.jl:22"""
+
+
+@dataclass
+class MixDiagonalPreconditioner:
+    """src/explorers/Preconditioner.jl:43-52 (default proportions 1//3, 1//3)"""
+    p0: float = 1.0 / 3.0
+    p1: float = 1.0 / 3.0
+
+
+@dataclass
+class AutoMALA:
+    """src/explorers/AutoMALA.jl:29-68"""
+    base_n_refresh: int = 3
+    exponent_n_refresh: float = 0.35
+    step_size: float = 1.0
+    preconditioner: Any = field(default_factory=MixDiagonalPreconditioner)
+    estimated_target_std_deviations: Any = None
 
 
 def default_explorer(target):
@@ -143,6 +185,8 @@ class ReducedRecorders:
     index_process: Any = None           # int64 [replica][scan]
     explorer_acceptance_pr: Any = None  # (mean[N], n[N]) keyed by chain
     explorer_n_steps: Any = None        # (sum[N], n[N])
+    am_factors: Any = None              # (mean[N], n[N])       src/explorers/AutoMALA.jl:277
+    reversibility_rate: Any = None      # (mean[N], n[N])       src/explorers/AutoMALA.jl:294
     online: Any = None                  # (mean[d], var[d], n)
     timing_extrema: Any = None          # {"round": seconds}
 
@@ -195,6 +239,11 @@ class PT:
                       target_params=[target.precision0, target.precision1])
         elif isinstance(target, TestSwapper):
             kw.update(target=_lib.TARGET_TEST_SWAPPER, dim=1, target_params=[target.constant_swap_accept_pr])
+        elif isinstance(target, Funnel):
+            ref = inputs.reference
+            if not isinstance(ref, ScaledPrecisionNormalLogPotential) or ref.dim != target.dim:
+                raise NotImplementedError("the device funnel path needs reference=ScaledPrecisionNormalLogPotential(prec, dim)")
+            kw.update(target=_lib.TARGET_FUNNEL, dim=target.dim, target_params=[ref.precision])
         else:
             raise NotImplementedError(
                 "target %r has no device log-potential; use the reference CPU path (Pigeons.jl)" % (target,))
@@ -205,6 +254,12 @@ class PT:
         elif isinstance(explorer, SliceSampler):
             kw.update(explorer=_lib.EXPLORER_SLICE, slice_w=explorer.w, slice_p=explorer.p,
                       slice_n_passes=explorer.n_passes, slice_max_iter=explorer.max_iter)
+        elif isinstance(explorer, AutoMALA):
+            pc = explorer.preconditioner
+            kind = 0 if isinstance(pc, IdentityPreconditioner) else 1 if isinstance(pc, DiagonalPreconditioner) else 2
+            kw.update(explorer=_lib.EXPLORER_AUTOMALA, am_base_n_refresh=explorer.base_n_refresh,
+                      am_exponent_n_refresh=explorer.exponent_n_refresh, am_step_size=explorer.step_size,
+                      am_preconditioner=kind, am_p0=getattr(pc, "p0", 0.0), am_p1=getattr(pc, "p1", 0.0))
         else:
             raise NotImplementedError("explorer %r is not available on the device" % (explorer,))
         make = engine_factory or Engine
@@ -251,7 +306,9 @@ def reduce_recorders(pt, elapsed=None):
     eng = pt.replicas
     eng.reduce()
     am, an, ss, sn = eng.explorer_stats()
+    fm, fn, rm, rn = eng.automala_stats()
     r = ReducedRecorders(
+        am_factors=(fm, fn), reversibility_rate=(rm, rn),
         swap_acceptance_pr=eng.swap_acceptance(),
         log_sum_ratio=eng.log_sum_ratio(),
         round_trip=eng.round_trip(),
@@ -268,6 +325,7 @@ def adapt(pt, reduced):
     """src/pt/pigeons.jl:152-162 with adapt_tempering (src/tempering/NonReversiblePT.jl:52-66)."""
     temp = pt.shared.tempering
     pt.reduced_recorders = reduced
+    adapt_explorer(pt, reduced)
     if isinstance(pt.inputs.target, TestSwapper) or len(temp.schedule.grids) == 1:
         return pt
     mean, n = reduced.swap_acceptance_pr
@@ -278,6 +336,26 @@ def adapt(pt, reduced):
     pt.shared.tempering = NonReversiblePT(temp.path, new_sched, barriers)
     (pt.shards if pt.shards is not None else pt.replicas).set_schedule(new_sched.grids)   # discretize on the device
     return pt
+
+
+def adapt_explorer(pt, reduced):
+    """adapt_explorer(::AutoMALA, ...) (src/explorers/AutoMALA.jl:70-79, Preconditioner.jl:54-55)."""
+    ex = pt.shared.explorer
+    if not isinstance(ex, AutoMALA) or reduced.am_factors is None:
+        return
+    fm, fn = reduced.am_factors
+    present = np.asarray(fn) > 0
+    new_step = ex.step_size * float(np.mean(np.asarray(fm)[present])) if present.any() else ex.step_size
+    std = None
+    if not isinstance(ex.preconditioner, IdentityPreconditioner):
+        std = np.sqrt(np.asarray(reduced.online[1], dtype=np.float64))
+    pt.shared.explorer = AutoMALA(ex.base_n_refresh, ex.exponent_n_refresh, new_step, ex.preconditioner, std)
+    eng = pt.shards if pt.shards is not None else pt.replicas
+    if hasattr(eng, "engines"):
+        for e in eng.engines:
+            e.set_explorer_adaptation(new_step, std)
+    else:
+        pt.replicas.set_explorer_adaptation(new_step, std)
 
 
 def stepping_stone_pair(pt):

@@ -41,17 +41,21 @@ def combine_reduced(parts, N, d):
             t_idx = np.repeat(np.arange(T)[:, None], rep.shape[1], axis=1)
             ip[rep, t_idx] = ch
         assert ip.min() >= 0
+    fm = cat([p["automala"][0] for p in parts]); fn = cat([p["automala"][1] for p in parts])
+    rm = cat([p["automala"][2] for p in parts]); rn = cat([p["automala"][3] for p in parts])
     online = parts[-1]["online"]            # the last shard owns the target chain
     return ReducedRecorders(swap_acceptance_pr=(sw_m, sw_n), log_sum_ratio=(up, un, dn, dnn),
                             round_trip=(restarts, trips), index_process=ip,
                             explorer_acceptance_pr=(am, an), explorer_n_steps=(ss, sn), online=online,
+                            am_factors=(fm, fn), reversibility_rate=(rm, rn),
                             timing_extrema={"round": None})
 
 
 def local_reduced(eng):
     eng.reduce()
     return {"swap": eng.swap_acceptance(), "lsr": eng.log_sum_ratio(), "round_trip": eng.round_trip(),
-            "explorer": eng.explorer_stats(), "ip": eng.index_process_shard(), "online": eng.online()}
+            "explorer": eng.explorer_stats(), "ip": eng.index_process_shard(), "online": eng.online(),
+            "automala": eng.automala_stats() if hasattr(eng, "automala_stats") else tuple(np.zeros(eng.K) for _ in range(4))}
 
 
 class LoopbackShards:

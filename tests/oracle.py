@@ -104,6 +104,9 @@ def lib():
     L.po_cumulative_barrier.argtypes = [C.c_void_p, C.c_double]
     L.po_get_step_size.restype = C.c_double
     L.po_get_step_size.argtypes = [C.c_void_p]
+    L.po_get_target_std.restype = C.c_int64
+    L.po_get_target_std.argtypes = [C.c_void_p, dp]
+    L.po_set_explorer_adaptation.argtypes = [C.c_void_p, C.c_double, dp]
     i32p = C.POINTER(C.c_int32)
     L.po_shard_explore.restype = C.c_int
     L.po_shard_explore.argtypes = [C.c_void_p, C.c_int64]
@@ -274,6 +277,19 @@ class OraclePT:
 
     def step_size(self):
         return float(self.L.po_get_step_size(self.h))
+
+    def target_std(self):
+        out = np.zeros(max(self.d, 1))
+        n = self.L.po_get_target_std(self.h, _dp(out))
+        return out[:self.d] if n else None
+
+    def set_explorer_adaptation(self, step_size, target_std=None):
+        s = None if target_std is None else np.ascontiguousarray(target_std, dtype=np.float64)
+        self.L.po_set_explorer_adaptation(self.h, step_size, None if s is None else _dp(s))
+
+    def automala_stats(self):
+        sl = slice(getattr(self, "c0", 0), getattr(self, "c0", 0) + getattr(self, "K", self.N))
+        return tuple(a[sl] for a in self.am_stats())
 
 
 class OracleShard(OraclePT):

@@ -339,3 +339,111 @@ def test_dist_shard_two_ranks_device_payloads(P, tmp_path):
         assert p.returncode == 0, se[-3000:]
     res = json.loads(outs[0][0].strip().splitlines()[-1])
     assert res["ok"] and res["boundary_swaps"] > 0, res
+
+
+# ---------------------------------------------------------------------------------------------
+# AutoMALA: MVN path with the analytic gradient, and BASELINE config 3,
+# Neal's funnel through the linear InterpolatingPath from a normal reference.
+# Integer outputs exact; floats to 1e-6 relative (north star) -- the funnel evaluates exp/log on
+# ocml (device) vs glibc (oracle), <= 1 ulp apart per call.
+# ---------------------------------------------------------------------------------------------
+def _mk_am(P, N, d, rounds, target="mvn", seed=1, precond=None):
+    precond = precond or P.MixDiagonalPreconditioner()
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio]
+    kind = {"IdentityPreconditioner": 0, "DiagonalPreconditioner": 1, "MixDiagonalPreconditioner": 2}[type(precond).__name__]
+    if target == "mvn":
+        inp = P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=P.AutoMALA(preconditioner=precond),
+                       seed=seed, record=rec, show_report=False)
+        ref = O.OraclePT(n_chains=N, dim=d, seed=seed, explorer=O.EXPLORER_AUTOMALA, am_preconditioner=kind)
+    else:
+        inp = P.Inputs(target=P.Funnel(d), reference=P.ScaledPrecisionNormalLogPotential(1.0 / 9.0, d), n_chains=N,
+                       n_rounds=rounds, explorer=P.AutoMALA(preconditioner=precond), seed=seed, record=rec, show_report=False)
+        ref = O.OraclePT(n_chains=N, dim=d, seed=seed, explorer=O.EXPLORER_AUTOMALA, target=O.TARGET_FUNNEL, p0=1.0 / 9.0,
+                         am_preconditioner=kind)
+    return P.PT(inp), ref
+
+
+def _check_am_round(P, pt, ref, rtol):
+    assert P.next_round(pt)
+    red = P.run_one_round(pt)
+    P.adapt(pt, red)
+    ref.run_round()
+    assert np.array_equal(red.index_process, ref.index_process())
+    assert red.round_trip == ref.round_trip()
+    ss, sn = red.explorer_n_steps
+    amr, anr, ssr, snr = ref.explorer_stats()
+    assert np.array_equal(sn, snr) and np.array_equal(ss, ssr)         # leapfrog counts: integers
+    fm, fn = red.am_factors
+    rm, rn = red.reversibility_rate
+    fmr, fnr, rmr, rnr = ref.am_stats()
+    assert np.array_equal(fn, fnr) and np.array_equal(rn, rnr)
+    np.testing.assert_allclose(fm, fmr, rtol=1e-12)                      # means of exact powers of two
+    np.testing.assert_allclose(rm, rmr, rtol=1e-12)
+    am, an = red.explorer_acceptance_pr
+    assert np.array_equal(an, anr)
+    np.testing.assert_allclose(am, amr, rtol=rtol, atol=1e-300)
+    m, n = red.swap_acceptance_pr
+    mr, nr = ref.swap_pr()
+    assert np.array_equal(n, nr)
+    np.testing.assert_allclose(m, mr, rtol=rtol, atol=1e-300)
+    np.testing.assert_allclose(pt.shared.tempering.schedule.grids, ref.schedule(), rtol=rtol)
+    np.testing.assert_allclose(pt.shared.explorer.step_size, ref.step_size(), rtol=1e-12)
+    std = ref.target_std()
+    if std is not None:
+        np.testing.assert_allclose(pt.shared.explorer.estimated_target_std_deviations, std, rtol=1e-6, atol=1e-12)
+    x, chain, rng = pt.replicas.states()
+    xr, cr, rr = ref.states()
+    assert np.array_equal(chain, cr) and np.array_equal(rng, rr)
+    np.testing.assert_allclose(x, xr, rtol=rtol, atol=1e-9 * rtol / 1e-6)
+
+
+@pytest.mark.parametrize("N,d,rounds,seed", [(6, 10, 7, 1), (5, 64, 5, 2), (8, 128, 5, 1), (4, 200, 4, 3), (3, 1000, 3, 1)])
+def test_automala_mvn_parity(P, N, d, rounds, seed):
+    pt, ref = _mk_am(P, N, d, rounds, "mvn", seed)
+    for _ in range(rounds):
+        _check_am_round(P, pt, ref, rtol=1e-9)
+
+
+@pytest.mark.parametrize("precond", ["IdentityPreconditioner", "DiagonalPreconditioner"])
+def test_automala_other_preconditioners(P, precond):
+    pt, ref = _mk_am(P, 5, 20, 5, "mvn", 4, precond=getattr(P, precond)())
+    for _ in range(5):
+        _check_am_round(P, pt, ref, rtol=1e-9)
+
+
+@pytest.mark.parametrize("N,d,rounds,seed", [(8, 8, 7, 1), (8, 128, 5, 1), (6, 70, 5, 2)])
+def test_automala_funnel_parity(P, N, d, rounds, seed):
+    """BASELINE configs[2] family: Neal's funnel, AutoMALA (d=128 at a chain count the oracle finishes fast)."""
+    pt, ref = _mk_am(P, N, d, rounds, "funnel", seed)
+    for _ in range(rounds):
+        _check_am_round(P, pt, ref, rtol=1e-6)
+
+
+def test_automala_stepping_stone_kat(P):
+    """reference test/test_stepping_stone.jl:15-27 with AutoMALA(): |logZ error| < 0.2 at d=10, N=6, 12 rounds."""
+    pt = P.pigeons(target=P.toy_mvn_target(10), explorer=P.AutoMALA(), n_chains=6, n_rounds=12, show_report=False)
+    p = P.stepping_stone_pair(pt)
+    truth = P.analytic_lognormalization(P.toy_mvn_target(10))
+    assert abs(p[0] - truth) < 0.2 and abs(p[1] - truth) < 0.2
+
+
+def test_config3_funnel_full_size_properties(P):
+    """BASELINE configs[2]: funnel d=128, n_chains=1024, AutoMALA -- size-independent properties."""
+    N, d = 1024, 128
+    pt = P.PT(P.Inputs(target=P.Funnel(d), reference=P.ScaledPrecisionNormalLogPotential(1.0 / 9.0, d), n_chains=N, n_rounds=4,
+                       explorer=P.AutoMALA(), record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False))
+    for r in range(1, 5):
+        assert P.next_round(pt)
+        red = P.run_one_round(pt)
+        P.adapt(pt, red)
+        ip = red.index_process
+        assert np.array_equal(np.sort(ip, axis=0), np.tile(np.arange(N)[:, None], (1, 2 ** r)))
+        assert np.all(np.abs(np.diff(ip, axis=1)) <= 1)
+        fm, fn = red.am_factors
+        assert fn[0] == 0 and np.all(fn[1:] > 0)                       # chain 1 is refreshed i.i.d.
+        assert np.all(np.log2(fm[1:] * 1.0) < 8)
+        rm, rn = red.reversibility_rate
+        assert np.all((rm >= 0) & (rm <= 1))
+        assert pt.shared.explorer.step_size > 0
+    x, chain, rng = pt.replicas.states()
+    assert np.all(np.isfinite(x)) and np.array_equal(np.sort(chain), np.arange(N))
