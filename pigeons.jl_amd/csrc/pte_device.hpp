@@ -83,6 +83,22 @@ __device__ __forceinline__ double upper_tree_root_dyn(double bs, int nlu) {
     return readlane_f64(v, 0);
 }
 
+// ---- DPP wave reduction with the association of the fixed tree; result uniform -----------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_step(double v) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v = dpp_add_step<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]  : lanes l, l^1
+    v = dpp_add_step<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]  : l, l^2
+    v = dpp_add_step<0x141, 0xF>(v);    // row_half_mirror      : other group of 4 (uniform inside groups)
+    v = dpp_add_step<0x140, 0xF>(v);    // row_mirror           : other group of 8
+    v = dpp_add_step<0x142, 0xA>(v);    // row_bcast15 -> rows 1,3 (disabled rows add +0.0)
+    v = dpp_add_step<0x143, 0xC>(v);    // row_bcast31 -> rows 2,3
+    return readlane_f64(v, 63);
+}
 // ---- sequential (uniform) stream: used on slow paths and for single draws ---------------------
 struct SeqRng {
     uint64_t seed, gamma;   // uniform

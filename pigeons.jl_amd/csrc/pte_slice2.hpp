@@ -63,6 +63,20 @@ struct DrawBuf {
         fill(lane, s_we, s_ke);
         return v;
     }
+    // randexp(rng) when the caller has already ensured the draw is buffered (k more are wanted after it)
+    __device__ __forceinline__ double randexp_ensured(int k_after, int lane, const double *s_we, const unsigned long long *s_ke) {
+        if (__builtin_expect((exok >> p) & 1ull, 1)) {
+            double v = readlane_f64(ex, p);
+            p += 1;
+            return v;
+        }
+        SeqRng s{seed + (uint64_t)(p + 1) * gamma, gamma};
+        double v = randexp_from_raw(s, mix64(s.seed));
+        seed = s.seed;
+        fill(lane, s_we, s_ke);          // p = 0: a full buffer of 64 draws >= k_after
+        (void)k_after;
+        return v;
+    }
     __device__ __forceinline__ uint64_t final_seed() const { return seed + (uint64_t)p * gamma; }
 };
 
