@@ -43,13 +43,15 @@ extern "C" {
 enum {
     PTE_TARGET_MVN_SCALED_PRECISION = 0, /* toy_mvn_target: src/paths/ScaledPrecisionNormalPath.jl:5-48   */
     PTE_TARGET_TEST_SWAPPER         = 1, /* TestSwapper:    src/swap/pair_swapper.jl:100-149               */
-    PTE_TARGET_FUNNEL               = 2  /* InterpolatingPath(normal ref, Neal's funnel)                   */
+    PTE_TARGET_FUNNEL               = 2, /* InterpolatingPath(normal ref, Neal's funnel)                   */
+    PTE_TARGET_ISING                = 3  /* InterpolatingPath(Ising(0), Ising(beta)): examples/ising.jl        */
 };
 enum {
     PTE_EXPLORER_NONE     = 0,           /* `nothing` (TestSwapper)                                        */
     PTE_EXPLORER_TOY      = 1,           /* ToyExplorer:  src/explorers/ToyExplorer.jl:5-14                */
     PTE_EXPLORER_SLICE    = 2,           /* SliceSampler: src/explorers/SliceSampler.jl:8-237              */
-    PTE_EXPLORER_AUTOMALA = 3            /* AutoMALA:     src/explorers/AutoMALA.jl:29-294                 */
+    PTE_EXPLORER_AUTOMALA = 3,           /* AutoMALA:     src/explorers/AutoMALA.jl:29-294                 */
+    PTE_EXPLORER_ISING_METROPOLIS = 4    /* IsingMetropolis: examples/ising.jl:91-116 (n_steps in slice_n_passes) */
 };
 enum {                                   /* Inputs.record (src/pt/Inputs.jl:57-62)                         */
     PTE_RECORD_ROUND_TRIP    = 1u << 0,  /* round_trip     src/recorders/RoundTripRecorder.jl              */
@@ -71,7 +73,8 @@ typedef struct pte_config {
     uint64_t seed;               /* Inputs.seed                                                            */
     int64_t  max_scans_per_round;/* capacity of the index-process buffer, 2^n_rounds                       */
     double   target_params[4];   /* MVN: {precision0, precision1}; TestSwapper: {accept pr};
-                                    FUNNEL: {reference precision}                                          */
+                                    FUNNEL: {reference precision}; ISING: {beta}, dim = base_length^2,
+                                    state = 0/1 spins as f64, row-major matrix[i,j] -> state[i*L + j]           */
     /* SliceSampler fields (SliceSampler.jl:8-20) */
     double   slice_w;
     int32_t  slice_p;

@@ -316,6 +316,7 @@ typedef struct {
     po_rng   rng;
     po_recorders rec;
     int64_t  replica_index;  /* 0-based */
+    int64_t  aux;            /* Ising: cached sum_pair_products (IsingState, examples/ising.jl:18-22) */
     /* AutoMALA scratch (src/explorers/Augmentation.jl buffers) */
     double  *buf;
 } po_replica;
@@ -489,6 +490,59 @@ static int64_t partner_chain(int64_t N, int even, int64_t chain0) {
 }
 static inline int is_reference(int64_t N, int64_t chain0) { return chain0 == 0 && N > 1; }  /* DEO.jl:13 */
 static inline int is_target(int64_t N, int64_t chain0) { return chain0 == N - 1; }          /* DEO.jl:14 */
+
+
+/* ---- 2-D Ising model (reference examples/ising.jl) ------------------------------------------------
+ * state: L x L spins in {false,true} (stored as 0.0 / 1.0 in the replica's state vector, row-major:
+ * matrix[i,j] <-> state[(i-1)*L + (j-1)]), plus the cached sum_pair_products (r->aux).
+ * log potential at a chain: InterpolatedLogPotential between IsingLogPotential(0.0, L) (default_reference,
+ * ising.jl:77) and IsingLogPotential(beta, L) with the linear interpolator. */
+static inline int ising_L(const po_pt *pt) { int L = (int)llround(sqrt((double)pt->d)); return L; }
+static inline int ising_sign(double b) { return b != 0.0 ? +1 : -1; }
+static inline int ising_wrap(int i, int L) { return i < 0 ? L - 1 : (i >= L ? 0 : i); }        /* wrap(), ising.jl:61-69, 0-based */
+static inline int ising_sum_neighbours(const double *m, int L, int i, int j) {                /* ising.jl:57-60 */
+    return ising_sign(m[ising_wrap(i - 1, L) * L + j]) + ising_sign(m[ising_wrap(i + 1, L) * L + j]) +
+           ising_sign(m[i * L + ising_wrap(j - 1, L)]) + ising_sign(m[i * L + ising_wrap(j + 1, L)]);
+}
+static int64_t ising_recompute(const double *m, int L) {                                       /* ising.jl:27-35 */
+    int64_t sum = 0;
+    for (int i = 0; i < L; i++) for (int j = 0; j < L; j++) sum += ising_sign(m[i * L + j]) * ising_sum_neighbours(m, L, i, j);
+    return sum / 2;
+}
+static void ising_flip(po_replica *r, int L, int i, int j) {                                    /* flip!, ising.jl:38-46 */
+    double *m = r->state;
+    int before = ising_sign(m[i * L + j]) * ising_sum_neighbours(m, L, i, j);
+    m[i * L + j] = m[i * L + j] != 0.0 ? 0.0 : 1.0;
+    int after = ising_sign(m[i * L + j]) * ising_sum_neighbours(m, L, i, j);
+    r->aux += (int64_t)(after - before);
+}
+/* InterpolatedLogPotential(state): ref = 0.0 * spp, target = beta_ising * spp (ising.jl:74) */
+static double ising_lp(const po_pt *pt, int64_t chain, int64_t spp) {
+    const double beta = pt->betas[chain];
+    const double ref = 0.0 * (double)spp, tgt = pt->cfg.p0 * (double)spp;
+    if (beta == 0.0) return ref;
+    if (beta == 1.0) return tgt;
+    return (1.0 - beta) * ref + beta * tgt;
+}
+/* rand(rng, Bool) for a generic AbstractRNG: assumed rand(rng, UInt64) % Bool (low bit) -- UNPINNED */
+static inline int po_rand_bool(po_rng *r) { return (int)(po_rng_next_u64(r) & 1ULL); }
+static void ising_sample_iid(po_pt *pt, po_replica *r) {                                       /* iid_bernoulli!, ising.jl:49-58 */
+    const int L = ising_L(pt);
+    for (int i = 0; i < L; i++) for (int j = 0; j < L; j++) r->state[i * L + j] = po_rand_bool(&r->rng) ? 1.0 : 0.0;
+    r->aux = ising_recompute(r->state, L);
+}
+static void ising_step(po_pt *pt, po_replica *r) {                                             /* step!(::IsingMetropolis), ising.jl:96-116 */
+    const int L = ising_L(pt);
+    for (int k = 0; k < pt->cfg.slice_n_passes; k++)
+        for (int i = 0; i < L; i++)
+            for (int j = 0; j < L; j++) {
+                double before = ising_lp(pt, r->chain, r->aux);
+                ising_flip(r, L, i, j);
+                double after = ising_lp(pt, r->chain, r->aux);
+                double accept_ratio = exp(after - before);
+                if (accept_ratio < 1 && po_rand(&r->rng) > accept_ratio) ising_flip(r, L, i, j);
+            }
+}
 
 /* ========================================================================== */
 /* explorers                                                                  */
@@ -735,6 +789,11 @@ static int automala_step(po_pt *pt, po_replica *r) {
 static int explore_replica(po_pt *pt, po_replica *r) {
     const int64_t N = pt->N;
     if (pt->cfg.target == PO_TARGET_TEST_SWAPPER) return 0;   /* state nothing, step! no-op (pair_swapper.jl:137-143) */
+    if (pt->cfg.target == PO_TARGET_ISING) {
+        if (is_reference(N, r->chain)) ising_sample_iid(pt, r);
+        else ising_step(pt, r);
+        return 0;
+    }
     if (is_reference(N, r->chain)) {
         mvn_sample_iid(pt, r);
     } else {
@@ -768,8 +827,9 @@ static int swap_stat(po_pt *pt, po_replica *r, int64_t partner, swap_stat_t *out
         return 0;
     }
     /* log_unnormalized_ratio(lps, partner, my_chain, state), log_potentials.jl:43-51 */
-    double lp_num = lp_at_chain(pt, partner, r->state);
-    double lp_den = lp_at_chain(pt, r->chain, r->state);
+    double lp_num, lp_den;
+    if (pt->cfg.target == PO_TARGET_ISING) { lp_num = ising_lp(pt, partner, r->aux); lp_den = ising_lp(pt, r->chain, r->aux); }
+    else { lp_num = lp_at_chain(pt, partner, r->state); lp_den = lp_at_chain(pt, r->chain, r->state); }
     double ans = lp_num - lp_den;
     if (isnan(ans)) { fail(pt, "Got NaN log-unnormalized ratio"); return 1; }
     out->log_ratio = ans;
@@ -859,6 +919,7 @@ po_pt *po_create(const po_config *cfg) {
         r->buf = (double *)calloc((size_t)(8 * (d > 0 ? d : 1)), sizeof(double));
         rec_alloc(&r->rec, N, d);
         rec_empty(&r->rec, N, d);
+        if (cfg->target == PO_TARGET_ISING) r->aux = ising_recompute(r->state, (int)llround(sqrt((double)d)));   /* falses(L, L), ising.jl:85 */
         /* funnel: initialization = zeros(dim) (test/supporting/dimensional-analysis.jl:24) -- calloc above */
         if (cfg->target == PO_TARGET_MVN) {
             /* initialization, src/targets/toy_mvn_target.jl:10-11 */
@@ -1146,7 +1207,7 @@ int64_t po_shard_payload_words(const po_pt *pt) { return pt->d + 6; }
 void po_shard_export(po_pt *pt, int side, double *buf) {
     po_replica *r = &pt->replicas[pt->replica_of_chain[side == 0 ? 0 : pt->K - 1]];
     memcpy(buf, r->state, sizeof(double) * (size_t)pt->d);
-    buf[pt->d] = pt->d > 0 ? po_sqr_norm(r->state, pt->d) : 0.0;
+    buf[pt->d] = pt->cfg.target == PO_TARGET_ISING ? (double)r->aux : (pt->d > 0 ? po_sqr_norm(r->state, pt->d) : 0.0);
     uint64_t w[4] = { r->rng.seed, r->rng.gamma, (uint64_t)r->replica_index, (uint64_t)r->rec.rt.state };
     memcpy(buf + pt->d + 1, w, sizeof w);
 }
@@ -1156,6 +1217,7 @@ void po_shard_import(po_pt *pt, int side, const double *buf) {
     uint64_t w[4];
     memcpy(w, buf + pt->d + 1, sizeof w);
     r->rng.seed = w[0]; r->rng.gamma = w[1]; r->replica_index = (int64_t)w[2]; r->rec.rt.state = (int64_t)w[3];
+    if (pt->cfg.target == PO_TARGET_ISING) r->aux = (int64_t)buf[pt->d];
 }
 int po_shard_reduce(po_pt *pt) {
     const int64_t N = pt->N, d = pt->d;

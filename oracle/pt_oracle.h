@@ -43,8 +43,8 @@ double po_fc_eval(const double *x, const double *y, const double *m, const doubl
                   const double *dd, int64_t n, double t);
 
 /* ---- parallel tempering --------------------------------------------------- */
-enum { PO_TARGET_MVN = 0, PO_TARGET_TEST_SWAPPER = 1, PO_TARGET_FUNNEL = 2 };
-enum { PO_EXPLORER_NONE = 0, PO_EXPLORER_TOY = 1, PO_EXPLORER_SLICE = 2, PO_EXPLORER_AUTOMALA = 3 };
+enum { PO_TARGET_MVN = 0, PO_TARGET_TEST_SWAPPER = 1, PO_TARGET_FUNNEL = 2, PO_TARGET_ISING = 3 };
+enum { PO_EXPLORER_NONE = 0, PO_EXPLORER_TOY = 1, PO_EXPLORER_SLICE = 2, PO_EXPLORER_AUTOMALA = 3, PO_EXPLORER_ISING = 4 };
 
 typedef struct po_config {
     int64_t  n_chains;
@@ -53,7 +53,9 @@ typedef struct po_config {
     int32_t  target;            /* PO_TARGET_*                                     */
     int32_t  explorer;          /* PO_EXPLORER_*                                   */
     double   p0, p1;            /* MVN: precision0/1. TestSwapper: p0 = accept pr.
-                                   Funnel: p0 = precision of the normal reference  */
+                                   Funnel: p0 = precision of the normal reference.
+                                   Ising: p0 = beta of the target IsingLogPotential; dim = base_length^2,
+                                   states are 0/1 spins stored as doubles; slice_n_passes = n_steps of IsingMetropolis */
     /* SliceSampler (src/explorers/SliceSampler.jl:8-20) */
     double   slice_w;
     int32_t  slice_p, slice_n_passes, slice_max_iter;

@@ -18,6 +18,7 @@
 #include "pte_slice4.hpp"
 #include "pte_slice5.hpp"
 #include "pte_automala.hpp"
+#include "pte_ising.hpp"
 
 using namespace pte;
 
@@ -269,6 +270,13 @@ int launch_explore(pte_engine *h, int64_t scan) {
         time_end(h);
         break;
     }
+    case PTE_EXPLORER_ISING_METROPOLIS: {
+        IsingParams ip{(int)std::llround(std::sqrt((double)h->d)), h->cfg.slice_n_passes, h->cfg.target_params[0]};
+        time_begin(h, 0);
+        hipLaunchKernelGGL(k_explore_ising, dim3((unsigned)N), dim3(64), (size_t)h->d, h->stream, h->dev, ip);
+        time_end(h);
+        break;
+    }
     default: return fail(h, "explorer %d is not implemented on the device", h->cfg.explorer);
     }
     HIP_OK(h, hipGetLastError());
@@ -338,17 +346,23 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     if (cfg->n_chains % cfg->world_size != 0) return fail(nullptr, "pte_create: n_chains (%lld) must be a multiple of world_size (%d)", (long long)cfg->n_chains, cfg->world_size);
     const bool swapper = cfg->target == PTE_TARGET_TEST_SWAPPER;
     const bool funnel = cfg->target == PTE_TARGET_FUNNEL;
-    if (!swapper && !funnel && cfg->target != PTE_TARGET_MVN_SCALED_PRECISION)
+    const bool ising = cfg->target == PTE_TARGET_ISING;
+    if (ising) {
+        const int64_t L = (int64_t)std::llround(std::sqrt((double)cfg->dim));
+        if (L < 2 || L * L != cfg->dim || cfg->dim > 65536) return fail(nullptr, "pte_create: Ising needs dim = base_length^2 <= 65536");
+        if (cfg->explorer != PTE_EXPLORER_ISING_METROPOLIS) return fail(nullptr, "pte_create: the Ising path is explored by IsingMetropolis only");
+    } else if (cfg->explorer == PTE_EXPLORER_ISING_METROPOLIS) return fail(nullptr, "pte_create: IsingMetropolis needs the Ising target");
+    if (!swapper && !funnel && !ising && cfg->target != PTE_TARGET_MVN_SCALED_PRECISION)
         return fail(nullptr, "pte_create: target %d has no device log-potential; use the reference CPU path", cfg->target);
     if (funnel && cfg->explorer != PTE_EXPLORER_AUTOMALA)
         return fail(nullptr, "pte_create: the funnel path is implemented for AutoMALA only; use the reference CPU path");
     if (cfg->explorer == PTE_EXPLORER_AUTOMALA && (cfg->dim < 1 || cfg->dim > 1024))
         return fail(nullptr, "pte_create: AutoMALA keeps the replica in registers, dim must be in 1..1024 (got %lld)", (long long)cfg->dim);
-    if (!swapper && (cfg->dim < 1 || cfg->dim > 4096))
+    if (!swapper && !ising && (cfg->dim < 1 || cfg->dim > 4096))
         return fail(nullptr, "pte_create: dim must be in 1..4096 (got %lld)", (long long)cfg->dim);
     if (swapper && cfg->explorer != PTE_EXPLORER_NONE)
         return fail(nullptr, "pte_create: TestSwapper has no explorer");
-    if (!swapper && cfg->explorer != PTE_EXPLORER_TOY && cfg->explorer != PTE_EXPLORER_SLICE && cfg->explorer != PTE_EXPLORER_AUTOMALA)
+    if (!swapper && !ising && cfg->explorer != PTE_EXPLORER_TOY && cfg->explorer != PTE_EXPLORER_SLICE && cfg->explorer != PTE_EXPLORER_AUTOMALA)
         return fail(nullptr, "pte_create: explorer %d is not implemented on the device", cfg->explorer);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -409,6 +423,7 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     if (rc) return bail(1);
     e.nhp = h->d_nhp; e.sd = h->d_sd; e.nprec = h->d_nprec; e.beta = h->d_beta;
     e.ref_nhp = -0.5 * cfg->target_params[0];
+    e.ising_beta = cfg->target_params[0];
     h->step_size = cfg->am_step_size;
     // n_refresh = base_n_refresh * ceil(Int, dim^exponent_n_refresh)  (AutoMALA.jl:120)
     h->am_n_refresh = cfg->am_base_n_refresh * (int)std::ceil(std::pow((double)(d > 0 ? d : 1), cfg->am_exponent_n_refresh));
@@ -422,12 +437,20 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     if (upload_ladder(h)) return bail(1);
     if (reset_recorders(h)) return bail(1);
     const double init_sd = swapper ? 1.0 : std::sqrt(cfg->target_params[1]);   // toy_mvn_target.jl:10-11
-    DISPATCH_NLU(h->nlu, k_init, dim3((unsigned)K), dim3(64), h->stream, e, (uint64_t)cfg->seed, init_sd);
+    if (!ising) { DISPATCH_NLU(h->nlu, k_init, dim3((unsigned)K), dim3(64), h->stream, e, (uint64_t)cfg->seed, init_sd); }
+    else {
+        std::vector<int32_t> ch((size_t)K), sl((size_t)K); std::vector<int64_t> rid((size_t)K);
+        for (int64_t il = 0; il < K; ++il) { ch[il] = (int32_t)(h->c0 + il); sl[il] = (int32_t)il; rid[il] = h->c0 + il; }
+        hipMemcpyAsync(e.chain_of_slot, ch.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice, h->stream);
+        hipMemcpyAsync(e.slot_of_chain, sl.data(), sizeof(int32_t) * K, hipMemcpyHostToDevice, h->stream);
+        hipMemcpyAsync(e.replica_id, rid.data(), sizeof(int64_t) * K, hipMemcpyHostToDevice, h->stream);
+        hipStreamSynchronize(h->stream);
+    }
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
         h->err = "k_init launch failed"; return bail(1);
     }
-    if (funnel) {
-        // initialization(::LogDensity, rng, i) = zeros(dim) (test/supporting/dimensional-analysis.jl:24): the streams
+    if (funnel || ising) {
+        // funnel: initialization(::LogDensity, rng, i) = zeros(dim); Ising: falses(L, L) (examples/ising.jl:85) (test/supporting/dimensional-analysis.jl:24): the streams
         // stay untouched; suff2 = funnel(0) = d terms evaluated on the host exactly like the kernels' tree of equal terms
         std::vector<uint64_t> rngs((size_t)(2 * K));
         const uint64_t G = 0x9e3779b97f4a7c15ULL;
@@ -452,6 +475,11 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
         for (int64_t len = P; len > 1; len /= 2) for (int64_t i = 0; i < len / 2; ++i) a[i] = a[2 * i] + a[2 * i + 1];
         std::vector<double> s2((size_t)K, a[0]);
         hipMemcpyAsync(e.suff2, s2.data(), sizeof(double) * K, hipMemcpyHostToDevice, h->stream);
+        if (ising) {   // all spins -1: every site contributes (-1)(-4) = 4, halved: sum_pair_products = 2 L^2
+            std::vector<double> spp((size_t)K, 2.0 * (double)d);
+            hipMemcpyAsync(e.suff, spp.data(), sizeof(double) * K, hipMemcpyHostToDevice, h->stream);
+            if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "ising init failed"; return bail(1); }
+        }
         if (hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "funnel init failed"; return bail(1); }
     }
     *out = h;
@@ -760,7 +788,19 @@ int pte_set_state(pte_engine *h, const double *state, const int64_t *chain, cons
     }
     if (rng) HIP_OK(h, hipMemcpyAsync(h->dev.rng, rng, sizeof(uint64_t) * 2 * N, hipMemcpyHostToDevice, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
-    if (state && d > 0) {   // refresh the swap statistic of every slot
+    if (state && d > 0 && h->cfg.target == PTE_TARGET_ISING) {   // sum_pair_products of every slot (examples/ising.jl:27-35)
+        const int64_t L = (int64_t)std::llround(std::sqrt((double)d));
+        std::vector<double> spp((size_t)N);
+        for (int64_t r = 0; r < N; ++r) {
+            const double *m = state + r * d;
+            long long sum = 0;
+            auto sg = [&](int64_t i, int64_t j) { return m[((i + L) % L) * L + ((j + L) % L)] != 0.0 ? 1 : -1; };
+            for (int64_t i = 0; i < L; ++i) for (int64_t j = 0; j < L; ++j)
+                sum += sg(i, j) * (sg(i - 1, j) + sg(i + 1, j) + sg(i, j - 1) + sg(i, j + 1));
+            spp[r] = (double)(sum / 2);
+        }
+        HIP_OK(h, hipMemcpy(h->dev.suff, spp.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+    } else if (state && d > 0) {   // refresh the swap statistic of every slot
         std::vector<double> suff(N);
         std::vector<double> row(d);
         double *tmp = nullptr;

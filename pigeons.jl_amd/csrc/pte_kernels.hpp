@@ -37,6 +37,7 @@ struct EngineDev {
     const double *beta;        // [chain] Schedule.grids                     (interpolated paths)
     double *suff2;             // [slot]  second swap statistic: target log density (interpolated paths)
     double ref_nhp;            // -0.5 * precision of the normal reference of an interpolated path
+    double ising_beta;         // beta of the target IsingLogPotential
     double *am_fac_sum; int64_t *am_fac_n;     // [chain] am_factors          (AutoMALA.jl:277)
     double *am_rev_sum; int64_t *am_rev_n;     // [chain] reversibility_rate  (AutoMALA.jl:294)
     // recorders (reset every round)
@@ -355,6 +356,13 @@ __device__ __forceinline__ double swap_log_ratio(const EngineDev &e, int slot, i
     const double S = e.suff[slot];
     if (e.target == 2) {
         const double ref = e.ref_nhp * S, tgt = e.suff2[slot];
+        const double bn = e.beta[pc], bd = e.beta[c];
+        const double num = bn == 0.0 ? ref : (bn == 1.0 ? tgt : (1.0 - bn) * ref + bn * tgt);
+        const double den = bd == 0.0 ? ref : (bd == 1.0 ? tgt : (1.0 - bd) * ref + bd * tgt);
+        return num - den;
+    }
+    if (e.target == 3) {     // Ising: S holds sum_pair_products; ref = 0.0 * spp, target = beta_target * spp (examples/ising.jl:74)
+        const double ref = 0.0 * S, tgt = e.ising_beta * S;
         const double bn = e.beta[pc], bd = e.beta[c];
         const double num = bn == 0.0 ? ref : (bn == 1.0 ? tgt : (1.0 - bn) * ref + bn * tgt);
         const double den = bd == 0.0 ? ref : (bd == 1.0 ? tgt : (1.0 - bd) * ref + bd * tgt);

@@ -10,8 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)                       # .../pigeons.jl_amd
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libpte.so")
 
-TARGET_MVN_SCALED_PRECISION, TARGET_TEST_SWAPPER, TARGET_FUNNEL = 0, 1, 2
-EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA = 0, 1, 2, 3
+TARGET_MVN_SCALED_PRECISION, TARGET_TEST_SWAPPER, TARGET_FUNNEL, TARGET_ISING = 0, 1, 2, 3
+EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA, EXPLORER_ISING_METROPOLIS = 0, 1, 2, 3, 4
 RECORD_ROUND_TRIP, RECORD_INDEX_PROCESS, RECORD_ONLINE = 1, 2, 4
 ABI_VERSION = 1
 

@@ -66,6 +66,21 @@ class Funnel:
 
 
 @dataclass
+class IsingLogPotential:
+    """2-D Ising model, p(state) ∝ exp(beta * sum of neighbour products) (reference examples/ising.jl:6-9,74).
+    The reference distribution is IsingLogPotential(0.0, base_length) (ising.jl:77); states are
+    base_length x base_length spin matrices, exposed here as 0/1 vectors in row-major order."""
+    beta: float = 1.0
+    base_length: int = 5
+
+
+@dataclass
+class IsingMetropolis:
+    """examples/ising.jl:91-93"""
+    n_steps: int = 3
+
+
+@dataclass
 class TestSwapper:
     """src/swap/pair_swapper.jl:100-149"""
     constant_swap_accept_pr: float = 1.0
@@ -119,6 +134,8 @@ def default_explorer(target):
         return ToyExplorer()           # src/targets/toy_mvn_target.jl:13
     if isinstance(target, TestSwapper):
         return None                    # src/swap/pair_swapper.jl:139
+    if isinstance(target, IsingLogPotential):
+        return IsingMetropolis()       # examples/ising.jl:94
     return SliceSampler()              # src/targets/target.jl:20
 
 
@@ -239,6 +256,8 @@ class PT:
                       target_params=[target.precision0, target.precision1])
         elif isinstance(target, TestSwapper):
             kw.update(target=_lib.TARGET_TEST_SWAPPER, dim=1, target_params=[target.constant_swap_accept_pr])
+        elif isinstance(target, IsingLogPotential):
+            kw.update(target=_lib.TARGET_ISING, dim=target.base_length ** 2, target_params=[target.beta])
         elif isinstance(target, Funnel):
             ref = inputs.reference
             if not isinstance(ref, ScaledPrecisionNormalLogPotential) or ref.dim != target.dim:
@@ -254,6 +273,8 @@ class PT:
         elif isinstance(explorer, SliceSampler):
             kw.update(explorer=_lib.EXPLORER_SLICE, slice_w=explorer.w, slice_p=explorer.p,
                       slice_n_passes=explorer.n_passes, slice_max_iter=explorer.max_iter)
+        elif isinstance(explorer, IsingMetropolis):
+            kw.update(explorer=_lib.EXPLORER_ISING_METROPOLIS, slice_n_passes=explorer.n_steps)
         elif isinstance(explorer, AutoMALA):
             pc = explorer.preconditioner
             kind = 0 if isinstance(pc, IdentityPreconditioner) else 1 if isinstance(pc, DiagonalPreconditioner) else 2

@@ -12,8 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "_build", "libpt_oracle.so")
 
-TARGET_MVN, TARGET_TEST_SWAPPER, TARGET_FUNNEL = 0, 1, 2
-EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA = 0, 1, 2, 3
+TARGET_MVN, TARGET_TEST_SWAPPER, TARGET_FUNNEL, TARGET_ISING = 0, 1, 2, 3
+EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA, EXPLORER_ISING = 0, 1, 2, 3, 4
 
 
 class Config(C.Structure):

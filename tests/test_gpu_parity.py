@@ -447,3 +447,69 @@ def test_config3_funnel_full_size_properties(P):
         assert pt.shared.explorer.step_size > 0
     x, chain, rng = pt.replicas.states()
     assert np.all(np.isfinite(x)) and np.array_equal(np.sort(chain), np.arange(N))
+
+
+# ---------------------------------------------------------------------------------------------
+# 2-D Ising (BASELINE configs[4], reference examples/ising.jl): integer path.  Spins, chains, RNG
+# counters and the index process must be bit-exact; sum_pair_products is an integer.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L,N,rounds,beta,seed", [(5, 10, 7, 1.0, 1), (8, 6, 6, 0.6, 2), (16, 5, 5, 1.0, 3), (32, 4, 3, 0.44, 1)])
+def test_ising_parity(P, L, N, rounds, beta, seed):
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio]
+    pt = P.PT(P.Inputs(target=P.IsingLogPotential(beta, L), n_chains=N, n_rounds=rounds, seed=seed, record=rec, show_report=False))
+    ref = O.OraclePT(target=O.TARGET_ISING, explorer=O.EXPLORER_ISING, dim=L * L, p0=beta, n_chains=N, seed=seed, slice_n_passes=3)
+    for _ in range(rounds):
+        assert P.next_round(pt)
+        red = P.run_one_round(pt)
+        P.adapt(pt, red)
+        ref.run_round()
+        assert np.array_equal(red.index_process, ref.index_process())
+        assert red.round_trip == ref.round_trip()
+        m, n = red.swap_acceptance_pr
+        mr, nr = ref.swap_pr()
+        assert np.array_equal(n, nr)
+        np.testing.assert_allclose(m, mr, rtol=RTOL, atol=1e-300)
+        np.testing.assert_allclose(pt.shared.tempering.schedule.grids, ref.schedule(), rtol=RTOL)
+        np.testing.assert_allclose(P.stepping_stone_pair(pt), ref.stepping_stone_pair(), rtol=RTOL)
+        x, chain, rng = pt.replicas.states()
+        xr, cr, rr = ref.states()
+        assert np.array_equal(x, xr) and np.array_equal(chain, cr) and np.array_equal(rng, rr)
+
+
+def test_ising_sharded_equals_single(P):
+    mk = lambda: P.Inputs(target=P.IsingLogPotential(1.0, 8), n_chains=8, n_rounds=5, show_report=False,
+                          record=[P.round_trip, P.index_process, P.log_sum_ratio])
+    one, many = P.PT(mk()), P.PT(mk(), n_shards=4)
+    for _ in range(5):
+        P.next_round(one); P.next_round(many)
+        ra = P.run_one_round(one); P.adapt(one, ra)
+        rb = P.run_one_round(many); P.adapt(many, rb)
+        assert np.array_equal(ra.index_process, rb.index_process) and ra.round_trip == rb.round_trip
+    xa, ca, ga = one.replicas.states()
+    xb, cb, gb = many.shards.states()
+    assert np.array_equal(xa, xb) and np.array_equal(ca, cb) and np.array_equal(ga, gb)
+    assert many.shards.n_boundary_swaps > 0
+
+
+def test_ising_ground_state_and_logz(P):
+    """5x5 periodic lattice at beta = 1: the target chain freezes into a ground state and
+    log(Z1/Z0) ~ log(2 e^50 / 2^25) = 33.36 (50 bonds)."""
+    pt = P.pigeons(target=P.IsingLogPotential(1.0, 5), n_chains=10, n_rounds=10, show_report=False)
+    assert abs(P.stepping_stone(pt) - (50 + math.log(2) - 25 * math.log(2))) < 0.5
+
+
+def test_config5_ising_full_size_properties(P):
+    """BASELINE configs[4] shape per GPU: 256 x 256 spins (a few chains; the sweep is sequential per replica)."""
+    L, N = 256, 16
+    pt = P.PT(P.Inputs(target=P.IsingLogPotential(1.0, L), n_chains=N, n_rounds=2, show_report=False,
+                       record=[P.round_trip, P.index_process, P.log_sum_ratio]))
+    for r in range(1, 3):
+        assert P.next_round(pt)
+        red = P.run_one_round(pt)
+        P.adapt(pt, red)
+        assert np.array_equal(np.sort(red.index_process, axis=0), np.tile(np.arange(N)[:, None], (1, 2 ** r)))
+    x, chain, rng = pt.replicas.states()
+    assert set(np.unique(x)) <= {0.0, 1.0} and np.array_equal(np.sort(chain), np.arange(N))
+    # magnetisation grows with beta: hot chains are disordered, the target chain is mostly aligned after a few sweeps
+    mag = np.abs(2 * x.mean(axis=1) - 1)[np.argsort(chain)]
+    assert mag[0] < 0.05 and mag[-1] > mag[0]
