@@ -127,6 +127,14 @@ def main():
     bytes_per_replica = 16 * d + 32 if args.explorer == "slice" else 8 * d + 32
     alg_bytes = bytes_per_replica * n_chains
     ex_avg_ms = ex_ms / max(ex_n, 1)
+    kernel_name = {"slice": "k_explore_slice5", "toy": "k_explore_toy"}[args.explorer]
+    traffic = None
+    try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this kernel at this workload
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(kernel_name)
+        if tj and d == 1024 and n_chains == 1024:
+            traffic = tj["fetch_bytes"] + tj["write_bytes"]
+    except Exception:
+        traffic = None
     achieved = alg_bytes / (ex_avg_ms * 1e-3) / 1e9 if ex_avg_ms > 0 else 0.0
     out = {
         "metric": "replica-steps/sec (explore+swap), toy_mvn d=%d, n_chains=%d; round-trip rate" % (d, total_chains),
@@ -139,9 +147,9 @@ def main():
                    "boundary_swaps_rank0": getattr(runner, "n_boundary_swaps", 0)},
         "round_trip_rate": trips / K, "n_round_trips": trips, "n_tempered_restarts": restarts,
         "lp_evals_per_replica_step": float(np.sum(ss_sum) / max(K * (total_chains - 1), 1)) + 2.0 * 3 * d if args.explorer == "slice" else 0.0,
-        "roofline": {"bound": "hbm", "kernel": "k_explore_slice2" if args.explorer == "slice" else "k_explore_toy",
+        "roofline": {"bound": "hbm", "kernel": kernel_name,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "avg_launch_ms": ex_avg_ms, "launches": ex_n,
+                     "traffic": traffic, "avg_launch_ms": ex_avg_ms, "launches": ex_n,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "swap_kernel_avg_launch_ms": sw_ms / max(sw_n, 1),
                      "note": "SliceSampler is bound by a sequential FP64 dependency chain per replica "

@@ -11,7 +11,7 @@ def main():
         print("== %s" % path)
         try:
             rows = con.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
-            print("%-72s %8s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+            print("%-72s %8s %14s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
             for r in rows:
                 print("%-72s %8d %14.0f %12.0f %7.2f" % (r[0][:72], r[1], r[2], r[3], r[4]))
         except sqlite3.Error as e:
