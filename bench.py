@@ -22,7 +22,7 @@ for p in (ROOT, os.path.join(ROOT, "pigeons.jl_amd"), os.path.join(ROOT, "tests"
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def cpu_baseline(d, cores, sample_chains=256, sample_scans=2):
+def cpu_baseline(d, cores, sample_chains=1024, sample_scans=2):
     """Restated CPU baseline (NOT Pigeons.jl): the oracle's full-recompute SliceSampler, OpenMP
     static schedule over replicas (mirrors @threads, reference src/pt/pigeons.jl:82-85), on a
     bounded sample of the same workload."""
@@ -30,6 +30,7 @@ def cpu_baseline(d, cores, sample_chains=256, sample_scans=2):
     pt = O.OraclePT(n_chains=sample_chains, dim=d, explorer=O.EXPLORER_SLICE, n_threads=cores,
                     record_index_process=0)
     pt.begin_round()
+    pt.run_scans(1)                       # untimed: spins up the OpenMP team, first-touch of the replica buffers
     t0 = time.perf_counter()
     pt.run_scans(sample_scans)
     dt = time.perf_counter() - t0

@@ -17,6 +17,7 @@
 #include "pte_slice3.hpp"
 #include "pte_slice4.hpp"
 #include "pte_slice5.hpp"
+#include "pte_slice6.hpp"
 #include "pte_automala.hpp"
 #include "pte_ising.hpp"
 
@@ -225,6 +226,12 @@ int launch_explore(pte_engine *h, int64_t scan) {
             DISPATCH_NLU(h->nlu, k_explore_slice, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_impl == 3) {
             DISPATCH_NLU(h->nlu, k_explore_slice3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
+        } else if (h->slice_impl == 6 && h->slice_m == 3) {
+            DISPATCH_NLU_M(h->nlu, k_explore_slice6, 3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
+        } else if (h->slice_impl == 6 && h->slice_m == 5) {
+            DISPATCH_NLU_M(h->nlu, k_explore_slice6, 5, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
+        } else if (h->slice_impl == 6) {
+            DISPATCH_NLU_M(h->nlu, k_explore_slice6, 4, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_impl == 5 && h->slice_m == 3) {
             DISPATCH_NLU_M(h->nlu, k_explore_slice5, 3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_impl == 5 && h->slice_m == 6) {

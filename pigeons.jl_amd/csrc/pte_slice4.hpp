@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64) void k_explore_slice4(EngineDev e, SliceParams 
 #ifdef PTE_PROFILE_SECTIONS
     // cycles: [0] head (draws, L/R) [1] batches [2] scalar fallback [3] tail; counts: [4] coords, [5] fallback coords, [6] batches, [7] block setup cycles
     long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define PROF_T(v) const long long v = (long long)__builtin_readcyclecounter()
+#define PROF_T(v) __builtin_amdgcn_sched_barrier(0); const long long v = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
 #define PROF_ADD(i, x) prof[i] += (x)
 #else
 #define PROF_T(v)

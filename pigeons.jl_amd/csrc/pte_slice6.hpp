@@ -1,4 +1,4 @@
-// pte_slice5.hpp -- k_explore_slice5: SliceSampler kernel with tree-free filtered predicates.
+// pte_slice6.hpp -- k_explore_slice6: slice5 + lane-parallel doubling and acceptance check.
 //
 // Bit-identical decisions, draws and states to k_explore_slice (v1) and the oracle, but no
 // log-density evaluation on the sequential path at all.  For the scaled-precision MVN path
@@ -17,15 +17,22 @@
 // recomputed from the register-resident block and the block sums.  The exact tree root is also
 // re-established at every block boundary and written out as the swap statistic.
 //
+// slice6: when an end point lies inside the slice (10-31 % of coordinates) the doubling steps are
+// generated speculatively from the draws (they do not depend on densities), their end points are
+// tested by the lanes in one shot and the stopping step is found with scalar bit logic; the following
+// shrinkage batches run Neal's acceptance check of the doubling scheme per lane (each lane bisects
+// for its own proposal with the O(1) predicate).  Anything unusual (sliver, degenerate bracket, more
+// than J doublings) restores the coordinate's counters and takes the scalar procedure.
+//
 // Per coordinate the wave therefore runs: 3 draws read from the pre-converted buffer, the
 // threshold, and batches of M shrinkage proposals evaluated by M lanes (as slice2/slice4).
 #pragma once
-#include "pte_slice4.hpp"
+#include "pte_slice5.hpp"
 
 namespace pte {
 
 template <int NLU, int M>
-__global__ __launch_bounds__(64) void k_explore_slice5(EngineDev e, SliceParams sp) {
+__global__ __launch_bounds__(64) void k_explore_slice6(EngineDev e, SliceParams sp) {
     __shared__ double s_we[256];
     __shared__ unsigned long long s_ke[256];
     const int lane = lane_id();
@@ -67,7 +74,6 @@ __global__ __launch_bounds__(64) void k_explore_slice5(EngineDev e, SliceParams 
     int err = 0, err_coord = -1;
 #ifdef PTE_PROFILE_SECTIONS
     long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long prof2 = 0;
 #endif
 
     for (int pass = 0; pass < sp.n_passes && !err; ++pass) {
@@ -114,10 +120,10 @@ __global__ __launch_bounds__(64) void k_explore_slice5(EngineDev e, SliceParams 
                 double xf = xold;
                 bool done = false, first = true;
                 int n_base = 0;
+                uint64_t ins0 = 0;
                 PROF_T(t1); PROF_ADD(0, t1 - t0); PROF_ADD(4, 1);
                 while (true) {
                     PROF_ADD(6, 1);
-                    PROF_T(s0);
                     const double Lb0 = Lb, Rb0 = Rb;
                     double u[M];
 #pragma unroll
@@ -130,22 +136,20 @@ __global__ __launch_bounds__(64) void k_explore_slice5(EngineDev e, SliceParams 
                         Lb = bitsel(below, v, Lb);
                         Rb = bitsel(below, Rb, v);
                     }
-#ifdef PTE_PROFILE_SECTIONS
-                    asm volatile("" :: "v"(cand), "v"(Lb), "v"(Rb));
-#endif
-                    PROF_T(s1); PROF_ADD(7, s1 - s0);
                     const double q = cand * cand;
                     const uint64_t ins = ballot64(q < Qlo);
                     const uint64_t outs = ballot64(q > Qhi);
                     const uint64_t live = first ? ((1ull << (M + 2)) - 1ull) : (((1ull << M) - 1ull) << 2);
                     const bool amb = (~(ins | outs) & live) != 0ull;
                     const bool risk = ballot64(!((Rb - Lb) > thr)) != 0ull;
-#ifdef PTE_PROFILE_SECTIONS
-                    asm volatile("" :: "s"(ins), "s"(outs), "s"((int)amb), "s"((int)risk));
-                    PROF_T(s2); prof2 += s2 - s1;
-#endif
                     if (first) {
-                        if (__builtin_expect((ins & 3ull) != 0ull || risk || amb, 0)) break;
+                        if (__builtin_expect((ins & 3ull) != 0ull || risk || amb, 0)) {
+                            ins0 = (amb || risk) ? 0ull : (ins & 3ull);
+#ifdef PTE_DEBUG_V6
+                            if (lane == 0 && cl == 1 && b == 0) printf("break l=%d ins=%llx outs=%llx amb=%d risk=%d ins0=%llu\n", l, (unsigned long long)ins, (unsigned long long)outs, (int)amb, (int)risk, (unsigned long long)ins0);
+#endif
+                            break;
+                        }
                         steps_n += 1;
                     } else if (__builtin_expect(risk || amb, 0)) {
                         Lb = Lb0; Rb = Rb0;
@@ -166,6 +170,115 @@ __global__ __launch_bounds__(64) void k_explore_slice5(EngineDev e, SliceParams 
                     first = false;
                     if (__builtin_expect(n_base + M > sp.max_iter, 0)) break;
                     dr.ensure(M, lane, s_we, s_ke);
+                }
+                if (!done && first && ins0 != 0ull) {
+                    // ---- lane-parallel doubling (slice_double, SliceSampler.jl:109-121) + shrinkage with slice_accept
+                    constexpr int J = 4;
+                    const long long steps_sum0 = steps_sum; const int steps_n0 = steps_n, acc_sum0 = acc_sum, acc_n0 = acc_n;
+                    bool bail = false;
+                    dr.ensure(J + M, lane, s_we, s_ke);
+                    const int p_dbl = dr.p;                  // == logical position after u0 (ensure keeps the stream position)
+                    const uint64_t seed_dbl = dr.seed;
+                    double Lc = L, Rc = R, cd = 0.0;
+                    unsigned sidemask = 0;
+#pragma unroll
+                    for (int j = 0; j < J; ++j) {
+                        const double V = readlane_f64(dr.unit, p_dbl + j);
+                        const bool sideL = V <= 0.5;
+                        const double W = Rc - Lc;
+                        const double Ln = Lc - W, Rn = Rc + W;
+                        const double en = sideL ? Ln : Rn;
+                        Lc = sideL ? Ln : Lc;
+                        Rc = sideL ? Rc : Rn;
+                        cd = (lane == j) ? en : cd;
+                        sidemask |= (sideL ? 1u : 0u) << j;
+                    }
+                    const double qd = cd * cd;
+                    const uint64_t insD = ballot64(qd < Qlo), outD = ballot64(qd > Qhi);
+                    if ((~(insD | outD) & ((1ull << J) - 1ull)) != 0ull) bail = true;
+                    int jstar = 0;
+                    {
+                        bool inL = (ins0 & 1ull) != 0ull, inR = (ins0 & 2ull) != 0ull;
+#pragma unroll
+                        for (int j = 0; j < J; ++j) {
+                            if (jstar == 0) {
+                                const bool inj = ((insD >> j) & 1ull) != 0ull;
+                                if ((sidemask >> j) & 1u) inL = inj; else inR = inj;
+                                if (!(inL || inR)) jstar = j + 1;
+                            }
+                        }
+                    }
+                    if (jstar == 0) bail = true;             // more than J doublings: scalar procedure
+                    double LL = L, RR = R;
+                    if (!bail) {
+                        const unsigned below = (1u << jstar) - 1u;
+                        const unsigned mL = sidemask & below, mR = ~sidemask & below;
+                        if (mL) LL = readlane_f64(cd, 31 - __builtin_clz(mL));
+                        if (mR) RR = readlane_f64(cd, 31 - __builtin_clz(mR));
+                        dr.p = p_dbl + jstar;
+                        steps_sum += jstar; steps_n += 1;     // explorer_n_steps += p - K
+                        // shrinkage batches; every lane runs slice_accept (:192-237) for its own proposal
+                        const double thr3 = 1e-6 * fmax(fabs(LL), fabs(RR));
+                        Lb = LL; Rb = RR; n_base = 0;
+                        while (!bail && !done) {
+                            dr.ensure(M, lane, s_we, s_ke);
+                            double u[M];
+#pragma unroll
+                            for (int n = 0; n < M; ++n) u[n] = readlane_f64(dr.unit, dr.p + n);
+#pragma unroll
+                            for (int n = 0; n < M; ++n) {
+                                const double v = Lb + u[n] * (Rb - Lb);
+                                cand = bitsel(lm[n + 2], v, cand);
+                                const int below2 = neg_mask(v - xold);
+                                Lb = bitsel(below2, v, Lb);
+                                Rb = bitsel(below2, Rb, v);
+                            }
+                            const double q3 = cand * cand;
+                            const bool my = lane >= 2 && lane < M + 2;
+                            const bool in3 = my && q3 < Qlo, out3 = q3 > Qhi;
+                            bool ambl = my && !(in3 || out3);
+                            bool ok = true;
+                            if (in3) {
+                                double Lhat = LL, Rhat = RR;
+                                bool oL = true, oR = true, Rst = false, Lst = false, D = false;   // both end points are outside after doubling
+                                while (Rhat - Lhat > w11) {
+                                    const double Mid = (Lhat + Rhat) / 2.0;
+                                    if ((xold < Mid && cand >= Mid) || (xold >= Mid && cand < Mid)) D = true;
+                                    if (cand < Mid) { Rhat = Mid; Rst = true; } else { Lhat = Mid; Lst = true; }
+                                    if (D) {
+                                        if (Lst) { const double qq = Lhat * Lhat; const bool i2 = qq < Qlo; if (!(i2 || qq > Qhi)) ambl = true; oL = !i2; Lst = false; }
+                                        if (Rst) { const double qq = Rhat * Rhat; const bool i2 = qq < Qlo; if (!(i2 || qq > Qhi)) ambl = true; oR = !i2; Rst = false; }
+                                        if (oL && oR) { ok = false; break; }
+                                    }
+                                }
+                            }
+                            const bool risk3 = ballot64(!((Rb - Lb) > thr3)) != 0ull;
+                            if (ballot64(ambl) != 0ull || risk3) { bail = true; break; }
+                            const uint64_t insm = (ballot64(in3) >> 2) & ((1ull << M) - 1ull);
+                            const uint64_t passm = (ballot64(in3 && ok) >> 2) & ((1ull << M) - 1ull);
+                            if (passm != 0ull) {
+                                const int n = (int)__builtin_ctzll(passm);
+                                xf = readlane_f64(cand, n + 2);
+                                dr.p += n + 1;
+                                steps_sum += n_base + n + 1; steps_n += 1;
+                                acc_n += __builtin_popcountll(insm & ((2ull << n) - 1ull));   // one slice_accept call per proposal inside the slice
+                                acc_sum += 1;
+                                done = true;
+                            } else {
+                                acc_n += __builtin_popcountll(insm);
+                                dr.p += M;
+                                n_base += M;
+                                if (n_base + M > sp.max_iter) bail = true;
+                            }
+                        }
+                    }
+                    if (bail) {       // restore and let the scalar procedure redo this coordinate from the u0 draw
+                        done = false;
+                        if (dr.seed != seed_dbl) { dr.seed = seed_dbl; dr.fill(lane, s_we, s_ke); }   // a refill happened in between
+                        dr.p = p_dbl;
+                        steps_sum = steps_sum0; steps_n = steps_n0; acc_sum = acc_sum0; acc_n = acc_n0;
+                        Lb = L; Rb = R; n_base = 0; first = true; xf = xold;
+                    }
                 }
                 PROF_T(t2); PROF_ADD(1, t2 - t1);
                 if (__builtin_expect(!done, 0)) {
@@ -253,7 +366,6 @@ __global__ __launch_bounds__(64) void k_explore_slice5(EngineDev e, SliceParams 
         e.expl_acc_sum[cl] += (double)acc_sum;     e.expl_acc_n[cl] += acc_n;
 #ifdef PTE_PROFILE_SECTIONS
         for (int i = 0; i < 8; ++i) e.on_m2[8 * cl + i] += (double)prof[i];   // debug builds only (needs d >= 8K)
-        e.on_m2[8 * cl + 3] = (double)prof2;   // (overwrites the tail column in this debug build)
 #endif
     }
     if (c == e.N - 1 && (e.record_flags & 4u)) { __threadfence_block(); record_online(e, slot, lane); }

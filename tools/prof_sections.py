@@ -7,6 +7,7 @@ lib = os.path.join(ROOT, "gpurun_out", "libpte_prof.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                 "-Wno-unused-value", "-DPTE_PROFILE_SECTIONS", "-o", lib, os.path.join(ROOT, "pigeons.jl_amd/csrc/pte.hip")], check=True)
+os.environ.setdefault("PTE_SLICE_IMPL", "5")
 from pigeons_amd import _lib
 _lib.LIB_PATH = lib
 import numpy as np
@@ -24,5 +25,5 @@ for ch in (1, 32, 64, 127):
     c = cnt[ch]
     tot = c[0] + c[1] + c[2] + c[3] + c[7]
     print("chain %3d: total %.2fM cycles/replica-step | " % (ch, tot / 1e6) + "  ".join("%s %.0f" % (nm, x) for nm, x in zip(names, c)))
-    print("   per coordinate: head %.0f  batches %.0f (%.2f batches, %.0f cyc/batch)  fallback %.0f (%.1f%% coords, %.0f cyc each)  tail %.0f"
-          % (c[0] / c[4], c[1] / c[4], c[6] / c[4], c[1] / c[6], c[2] / c[4], 100 * c[5] / c[4], c[2] / max(c[5], 1), c[3] / c[4]))
+    print("   per coordinate: head %.0f  batches %.0f (%.2f batches, %.0f cyc/batch)  fallback %.0f (%.1f%% coords, %.0f cyc each)  tail %.0f | proposal chain per batch %.0f, tests+ballots per batch %.0f"
+          % (c[0] / c[4], c[1] / c[4], c[6] / c[4], c[1] / c[6], c[2] / c[4], 100 * c[5] / c[4], c[2] / max(c[5], 1), c[3] / c[4], c[7] / c[6], c[3] / c[6]))
