@@ -122,7 +122,136 @@ __global__ __launch_bounds__(64) void k_explore_ising(EngineDev e, IsingParams i
     }
     __syncthreads();
     for (int s = lane; s < d; s += 64) xrow[s] = spins[s] ? 1.0 : 0.0;
+#ifdef PTE_DEBUG_ISING
+    if (lane == 0) printf("bytes c=%d spp=%lld\n", (int)c, spp);
+#endif
     if (lane == 0) { e.suff[slot] = (double)spp; e.rng[2 * slot] = seed + (uint64_t)p * gamma; }
+}
+
+}  // namespace pte
+
+namespace pte {
+
+// ---------------------------------------------------------------------------------------------
+// k_explore_ising_bits: same sweep for base_length % 32 == 0 with the lattice bit-packed in LDS
+// (L*L/8 bytes) and the current / upper / lower words of the row held in scalar registers: the
+// per-site work is ~25 scalar integer instructions; the uniform is compared against the guard-banded
+// thresholds in the integer domain (bit patterns of positive doubles are ordered like the doubles).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lds_word(const unsigned *w, int i) { return (unsigned)__builtin_amdgcn_readfirstlane((int)w[i]); }
+
+__global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingParams ip) {
+    extern __shared__ unsigned words[];
+    const int lane = lane_id();
+    const int64_t cl = blockIdx.x;
+    if (cl >= e.K) return;
+    const int64_t c = e.c0 + cl;
+    const int slot = e.slot_of_chain[cl];
+    const int L = ip.L, d = L * L, W = L >> 5, NW = d >> 5;
+    double *xrow = e.x + (int64_t)slot * e.ld;
+    uint64_t seed = e.rng[2 * slot];
+    const uint64_t gamma = e.rng[2 * slot + 1];
+
+    if (c == 0 && e.N > 1) {
+        for (int wd = lane; wd < NW; wd += 64) {
+            unsigned v = 0;
+            for (int t = 0; t < 32; ++t) v |= (unsigned)(mix64(seed + (uint64_t)(32 * wd + t + 1) * gamma) & 1ull) << t;
+            words[wd] = v;
+        }
+        seed += (uint64_t)d * gamma;
+    } else {
+        for (int wd = lane; wd < NW; wd += 64) {
+            unsigned v = 0;
+            for (int t = 0; t < 32; ++t) v |= (xrow[32 * wd + t] != 0.0 ? 1u : 0u) << t;
+            words[wd] = v;
+        }
+    }
+    __syncthreads();
+    long long spp;
+    if (c == 0 && e.N > 1) {
+        // recompute_sum_pair_products: every bond once = sum over sites of (right + down neighbour products)
+        long long acc = 0;
+        for (int wd = lane; wd < NW; wd += 64) {
+            const int i = wd / W, wj = wd - i * W;
+            const unsigned cur = words[wd], dn = words[(i == L - 1 ? 0 : i + 1) * W + wj];
+            const unsigned nxt = words[i * W + (wj == W - 1 ? 0 : wj + 1)];
+            const unsigned right = (cur >> 1) | (nxt << 31);
+            acc += 64 - 2 * ((int)__popc(cur ^ right) + (int)__popc(cur ^ dn));     // +1 per equal pair, -1 per unequal pair
+        }
+        for (int k = 1; k < 64; k <<= 1) acc += __shfl_xor(acc, k, 64);
+        spp = acc;
+    } else {
+        spp = (long long)e.suff[slot];
+        const double beta = e.beta[c], bt = ip.beta_target;
+        const double bb = beta * bt;
+        const double r4 = exp(-4.0 * bb), r8 = exp(-8.0 * bb);
+        // guard-banded thresholds as integer bit patterns held in scalar registers
+        auto hi32 = [](double v) { return (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(v)); };
+        auto lo32 = [](double v) { return (unsigned)__builtin_amdgcn_readfirstlane(__double2loint(v)); };
+        const double r4l = r4 * (1.0 - 1e-9), r4h = r4 * (1.0 + 1e-9), r8l = r8 * (1.0 - 1e-9), r8h = r8 * (1.0 + 1e-9);
+        const unsigned r4lo_h = hi32(r4l), r4hi_h = hi32(r4h), r8lo_h = hi32(r8l), r8hi_h = hi32(r8h);
+        const unsigned long long r4lo = ((unsigned long long)r4lo_h << 32) | lo32(r4l), r4hi = ((unsigned long long)r4hi_h << 32) | lo32(r4h);
+        const unsigned long long r8lo = ((unsigned long long)r8lo_h << 32) | lo32(r8l), r8hi = ((unsigned long long)r8hi_h << 32) | lo32(r8h);
+        const bool filter_ok = bb > 1e-6;
+        double unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma));
+        int p = 0;
+        for (int k = 0; k < ip.n_steps; ++k) {
+            for (int i = 0; i < L; ++i) {
+                const int rowu = ((i == 0 ? L : i) - 1) * W, rowd = (i == L - 1 ? 0 : i + 1) * W, row = i * W;
+                unsigned leftbit = lds_word(words, row + W - 1) >> 31;       // left neighbour of (i, 0): (i, L-1), not yet updated
+                unsigned first_updated = 0;
+                for (int wj = 0; wj < W; ++wj) {
+                    unsigned cur = lds_word(words, row + wj);
+                    const unsigned up = lds_word(words, rowu + wj), dn = lds_word(words, rowd + wj);
+                    // right neighbour of bit 31: bit 0 of the next word (old value), or of word 0 of this row (updated) at the row end
+                    const unsigned rightbit = (wj == W - 1) ? (first_updated & 1u) : (lds_word(words, row + wj + 1) & 1u);
+                    const unsigned cur0 = cur;
+                    for (int t = 0; t < 32; ++t) {
+                        // branch-light scalar code: selects instead of jumps, one rare branch for the guard band
+                        const unsigned sgb = (cur >> t) & 1u;
+                        const unsigned lf = t == 0 ? leftbit : ((cur >> (t - 1)) & 1u);
+                        // at the end of a one-word row the right neighbour of bit 31 is bit 0 of this very word (already updated)
+                        const unsigned rt = t == 31 ? (W == 1 ? (cur & 1u) : rightbit) : ((cur >> (t + 1)) & 1u);
+                        const int nb = 2 * (int)(((up >> t) & 1u) + ((dn >> t) & 1u) + lf + rt) - 4;
+                        const int delta = (1 - 2 * (int)sgb) * 2 * nb;
+                        const int need = (delta < 0) ? 1 : 0;
+                        if (__builtin_expect(p == 64, 0)) { seed += 64ull * gamma; unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma)); p = 0; }
+                        const unsigned uhi = (unsigned)__builtin_amdgcn_readlane(__double2hiint(unit), p);   // read speculatively, consumed iff `need`
+                        const unsigned hi_h = delta == -4 ? r4hi_h : r8hi_h, lo_h = delta == -4 ? r4lo_h : r8lo_h;
+                        int rej = need & (uhi > hi_h ? 1 : 0);
+                        const int sure_acc = uhi < lo_h ? 1 : 0;
+                        if (__builtin_expect((need & (1 - rej) & (1 - sure_acc)) | (need & (filter_ok ? 0 : 1)), 0)) {
+                            // guard band (or a chain where the filter is not valid): exact arithmetic of the reference
+                            const unsigned ulo = (unsigned)__builtin_amdgcn_readlane(__double2loint(unit), p);
+                            const unsigned long long ub = ((unsigned long long)uhi << 32) | ulo;
+                            const unsigned long long lo = delta == -4 ? r4lo : r8lo, hi = delta == -4 ? r4hi : r8hi;
+                            if (filter_ok && ub > hi) rej = 1;
+                            else if (filter_ok && ub < lo) rej = 0;
+                            else {
+                                const double ratio = exp(ising_lp(beta, bt, (double)(spp + delta)) - ising_lp(beta, bt, (double)spp));
+                                if (ratio < 1) rej = (__longlong_as_double((long long)ub) > ratio) ? 1 : 0;
+                                else { rej = 0; p -= 1; }        // accept_ratio >= 1: the reference draws nothing
+                            }
+                        }
+                        p += need;
+                        const int acc = 1 - rej;
+                        cur ^= (unsigned)acc << t;
+                        spp += acc * delta;
+                    }
+                    if (cur != cur0 && lane == 0) words[row + wj] = cur;
+                    if (wj == 0) first_updated = cur;
+                    leftbit = cur >> 31;
+                }
+            }
+        }
+        seed += (uint64_t)p * gamma;
+    }
+    __syncthreads();
+    for (int s = lane; s < d; s += 64) xrow[s] = ((words[s >> 5] >> (s & 31)) & 1u) ? 1.0 : 0.0;
+#ifdef PTE_DEBUG_ISING
+    if (lane == 0) printf("bits c=%d spp=%lld\n", (int)c, spp);
+#endif
+    if (lane == 0) { e.suff[slot] = (double)spp; e.rng[2 * slot] = seed; }
 }
 
 }  // namespace pte
