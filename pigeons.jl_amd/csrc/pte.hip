@@ -18,6 +18,7 @@
 #include "pte_slice4.hpp"
 #include "pte_slice5.hpp"
 #include "pte_slice6.hpp"
+#include "pte_slice7.hpp"
 #include "pte_automala.hpp"
 #include "pte_ising.hpp"
 
@@ -224,6 +225,10 @@ int launch_explore(pte_engine *h, int64_t scan) {
         time_begin(h, 0);
         if (h->slice_impl == 1) {
             DISPATCH_NLU(h->nlu, k_explore_slice, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
+        } else if (h->slice_impl == 7) {
+            S7Tune tn{2, 6, 2};
+            if (const char *t = std::getenv("PTE_S7_BUDGETS")) std::sscanf(t, "%d,%d,%d", &tn.bud_d, &tn.bud_s, &tn.bud_a);
+            DISPATCH_NLU(h->nlu, k_explore_slice7, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, tn);
         } else if (h->slice_impl == 3) {
             DISPATCH_NLU(h->nlu, k_explore_slice3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_impl == 6 && h->slice_m == 3) {

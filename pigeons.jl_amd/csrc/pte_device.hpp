@@ -48,6 +48,9 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane /*uniform*
     uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
     return ((uint64_t)hi << 32) | lo;
 }
+__device__ __forceinline__ double writelane_f64(double old, double v /*uniform*/, int lane /*uniform*/) {
+    return (lane_id() == lane) ? v : old;
+}
 __device__ __forceinline__ double shfl_xor_f64(double v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
 
