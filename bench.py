@@ -128,7 +128,8 @@ def main():
     bytes_per_replica = 16 * d + 32 if args.explorer == "slice" else 8 * d + 32
     alg_bytes = bytes_per_replica * n_chains
     ex_avg_ms = ex_ms / max(ex_n, 1)
-    kernel_name = {"slice": "k_explore_slice5", "toy": "k_explore_toy"}[args.explorer]
+    impl = os.environ.get("PTE_SLICE_IMPL", "7")
+    kernel_name = {"slice": "k_explore_slice" + ("" if impl == "1" else impl), "toy": "k_explore_toy"}[args.explorer]
     traffic = None
     try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this kernel at this workload
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(kernel_name)
@@ -153,8 +154,8 @@ def main():
                      "traffic": traffic, "avg_launch_ms": ex_avg_ms, "launches": ex_n,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "swap_kernel_avg_launch_ms": sw_ms / max(sw_n, 1),
-                     "note": "SliceSampler is bound by a sequential FP64 dependency chain per replica "
-                             "(~6 log-density evaluations per coordinate, 3*d coordinates), not by HBM; see DESIGN.md"},
+                     "note": "SliceSampler is bound by the instruction issue of ONE wave per replica walking a sequential "
+                             "decision chain (3*d coordinate updates, ~6.5 draws each), not by HBM; see DESIGN.md sec. 5"},
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.explorer == "slice":

@@ -45,7 +45,7 @@ struct pte_engine {
     EngineDev dev{};
     hipStream_t stream = nullptr;
     int nlu = 0;
-    int slice_impl = 5, slice_m = 4;   // PTE_SLICE_IMPL=1 selects the plain sequential kernel (A/B + bisecting)
+    int slice_impl = 7, slice_m = 4;   // PTE_SLICE_IMPL=1 selects the plain sequential kernel (A/B + bisecting)
     int64_t N = 0, d = 0;          // global chains, state dimension
     int64_t K = 0, c0 = 0;         // local chains [c0, c0+K)
     int world = 1, rank = 0;
@@ -226,7 +226,7 @@ int launch_explore(pte_engine *h, int64_t scan) {
         if (h->slice_impl == 1) {
             DISPATCH_NLU(h->nlu, k_explore_slice, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_impl == 7) {
-            S7Tune tn{2, 6, 2};
+            S7Tune tn{2, 8, 2};
             if (const char *t = std::getenv("PTE_S7_BUDGETS")) std::sscanf(t, "%d,%d,%d", &tn.bud_d, &tn.bud_s, &tn.bud_a);
             DISPATCH_NLU(h->nlu, k_explore_slice7, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, tn);
         } else if (h->slice_impl == 3) {
