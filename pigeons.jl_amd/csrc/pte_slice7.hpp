@@ -88,6 +88,8 @@ __global__ __launch_bounds__(64) void k_explore_slice7(EngineDev e, SliceParams 
     uint64_t wseed = e.rng[2 * slot];
     const uint64_t gamma = e.rng[2 * slot + 1];
     int p = 0;                                         // uniform: next unread draw of the window
+    uint64_t gamma_inv = gamma;                        // gamma^-1 mod 2^64 (gamma is odd): Newton, 5 steps
+    for (int k = 0; k < 5; ++k) gamma_inv *= 2ull - gamma * gamma_inv;
     auto fill_window = [&]() __attribute__((always_inline)) {
         __syncthreads();                               // one wave per block: orders the LDS accesses
 #pragma unroll
@@ -335,8 +337,7 @@ __global__ __launch_bounds__(64) void k_explore_slice7(EngineDev e, SliceParams 
                     Sest = Sest + fabs(xn * xn - xo * xo);
                     if (lane == l) X = xn;
                     l += 1;
-                    wseed = rs.seed;
-                    fill_window();
+                    p += (int)((rs.seed - (wseed + (uint64_t)p * gamma)) * gamma_inv);   // draws consumed; window stays
                     PROF_T(t5); PROF_ADD(7, t5 - t4); PROF_ADD(6, 1);
                 }
             }
