@@ -157,6 +157,21 @@ int pte_swap_finish(pte_engine *h, int64_t scan, const double *nbr_stats, int32_
 int64_t pte_boundary_payload_bytes(const pte_engine *h);            /* 8 * (d + 6) */
 int pte_boundary_export(pte_engine *h, int side, void *dst, int dst_is_device);
 int pte_boundary_import(pte_engine *h, int side, const void *src, int src_is_device);
+/* Device-resident, stream-ordered variant of the two phases (no host round trip per scan): the boundary
+ * chain's SwapStat and -- speculatively -- its replica's payload are packed into one message of
+ * pte_shard_message_bytes() = 8 (d + 8) bytes per active side; the caller moves send -> neighbour's recv
+ * with stream-ordered transfers (RCCL send/recv enqueued on pte_get_stream(), replacing the reference's
+ * MPI transmits, src/mpi_utils/Entangler.jl:118-180) and the receiving engine decides and applies the
+ * payload on the device iff the swap is accepted.  All four buffers are caller-owned device memory.
+ *   pte_shard_scan_begin : explore!(scan) + phase 1 + pack; active_out[2] as for pte_swap_begin (host-computable)
+ *   pte_shard_scan_finish: phase 2 from the received messages + conditional import
+ *   pte_shard_sync       : synchronise, raise device errors, boundary_swaps_out[2] = applied swaps per side */
+void *pte_get_stream(const pte_engine *h);                          /* hipStream_t of the engine */
+int64_t pte_shard_message_bytes(const pte_engine *h);
+int pte_shard_set_buffers(pte_engine *h, void *send_lo, void *recv_lo, void *send_hi, void *recv_hi);
+int pte_shard_scan_begin(pte_engine *h, int64_t scan, int32_t *active_out);
+int pte_shard_scan_finish(pte_engine *h, int64_t scan);
+int pte_shard_sync(pte_engine *h, int64_t *boundary_swaps_out);
 /* index process of the local slots: replica[scan][K], chain[scan][K] (global ids). */
 int pte_get_index_process_shard(const pte_engine *h, int64_t *replica, int64_t *chain, int64_t *n_scans);
 int pte_get_replica_ids(const pte_engine *h, int64_t *out /*K*/);

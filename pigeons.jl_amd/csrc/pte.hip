@@ -52,6 +52,8 @@ struct pte_engine {
     int32_t *slot_map[2] = {nullptr, nullptr};   // ping-pong buffers of slot_of_chain (two-phase swap)
     int slot_cur = 0;
     double *d_payload = nullptr;   // staging buffer for boundary export/import
+    double *msg_send[2] = {nullptr, nullptr}, *msg_recv[2] = {nullptr, nullptr};   // device-resident exchange (caller-owned)
+    int64_t *d_napplied = nullptr;  // [2] boundary swaps applied on the device path
     std::vector<double> betas;
     std::vector<void *> allocs;
     double *d_nhp = nullptr, *d_sd = nullptr, *d_nprec = nullptr, *d_beta = nullptr, *d_target_std = nullptr;
@@ -413,6 +415,7 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.nbr_stat, 4);
     rc |= dev_alloc(h, &e.bflag, 2);
     rc |= dev_alloc(h, &h->d_payload, (size_t)(dd + 8));
+    rc |= dev_alloc(h, &h->d_napplied, 2);
     rc |= dev_alloc(h, &e.suff, (size_t)K);
     rc |= dev_alloc(h, &h->d_nhp, (size_t)N);
     rc |= dev_alloc(h, &h->d_sd, (size_t)N);
@@ -766,6 +769,71 @@ int pte_boundary_import(pte_engine *h, int side, const void *src, int src_is_dev
     HIP_OK(h, hipGetLastError());
     HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
+}
+
+// ---- device-resident, stream-ordered boundary exchange -------------------------------------------
+void *pte_get_stream(const pte_engine *h) { return h ? (void *)h->stream : nullptr; }
+int64_t pte_shard_message_bytes(const pte_engine *h) { return h ? (int64_t)sizeof(double) * (h->d + 8) : 0; }
+int pte_shard_set_buffers(pte_engine *h, void *send_lo, void *recv_lo, void *send_hi, void *recv_hi) {
+    if (!h) return 1;
+    h->msg_send[0] = (double *)send_lo; h->msg_recv[0] = (double *)recv_lo;
+    h->msg_send[1] = (double *)send_hi; h->msg_recv[1] = (double *)recv_hi;
+    return 0;
+}
+int pte_shard_scan_begin(pte_engine *h, int64_t scan, int32_t *active_out) {
+    if (!h || !active_out) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    if (!h->msg_send[0] || !h->msg_recv[0] || !h->msg_send[1] || !h->msg_recv[1])
+        return fail(h, "pte_shard_scan_begin: call pte_shard_set_buffers first");
+    if ((h->cfg.record_flags & PTE_RECORD_INDEX_PROCESS) && h->scans_in_round >= h->cfg.max_scans_per_round)
+        return fail(h, "index_process buffer full (max_scans_per_round = %lld)", (long long)h->cfg.max_scans_per_round);
+    if (launch_explore(h, scan)) return 1;
+    const int64_t K = h->K;
+    const int even = (scan % 2 == 0) ? 1 : 0;
+    const unsigned block = 256, grid = (unsigned)((K + block - 1) / block);
+    time_begin(h, 1);
+    hipLaunchKernelGGL(k_swap_stats, dim3(grid), dim3(block), 0, h->stream, h->dev, even, h->scans_in_round);
+    boundary_active(h, even, active_out);
+    if (active_out[0] || active_out[1])
+        hipLaunchKernelGGL(k_boundary_pack, dim3(2), dim3(256), 0, h->stream, h->dev, (int)active_out[0], (int)active_out[1],
+                           h->msg_send[0], h->msg_send[1]);
+    time_end(h);
+    HIP_OK(h, hipGetLastError());
+    return 0;
+}
+int pte_shard_scan_finish(pte_engine *h, int64_t scan) {
+    if (!h) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    const int64_t K = h->K;
+    const int even = (scan % 2 == 0) ? 1 : 0;
+    int32_t active[2];
+    boundary_active(h, even, active);
+    const unsigned block = 256, grid = (unsigned)((K + block - 1) / block);
+    time_begin(h, 1);
+    hipLaunchKernelGGL(k_boundary_stats_in, dim3(1), dim3(64), 0, h->stream, h->dev, (int)active[0], (int)active[1],
+                       (const double *)h->msg_recv[0], (const double *)h->msg_recv[1]);
+    hipLaunchKernelGGL(k_swap_decide, dim3(grid), dim3(block), 0, h->stream, h->dev, even);
+    h->slot_cur ^= 1;                                   // the decide kernel wrote the new chain -> slot map
+    h->dev.slot_of_chain = h->slot_map[h->slot_cur];
+    h->dev.slot_of_chain_alt = h->slot_map[h->slot_cur ^ 1];
+    if (active[0] || active[1])
+        hipLaunchKernelGGL(k_boundary_apply, dim3(2), dim3(256), 0, h->stream, h->dev, (const double *)h->msg_recv[0],
+                           (const double *)h->msg_recv[1], h->d_napplied);
+    time_end(h);
+    HIP_OK(h, hipGetLastError());
+    h->scans_in_round += 1;
+    return 0;
+}
+int pte_shard_sync(pte_engine *h, int64_t *boundary_swaps_out) {
+    if (!h) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    int rc = check_device_error(h);                     // synchronises the engine's stream
+    time_collect(h);
+    if (boundary_swaps_out) {
+        HIP_OK(h, hipMemcpyAsync(boundary_swaps_out, h->d_napplied, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(h, hipStreamSynchronize(h->stream));
+    }
+    return rc;
 }
 
 int pte_get_state(const pte_engine *hc, double *state, int64_t *chain, uint64_t *rng) {

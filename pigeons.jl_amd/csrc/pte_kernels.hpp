@@ -545,6 +545,56 @@ __global__ __launch_bounds__(256) void k_boundary_import(EngineDev e, int side, 
     }
 }
 
+// ---- device-resident boundary exchange (no host round trip per scan) -----------------------------
+// message layout (8-byte words): [0] log_ratio, [1] uniform of the boundary chain, [2 .. d+8) payload.
+// The payload travels speculatively with the SwapStat; the receiver applies it iff the swap is accepted
+// (both sides take the same decision from the same two stats).
+__global__ __launch_bounds__(256) void k_boundary_pack(EngineDev e, int active0, int active1, double *msg0, double *msg1) {
+    const int side = blockIdx.x;
+    if (!(side == 0 ? active0 : active1)) return;
+    double *msg = side == 0 ? msg0 : msg1;
+    const int64_t cl = side == 0 ? 0 : e.K - 1;
+    const int slot = e.slot_of_chain[cl];
+    const double *xrow = e.x + (int64_t)slot * e.ld;
+    double *buf = msg + 2;
+    for (int64_t i = threadIdx.x; i < e.d; i += blockDim.x) buf[i] = xrow[i];
+    if (threadIdx.x == 0) {
+        msg[0] = e.stat[2 * cl]; msg[1] = e.stat[2 * cl + 1];
+        buf[e.d] = e.suff[slot];
+        unsigned long long *w = reinterpret_cast<unsigned long long *>(buf + e.d + 1);
+        w[0] = e.rng[2 * slot]; w[1] = e.rng[2 * slot + 1];
+        w[2] = (unsigned long long)e.replica_id[slot];
+        w[3] = (unsigned long long)e.rt_state[slot];
+        buf[e.d + 5] = e.suff2[slot];
+    }
+}
+__global__ void k_boundary_stats_in(EngineDev e, int active0, int active1, const double *msg0, const double *msg1) {
+    if (threadIdx.x == 0) {
+        e.nbr_stat[0] = active0 ? msg0[0] : 0.0; e.nbr_stat[1] = active0 ? msg0[1] : 0.0;
+        e.nbr_stat[2] = active1 ? msg1[0] : 0.0; e.nbr_stat[3] = active1 ? msg1[1] : 0.0;
+        e.bflag[0] = 0; e.bflag[1] = 0;
+    }
+}
+// runs after k_swap_decide (slot maps already flipped on the host side: e.slot_of_chain is the new map,
+// in which a boundary slot keeps its chain)
+__global__ __launch_bounds__(256) void k_boundary_apply(EngineDev e, const double *msg0, const double *msg1, int64_t *n_applied) {
+    const int side = blockIdx.x;
+    if (!e.bflag[side]) return;
+    const double *buf = (side == 0 ? msg0 : msg1) + 2;
+    const int slot = e.slot_of_chain[side == 0 ? 0 : e.K - 1];
+    double *xrow = e.x + (int64_t)slot * e.ld;
+    for (int64_t i = threadIdx.x; i < e.d; i += blockDim.x) xrow[i] = buf[i];
+    if (threadIdx.x == 0) {
+        e.suff[slot] = buf[e.d];
+        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(buf + e.d + 1);
+        e.rng[2 * slot] = w[0]; e.rng[2 * slot + 1] = w[1];
+        e.replica_id[slot] = (int64_t)w[2];
+        e.rt_state[slot] = (int64_t)w[3];
+        e.suff2[slot] = buf[e.d + 5];
+        n_applied[side] += 1;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // test kernels
 // ---------------------------------------------------------------------------------------------

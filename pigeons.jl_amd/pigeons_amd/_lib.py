@@ -49,6 +49,8 @@ EXPORTS = [
     "pte_timing_reset", "pte_timing_get", "pte_test_rng_fill", "pte_test_sqr_norm",
     "pte_shard_info", "pte_swap_begin", "pte_swap_finish", "pte_boundary_payload_bytes",
     "pte_boundary_export", "pte_boundary_import", "pte_get_index_process_shard", "pte_get_replica_ids",
+    "pte_get_stream", "pte_shard_message_bytes", "pte_shard_set_buffers", "pte_shard_scan_begin",
+    "pte_shard_scan_finish", "pte_shard_sync",
 ]
 
 _lib = None
@@ -63,6 +65,13 @@ def load():
         raise PteError(
             "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    try:
+        # PyTorch-ROCm bundles its own libamdhip64; loading it FIRST makes libpte bind to the same HIP
+        # runtime, so that torch device tensors / RCCL and the engine can share streams and pointers in
+        # one process (two runtimes in one process: the second one sees no GPU).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     dp, ip, up = C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
     vp = C.c_void_p
@@ -101,8 +110,16 @@ def load():
     L.pte_get_index_process_shard.argtypes = [vp, ip, ip, ip]
     L.pte_get_replica_ids.argtypes = [vp, ip]
     L.pte_boundary_payload_bytes.restype = C.c_int64
+    L.pte_get_stream.argtypes = [vp]
+    L.pte_get_stream.restype = C.c_void_p
+    L.pte_shard_message_bytes.argtypes = [vp]
+    L.pte_shard_message_bytes.restype = C.c_int64
+    L.pte_shard_set_buffers.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.pte_shard_scan_begin.argtypes = [vp, C.c_int64, i32p]
+    L.pte_shard_scan_finish.argtypes = [vp, C.c_int64]
+    L.pte_shard_sync.argtypes = [vp, ip]
     for name in EXPORTS:
-        if name not in ("pte_last_error", "pte_boundary_payload_bytes"):
+        if name not in ("pte_last_error", "pte_boundary_payload_bytes", "pte_get_stream", "pte_shard_message_bytes"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

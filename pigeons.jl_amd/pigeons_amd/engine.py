@@ -155,6 +155,29 @@ class Engine:
     def boundary_import(self, side, ptr, is_device):
         self._chk(self.L.pte_boundary_import(self.h, side, C.c_void_p(ptr), 1 if is_device else 0))
 
+    # --- device-resident, stream-ordered boundary exchange (include/pte.h: pte_shard_scan_*)
+    def stream_ptr(self):
+        return int(self.L.pte_get_stream(self.h) or 0)
+
+    def message_words(self):
+        return int(self.L.pte_shard_message_bytes(self.h)) // 8
+
+    def shard_set_buffers(self, send_lo, recv_lo, send_hi, recv_hi):
+        self._chk(self.L.pte_shard_set_buffers(self.h, C.c_void_p(send_lo), C.c_void_p(recv_lo), C.c_void_p(send_hi), C.c_void_p(recv_hi)))
+
+    def shard_scan_begin(self, scan):
+        active = np.zeros(2, dtype=np.int32)
+        self._chk(self.L.pte_shard_scan_begin(self.h, scan, active.ctypes.data_as(C.POINTER(C.c_int32))))
+        return active
+
+    def shard_scan_finish(self, scan):
+        self._chk(self.L.pte_shard_scan_finish(self.h, scan))
+
+    def shard_sync(self):
+        n = np.zeros(2, dtype=np.int64)
+        self._chk(self.L.pte_shard_sync(self.h, _ip(n)))
+        return n
+
     def explorer_stats(self):
         am = np.zeros(self.K); ss = np.zeros(self.K)
         an = np.zeros(self.K, dtype=np.int64); sn = np.zeros(self.K, dtype=np.int64)

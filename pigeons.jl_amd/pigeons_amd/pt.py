@@ -229,11 +229,12 @@ class PT:
     """src/pt/PT.jl:6-51.  `replicas` is the device engine.
 
     Sharding (not in the reference's PT; replaces its MPI `EntangledReplicas`):
-      n_shards=G           G chain-shards driven from this process (LoopbackShards; single-GPU tests)
+      n_shards=G           G chain-shards driven from this process (LoopbackShards; single-GPU tests;
+                           device_messages=True: the device-resident exchange kernels of the RCCL path)
       rank=r, world=G      this process owns shard r of G (DistShard over torch.distributed)
     """
 
-    def __init__(self, inputs: Inputs, n_shards=1, rank=0, world=1, dist_device=None, engine_factory=None):
+    def __init__(self, inputs: Inputs, n_shards=1, rank=0, world=1, dist_device=None, engine_factory=None, device_messages=False):
         self.inputs = inputs
         target = inputs.target
         explorer = inputs.explorer if inputs.explorer is not None else default_explorer(target)
@@ -287,7 +288,7 @@ class PT:
         self.shards = None
         if n_shards > 1:
             from .sharded import LoopbackShards
-            self.shards = LoopbackShards([make(rank=g, world_size=n_shards, **kw) for g in range(n_shards)])
+            self.shards = LoopbackShards([make(rank=g, world_size=n_shards, **kw) for g in range(n_shards)], device_messages=device_messages)
             self.replicas = self.shards.engines[0]
         elif world > 1:
             from .sharded import DistShard

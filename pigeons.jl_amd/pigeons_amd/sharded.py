@@ -13,6 +13,11 @@ pte_boundary_export / pte_boundary_import):
   * LoopbackShards -- G engines in ONE process (tests on a single GPU; bytes move by plain copies);
   * DistShard      -- one engine per process, torch.distributed point-to-point between neighbour
                       ranks (backend nccl == RCCL over xGMI for device payloads; gloo on CPU).
+With the nccl backend DistShard uses the device-resident variant (pte_shard_scan_begin / _finish): the
+boundary SwapStat and, speculatively, the replica payload travel in ONE message per active side and
+scan, RCCL send/recv are enqueued on the engine's HIP stream, the receiver decides and applies the
+payload on the device -- no host synchronisation inside the scan loop.  LoopbackShards(device_messages=
+True) drives the same kernels on one GPU (device-to-device copies) for the parity tests.
 A shard "engine" is anything with the Engine methods used below (the HIP Engine in production; the
 oracle-backed shard in the CPU tests).
 """
@@ -61,14 +66,43 @@ def local_reduced(eng):
 class LoopbackShards:
     """G shard engines in one process, run scan-synchronously; boundary bytes move by host copies."""
 
-    def __init__(self, engines):
+    def __init__(self, engines, device_messages=False):
         self.engines = list(engines)
         self.G = len(self.engines)
         self.N = self.engines[0].N
         self.d = self.engines[0].d
         self.n_boundary_swaps = 0
+        self.device_messages = device_messages
+        if device_messages:
+            import torch
+            self.torch = torch
+            w = self.engines[0].message_words()
+            dev = torch.device("cuda", 0)
+            self.msg = [[torch.zeros(w, dtype=torch.float64, device=dev) for _ in range(4)] for _ in self.engines]
+            for e, m in zip(self.engines, self.msg):      # order: send_lo, recv_lo, send_hi, recv_hi
+                e.shard_set_buffers(*[t.data_ptr() for t in m])
+
+    def _run_scans_device(self, first_scan, n_scans):
+        """Same kernels as the RCCL path; the transfers are device-to-device copies with a full
+        synchronisation between the phases (this driver tests the kernels, not the stream ordering)."""
+        E, G, torch = self.engines, self.G, self.torch
+        for s in range(first_scan, first_scan + n_scans):
+            active = [e.shard_scan_begin(s) for e in E]
+            for e in E:
+                e.shard_sync()
+            for g in range(G - 1):
+                assert active[g][1] == active[g + 1][0]
+                if active[g][1]:
+                    self.msg[g + 1][1].copy_(self.msg[g][2])      # upper neighbour's recv_lo <- my send_hi
+                    self.msg[g][3].copy_(self.msg[g + 1][0])      # my recv_hi <- upper neighbour's send_lo
+            torch.cuda.synchronize()
+            for e in E:
+                e.shard_scan_finish(s)
+        self.n_boundary_swaps = int(sum(e.shard_sync()[1] for e in E))
 
     def run_scans(self, first_scan, n_scans):
+        if self.device_messages:
+            return self._run_scans_device(first_scan, n_scans)
         E, G = self.engines, self.G
         for s in range(first_scan, first_scan + n_scans):
             for e in E:
@@ -132,6 +166,36 @@ class DistShard:
         self.stat_send = [torch.zeros(2, dtype=torch.float64, device=self.device) for _ in range(2)]
         self.stat_recv = [torch.zeros(2, dtype=torch.float64, device=self.device) for _ in range(2)]
         self.n_boundary_swaps = 0
+        # device-resident exchange: RCCL ops ordered on the engine's own HIP stream
+        import os
+        self.stream_ordered = (self.on_device and dist.get_backend(group) == "nccl" and hasattr(engine, "shard_scan_begin")
+                               and os.environ.get("PTE_DIST_HOST_DRIVEN", "0") != "1")
+        if self.stream_ordered:
+            mw = engine.message_words()
+            self.msg = [torch.zeros(mw, dtype=torch.float64, device=self.device) for _ in range(4)]   # send_lo, recv_lo, send_hi, recv_hi
+            engine.shard_set_buffers(*[t.data_ptr() for t in self.msg])
+            self.stream = torch.cuda.ExternalStream(engine.stream_ptr(), device=self.device)
+            self.debug_sync = os.environ.get("PTE_DIST_SYNC", "0") == "1"
+
+    def _run_scans_stream_ordered(self, first_scan, n_scans):
+        e, torch, dist = self.e, self.torch, self.dist
+        with torch.cuda.stream(self.stream):
+            for s in range(first_scan, first_scan + n_scans):
+                active = e.shard_scan_begin(s)           # explore + SwapStats + pack, enqueued
+                ops = []
+                for sd in (0, 1):
+                    if active[sd]:
+                        peer = self.rank - 1 if sd == 0 else self.rank + 1
+                        ops.append(dist.P2POp(dist.isend, self.msg[2 * sd], peer, self.group))
+                        ops.append(dist.P2POp(dist.irecv, self.msg[2 * sd + 1], peer, self.group))
+                if ops:
+                    for r in dist.batch_isend_irecv(ops):
+                        r.wait()                          # nccl: orders the current stream after the transfer, no host block
+                if self.debug_sync:
+                    torch.cuda.synchronize(self.device)
+                e.shard_scan_finish(s)                   # decide + conditional import, enqueued
+        n = e.shard_sync()
+        self.n_boundary_swaps = int(n[0] + n[1])
 
     def _exchange(self, sides, send, recv):
         dist = self.dist
@@ -145,6 +209,8 @@ class DistShard:
                 r.wait()
 
     def run_scans(self, first_scan, n_scans):
+        if self.stream_ordered:
+            return self._run_scans_stream_ordered(first_scan, n_scans)
         e, torch = self.e, self.torch
         for s in range(first_scan, first_scan + n_scans):
             e.explore(s)

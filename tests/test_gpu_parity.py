@@ -276,12 +276,13 @@ def test_full_size_properties_metric_config(P):
     (16, 130, 8, "slice", 4),   # K = 2
     (6, 3, 6, "toy", 5),        # K = 1: every pair is a boundary pair
 ])
-def test_sharded_engines_equal_single_engine(P, N, d, G, explorer, rounds):
+@pytest.mark.parametrize("device_messages", [False, True])   # True: the stream-ordered RCCL path's kernels
+def test_sharded_engines_equal_single_engine(P, N, d, G, explorer, rounds, device_messages):
     exp = {"toy": P.ToyExplorer, "slice": P.SliceSampler}[explorer]
     rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.online]
     mk = lambda: P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=exp(), record=rec, show_report=False)
     one = P.PT(mk())
-    many = P.PT(mk(), n_shards=G)
+    many = P.PT(mk(), n_shards=G, device_messages=device_messages)
     for _ in range(rounds):
         assert P.next_round(one) and P.next_round(many)
         ra = P.run_one_round(one); P.adapt(one, ra)
@@ -349,6 +350,47 @@ def test_dist_shard_two_ranks_device_payloads(P, tmp_path):
         assert p.returncode == 0, se[-3000:]
     res = json.loads(outs[0][0].strip().splitlines()[-1])
     assert res["ok"] and res["boundary_swaps"] > 0, res
+
+
+NCCL_WORLD1_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path[:0] = [%(root)r, %(root)r + "/pigeons.jl_amd", %(root)r + "/tests"]
+import torch, torch.distributed as dist
+import pigeons_amd as P
+from pigeons_amd.sharded import DistShard
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+mk = lambda: P.Inputs(target=P.toy_mvn_target(70), n_chains=8, n_rounds=4, explorer=P.SliceSampler(), show_report=False,
+                      record=[P.round_trip, P.index_process, P.log_sum_ratio])
+pt = P.PT(mk()); one = P.PT(mk())
+pt.shards = DistShard(pt.replicas, 0, 1, device=torch.device("cuda", 0))
+ok = bool(pt.shards.stream_ordered)
+for _ in range(4):
+    P.next_round(pt); red = P.run_one_round(pt); P.adapt(pt, red)
+    P.next_round(one); ra = P.run_one_round(one); P.adapt(one, ra)
+    ok &= bool(np.array_equal(ra.index_process, red.index_process)) and ra.round_trip == red.round_trip
+    ok &= bool(np.array_equal(ra.swap_acceptance_pr[0], red.swap_acceptance_pr[0]))
+x, chain, rng = pt.shards.states(); xa, ca, ga = one.replicas.states()
+ok &= bool(np.array_equal(x, xa) and np.array_equal(chain, ca) and np.array_equal(rng, ga))
+print(json.dumps({"ok": ok}))
+dist.destroy_process_group()
+'''
+
+
+def test_dist_shard_stream_ordered_driver_on_rccl_world1(P, tmp_path):
+    """The stream-ordered RCCL driver (engine kernels + collectives enqueued on the engine's HIP stream through
+    torch.cuda.ExternalStream) with a 1-rank nccl group: no peers, but the enqueue / sync / reduce plumbing runs."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker1.py"
+    script.write_text(NCCL_WORLD1_WORKER % {"root": root})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="1", RANK="0")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert lines, (p.stdout[-2000:], p.stderr[-2000:])
+    assert json.loads(lines[-1])["ok"]
 
 
 # ---------------------------------------------------------------------------------------------
