@@ -56,7 +56,9 @@ enum {
 enum {                                   /* Inputs.record (src/pt/Inputs.jl:57-62)                         */
     PTE_RECORD_ROUND_TRIP    = 1u << 0,  /* round_trip     src/recorders/RoundTripRecorder.jl              */
     PTE_RECORD_INDEX_PROCESS = 1u << 1,  /* index_process  src/recorders/recorder.jl:81                    */
-    PTE_RECORD_ONLINE        = 1u << 2   /* online / _transformed_online (target chain mean, variance)     */
+    PTE_RECORD_ONLINE        = 1u << 2,  /* online / _transformed_online (target chain mean, variance)     */
+    PTE_RECORD_TRACES        = 1u << 3,  /* traces: [state; log density] of the target chain per scan (src/recorders/recorder.jl:27,39-43; src/pt/pigeons.jl:116-125) */
+    PTE_RECORD_ENERGY_AC1    = 1u << 4   /* energy_ac1: per-chain covariance of the log density before / after explore! (recorder.jl:113; pigeons.jl:134-143) */
 };
 
 /* Mirrors the fields of `Inputs` (src/pt/Inputs.jl:9-102) and of the explorer
@@ -132,6 +134,13 @@ int pte_get_explorer_stats(const pte_engine *h, double *acceptance_mean /*N*/, i
 int pte_get_automala_stats(const pte_engine *h, double *factor_mean /*N*/, int64_t *factor_n /*N*/,
                            double *reversibility_mean /*N*/, int64_t *reversibility_n /*N*/);
 int pte_get_online(const pte_engine *h, double *mean /*d*/, double *variance /*d*/, int64_t *n);
+/* the (d+1)-th entry of the `online` sample extract_sample(state::Array, lp) = [state; lp(state)] (src/pt/state.jl:79) */
+int pte_get_online_log_density(const pte_engine *h, double *mean, double *variance);
+/* energy_ac1s(pt) (src/recorders/recorder.jl:156-173) for the local chains: cor[K] (NaN where n < 2), n[K],
+ * moments[5K] = running (mean before, mean after, C_bb, C_ba, C_aa); NULL pointers are skipped. */
+int pte_get_energy_ac1(const pte_engine *h, double *cor, int64_t *n, double *moments);
+/* traces of the last round, out[scan][d+1]; *n_scans = 0 on shards that do not own the target chain. */
+int pte_get_traces(const pte_engine *h, double *out, int64_t *n_scans);
 
 /* Replica fields in replica order (src/replicas/Replica.jl:5-30): state [N*d], chain [N],
  * rng [2N] = (seed, gamma) of each SplittableRandom.  NULL pointers are skipped. */

@@ -225,6 +225,32 @@ static inline void logsum_merge(po_logsum *a, const po_logsum *b) {
 }
 
 /* src/recorders/RoundTripRecorder.jl:4-54 */
+/* OnlineStatsBase 1.x `CovMatrix(2)` (third-party, not under /root/reference; the reference pins
+ * OnlineStatsBase = "1", Project.toml:91): b = running mean, A = running mean of x x' (upper triangle),
+ * both with the EqualWeight smoothing a += (1/n)(x - a); merge smooths with n2/(n1+n2);
+ * value = (A - b b') n/(n-1); cor = D^-1/2 value D^-1/2. */
+typedef struct { int64_t n; double b[2]; double A[3]; } po_cov2;
+static inline void cov2_fit(po_cov2 *o, double x0, double x1) {
+    o->n += 1;
+    const double g = 1.0 / (double)o->n;
+    o->b[0] += g * (x0 - o->b[0]); o->b[1] += g * (x1 - o->b[1]);
+    o->A[0] += g * (x0 * x0 - o->A[0]); o->A[1] += g * (x0 * x1 - o->A[1]); o->A[2] += g * (x1 * x1 - o->A[2]);
+}
+static inline void cov2_merge(po_cov2 *a, const po_cov2 *b) {
+    if (b->n == 0) return;
+    a->n += b->n;
+    const double g = (double)b->n / (double)a->n;
+    for (int i = 0; i < 3; i++) a->A[i] += g * (b->A[i] - a->A[i]);
+    for (int i = 0; i < 2; i++) a->b[i] += g * (b->b[i] - a->b[i]);
+}
+static inline double cov2_cor12(const po_cov2 *o) {      /* cor(o)[1,2], energy_ac1s (recorder.jl:162-173) */
+    const double bes = (double)o->n / (double)(o->n - 1);
+    const double c00 = (o->A[0] - o->b[0] * o->b[0]) * bes, c01 = (o->A[1] - o->b[0] * o->b[1]) * bes,
+                 c11 = (o->A[2] - o->b[1] * o->b[1]) * bes;
+    const double v0 = 1.0 / sqrt(c00), v1 = 1.0 / sqrt(c11);
+    return (c01 * v1) * v0;
+}
+
 typedef struct { int64_t n_tempered_restarts, n_round_trips, state; } po_round_trip;
 static inline void round_trip_record(po_round_trip *r, int is_ref, int is_target) {
     if (r->state == 0 && is_ref) r->state = 1;
@@ -244,8 +270,10 @@ typedef struct {
     po_mean   *rev_rate;    /* [N]   AutoMALA.jl:294                              */
     po_round_trip rt;
     int64_t   *ip; int64_t ip_len, ip_cap;   /* index_process[replica_index]      */
-    po_mean   *on_mean;     /* [d] _transformed_online / online, target chain     */
-    po_var    *on_var;      /* [d]                                                */
+    po_mean   *on_mean;     /* [d+1] _transformed_online / online, target chain; entry d = log density
+                               (extract_sample(state::Array, lp) = [state; lp(state)], src/pt/state.jl:79) */
+    po_var    *on_var;      /* [d+1]                                              */
+    po_cov2   *eac;         /* [N] energy_ac1 = GroupBy(Int, CovMatrix(2)), recorder.jl:113 */
 } po_recorders;
 
 static void rec_alloc(po_recorders *r, int64_t N, int64_t d) {
@@ -258,8 +286,9 @@ static void rec_alloc(po_recorders *r, int64_t N, int64_t d) {
     r->expl_steps = (po_sum *)calloc((size_t)N, sizeof(po_sum));
     r->am_factors = (po_mean *)calloc((size_t)N, sizeof(po_mean));
     r->rev_rate = (po_mean *)calloc((size_t)N, sizeof(po_mean));
-    r->on_mean = (po_mean *)calloc((size_t)(d > 0 ? d : 1), sizeof(po_mean));
-    r->on_var = (po_var *)calloc((size_t)(d > 0 ? d : 1), sizeof(po_var));
+    r->on_mean = (po_mean *)calloc((size_t)(d + 1), sizeof(po_mean));
+    r->on_var = (po_var *)calloc((size_t)(d + 1), sizeof(po_var));
+    r->eac = (po_cov2 *)calloc((size_t)N, sizeof(po_cov2));
 }
 static void rec_empty(po_recorders *r, int64_t N, int64_t d) {
     int64_t np = N > 1 ? N - 1 : 1;
@@ -274,12 +303,13 @@ static void rec_empty(po_recorders *r, int64_t N, int64_t d) {
     memset(r->rev_rate, 0, sizeof(po_mean) * (size_t)N);
     memset(&r->rt, 0, sizeof(r->rt));
     r->ip_len = 0;
-    memset(r->on_mean, 0, sizeof(po_mean) * (size_t)(d > 0 ? d : 1));
-    memset(r->on_var, 0, sizeof(po_var) * (size_t)(d > 0 ? d : 1));
+    memset(r->on_mean, 0, sizeof(po_mean) * (size_t)(d + 1));
+    memset(r->on_var, 0, sizeof(po_var) * (size_t)(d + 1));
+    memset(r->eac, 0, sizeof(po_cov2) * (size_t)N);
 }
 static void rec_free(po_recorders *r) {
     free(r->swap_pr); free(r->lsr_up); free(r->lsr_dn); free(r->expl_acc); free(r->expl_steps);
-    free(r->am_factors); free(r->rev_rate); free(r->ip); free(r->on_mean); free(r->on_var);
+    free(r->am_factors); free(r->rev_rate); free(r->ip); free(r->on_mean); free(r->on_var); free(r->eac);
 }
 /* merge_recorders (src/recorders/recorders.jl:122-130): a <- merge(a, b).
  * index_process dicts have disjoint keys (one per replica) and are collected by
@@ -295,11 +325,12 @@ static void rec_merge(po_recorders *a, const po_recorders *b, int64_t N, int64_t
         sum_merge(&a->expl_steps[i], &b->expl_steps[i]);
         mean_merge(&a->am_factors[i], &b->am_factors[i]);
         mean_merge(&a->rev_rate[i], &b->rev_rate[i]);
+        cov2_merge(&a->eac[i], &b->eac[i]);
     }
     a->rt.n_tempered_restarts += b->rt.n_tempered_restarts;
     a->rt.n_round_trips += b->rt.n_round_trips;
     a->rt.state = 0;
-    for (int64_t i = 0; i < d; i++) {
+    for (int64_t i = 0; i <= d; i++) {
         mean_merge(&a->on_mean[i], &b->on_mean[i]);
         var_merge(&a->on_var[i], &b->on_var[i]);
     }
@@ -343,6 +374,9 @@ struct po_pt {
     double  *cb_x, *cb_y, *cb_m, *cb_c, *cb_d;  /* cumulative barrier interpolant */
     int      cb_valid;
     double   stepping_stone[2];
+    int64_t  traces_n;
+    double  *traces; int64_t traces_cap;   /* [scan][d+1] target-chain samples of the current round (recorder.jl:27,39-43) */
+    double  *reduced_traces; int64_t reduced_traces_n;
     char     err[512];
     int      failed;
 };
@@ -359,6 +393,7 @@ void po_default_config(po_config *c) {
     c->am_base_n_refresh = 3; c->am_exponent_n_refresh = 0.35; c->am_step_size = 1.0;
     c->am_preconditioner = 2; c->am_p0 = 1.0 / 3.0; c->am_p1 = 1.0 / 3.0;
     c->record_round_trip = 1; c->record_index_process = 1; c->record_online = 0;
+    c->record_traces = 0; c->record_energy_ac1 = 0;
     c->n_threads = 1;
     c->rank = 0; c->world_size = 1;
 }
@@ -786,9 +821,30 @@ static int automala_step(po_pt *pt, po_replica *r) {
 }
 
 /* explore!(pt, replica, explorer), src/pt/pigeons.jl:101-132 */
+static inline double lp_of_replica(const po_pt *pt, const po_replica *r) {   /* find_log_potential(replica, ...)(replica.state) */
+    return pt->cfg.target == PO_TARGET_ISING ? ising_lp(pt, r->chain, r->aux) : lp_at_chain(pt, r->chain, r->state);
+}
+static int explore_replica_inner(po_pt *pt, po_replica *r);
 static int explore_replica(po_pt *pt, po_replica *r) {
-    const int64_t N = pt->N;
     if (pt->cfg.target == PO_TARGET_TEST_SWAPPER) return 0;   /* state nothing, step! no-op (pair_swapper.jl:137-143) */
+    const int ac = pt->cfg.record_energy_ac1;
+    const double before = ac ? lp_of_replica(pt, r) : 0.0;    /* eval_if_ac_requested, pigeons.jl:134-137 */
+    if (explore_replica_inner(pt, r)) return 1;
+    if (ac) cov2_fit(&r->rec.eac[r->chain], before, lp_of_replica(pt, r));   /* process_ac!, :139-143 */
+    if (pt->cfg.record_traces && is_target(pt->N, r->chain) && pt->cfg.target != PO_TARGET_ISING) {   /* pigeons.jl:116-125 */
+        const int64_t w = pt->d + 1, t = pt->scan - 1;
+        if (t >= pt->traces_cap) {                              /* only the replica at the target chain gets here */
+            pt->traces_cap = 2 * (t + 1);
+            pt->traces = (double *)realloc(pt->traces, sizeof(double) * (size_t)(pt->traces_cap * w));
+        }
+        memcpy(pt->traces + t * w, r->state, sizeof(double) * (size_t)pt->d);
+        pt->traces[t * w + pt->d] = lp_of_replica(pt, r);
+        if (t + 1 > pt->traces_n) pt->traces_n = t + 1;
+    }
+    return 0;
+}
+static int explore_replica_inner(po_pt *pt, po_replica *r) {
+    const int64_t N = pt->N;
     if (pt->cfg.target == PO_TARGET_ISING) {
         if (is_reference(N, r->chain)) ising_sample_iid(pt, r);
         else ising_step(pt, r);
@@ -809,6 +865,11 @@ static int explore_replica(po_pt *pt, po_replica *r) {
         for (int64_t i = 0; i < pt->d; i++) {       /* OnlineStateRecorder.jl:87-96 */
             mean_fit(&r->rec.on_mean[i], r->state[i]);
             var_fit(&r->rec.on_var[i], r->state[i]);
+        }
+        if (pt->cfg.record_online) {                /* :online sees extract_sample = [state; lp(state)], state.jl:79 */
+            const double lp = lp_at_chain(pt, r->chain, r->state);
+            mean_fit(&r->rec.on_mean[pt->d], lp);
+            var_fit(&r->rec.on_var[pt->d], lp);
         }
     }
     return 0;
@@ -940,7 +1001,7 @@ void po_destroy(po_pt *pt) {
     free(pt->shard_stat); free(pt->shard_ip_replica); free(pt->shard_ip_chain);
     rec_free(&pt->reduced);
     free(pt->replicas); free(pt->replica_of_chain); free(pt->betas); free(pt->target_std);
-    free(pt->reduced_ip); free(pt->cb_x);
+    free(pt->reduced_ip); free(pt->cb_x); free(pt->traces); free(pt->reduced_traces);
     free(pt);
 }
 
@@ -1039,6 +1100,8 @@ int po_end_round(po_pt *pt) {
             memcpy(pt->reduced_ip + r * n_scans, pt->replicas[r].rec.ip, sizeof(int64_t) * (size_t)pt->replicas[r].rec.ip_len);
     }
     pt->reduced_n_scans = n_scans;
+    { free(pt->reduced_traces); pt->reduced_traces = pt->traces; pt->traces = NULL; pt->traces_cap = 0;
+      pt->reduced_traces_n = pt->traces_n; pt->traces_n = 0; }
     for (int64_t s = 1; s < N; s *= 2)
         for (int64_t i = 0; i + s < N; i += 2 * s)
             rec_merge(&pt->replicas[i].rec, &pt->replicas[i + s].rec, N, d);
@@ -1109,6 +1172,23 @@ void po_get_am_stats(const po_pt *pt, double *fm, int64_t *fn, double *rm, int64
         fm[i] = pt->reduced.am_factors[i].mu; fn[i] = pt->reduced.am_factors[i].n;
         rm[i] = pt->reduced.rev_rate[i].mu; rn[i] = pt->reduced.rev_rate[i].n;
     }
+}
+/* energy_ac1s(pt) (recorder.jl:156-173): cor[c] of (lp before, lp after) the exploration step at chain c; raw = {b0,b1,A00,A01,A11} */
+void po_get_energy_ac1(const po_pt *pt, double *cor, int64_t *n, double *raw) {
+    for (int64_t c = 0; c < pt->N; c++) {
+        const po_cov2 *o = &pt->reduced.eac[c];
+        if (cor) cor[c] = o->n > 1 ? cov2_cor12(o) : NAN;
+        if (n) n[c] = o->n;
+        if (raw) { raw[5 * c] = o->b[0]; raw[5 * c + 1] = o->b[1]; raw[5 * c + 2] = o->A[0]; raw[5 * c + 3] = o->A[1]; raw[5 * c + 4] = o->A[2]; }
+    }
+}
+/* traces of the last round: out[scan][d+1] = [state; log density] of the target chain; returns the number of scans */
+int64_t po_get_traces(const po_pt *pt, double *out) {
+    if (out && pt->reduced_traces) memcpy(out, pt->reduced_traces, sizeof(double) * (size_t)(pt->reduced_traces_n * (pt->d + 1)));
+    return pt->reduced_traces_n;
+}
+void po_get_online_lp(const po_pt *pt, double *mean, double *var, int64_t *n) {
+    *mean = pt->reduced.on_mean[pt->d].mu; *var = var_value(&pt->reduced.on_var[pt->d]); *n = pt->reduced.on_mean[pt->d].n;
 }
 int64_t po_get_online(const po_pt *pt, double *mean, double *var) {
     for (int64_t i = 0; i < pt->d; i++) { mean[i] = pt->reduced.on_mean[i].mu; var[i] = var_value(&pt->reduced.on_var[i]); }
@@ -1229,6 +1309,8 @@ int po_shard_reduce(po_pt *pt) {
         (void)st;                                           /* ... including its state (RoundTripRecorder.jl:30-34) */
     }
     pt->reduced_n_scans = pt->shard_ip_len / pt->K;
+    { free(pt->reduced_traces); pt->reduced_traces = pt->traces; pt->traces = NULL; pt->traces_cap = 0;
+      pt->reduced_traces_n = pt->traces_n; pt->traces_n = 0; }
     return 0;
 }
 void po_shard_replica_ids(const po_pt *pt, int64_t *out) { for (int64_t s = 0; s < pt->K; s++) out[s] = pt->replicas[s].replica_index; }

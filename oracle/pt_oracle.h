@@ -71,6 +71,8 @@ typedef struct po_config {
     /* chain sharding (test-only restatement of the build's multi-GPU protocol):
        this instance owns chains [rank*N/world, (rank+1)*N/world) and the replicas at them */
     int32_t  rank, world_size;
+    /* traces (target chain [state; lp] per scan) and energy_ac1 */
+    int32_t  record_traces, record_energy_ac1;
 } po_config;
 
 typedef struct po_pt po_pt;
@@ -116,6 +118,9 @@ void    po_get_explorer_stats(const po_pt *pt, double *acc_mean, int64_t *acc_n,
 void    po_get_am_stats(const po_pt *pt, double *factor_mean, int64_t *factor_n,
                         double *rev_mean, int64_t *rev_n);                       /* N each   */
 int64_t po_get_online(const po_pt *pt, double *mean, double *var);               /* d each; returns n */
+void    po_get_online_lp(const po_pt *pt, double *mean, double *var, int64_t *n); /* entry d+1 of `online`: the log density */
+void    po_get_energy_ac1(const po_pt *pt, double *cor /*N*/, int64_t *n /*N*/, double *raw /*5N or NULL*/);
+int64_t po_get_traces(const po_pt *pt, double *out /*[scan][d+1]*/);              /* returns the number of scans */
 void    po_get_stepping_stone(const po_pt *pt, double *pair);                    /* 2        */
 double  po_get_global_barrier(const po_pt *pt);
 double  po_cumulative_barrier(const po_pt *pt, double beta);

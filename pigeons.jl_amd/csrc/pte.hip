@@ -33,7 +33,9 @@ struct Snapshot {   // reduced recorders of the last round, host side
     std::vector<double> lsr_up, lsr_dn; std::vector<int64_t> lsr_n;
     int64_t restarts = 0, trips = 0;
     std::vector<double> acc_mean, steps_sum; std::vector<int64_t> acc_n, steps_n;
-    std::vector<double> on_mean, on_var; int64_t on_n = 0;
+    std::vector<double> on_mean, on_var; int64_t on_n = 0;   // d + 1 entries: [state; log density]
+    std::vector<double> eac_cor, eac_raw; std::vector<int64_t> eac_n;   // energy_ac1 per local chain
+    std::vector<double> traces; int64_t traces_n = 0;        // [scan][d+1]
     std::vector<int32_t> ip_chain, ip_replica;   // [scan][slot]
     int64_t n_scans = 0;
 };
@@ -165,8 +167,10 @@ int reset_recorders(pte_engine *h) {
     HIP_OK(h, hipMemsetAsync(e.am_rev_sum, 0, sizeof(double) * N, h->stream));
     HIP_OK(h, hipMemsetAsync(e.am_rev_n, 0, sizeof(int64_t) * N, h->stream));
     const int64_t dd = h->d > 0 ? h->d : 1;
-    HIP_OK(h, hipMemsetAsync(e.on_mean, 0, sizeof(double) * dd, h->stream));
-    HIP_OK(h, hipMemsetAsync(e.on_m2, 0, sizeof(double) * dd, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.on_mean, 0, sizeof(double) * (h->d + 1), h->stream));
+    HIP_OK(h, hipMemsetAsync(e.on_m2, 0, sizeof(double) * (h->d + 1), h->stream));
+    HIP_OK(h, hipMemsetAsync(e.eac, 0, sizeof(double) * 5 * N, h->stream));
+    HIP_OK(h, hipMemsetAsync(e.eac_n, 0, sizeof(int64_t) * N, h->stream));
     HIP_OK(h, hipMemsetAsync(e.on_n, 0, sizeof(int64_t), h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));   // `ninf` must outlive the copies
     h->scans_in_round = 0;
@@ -215,6 +219,10 @@ void time_collect(pte_engine *h) {
 int launch_explore(pte_engine *h, int64_t scan) {
     (void)scan;
     const int64_t N = h->K;
+    if ((h->cfg.record_flags & PTE_RECORD_TRACES) && h->scans_in_round >= h->cfg.max_scans_per_round)
+        return fail(h, "traces buffer full: %lld scans since the last pte_reduce (max_scans_per_round = %lld)",
+                    (long long)h->scans_in_round, (long long)h->cfg.max_scans_per_round);
+    h->dev.trace_idx = h->scans_in_round;
     switch (h->cfg.explorer) {
     case PTE_EXPLORER_NONE: return 0;
     case PTE_EXPLORER_TOY:
@@ -432,7 +440,9 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.rt_trips, (size_t)K);
     rc |= dev_alloc(h, &e.expl_acc_sum, (size_t)K);   rc |= dev_alloc(h, &e.expl_acc_n, (size_t)K);
     rc |= dev_alloc(h, &e.expl_steps_sum, (size_t)K); rc |= dev_alloc(h, &e.expl_steps_n, (size_t)K);
-    rc |= dev_alloc(h, &e.on_mean, (size_t)dd);   rc |= dev_alloc(h, &e.on_m2, (size_t)dd);
+    rc |= dev_alloc(h, &e.on_mean, (size_t)(d + 1));   rc |= dev_alloc(h, &e.on_m2, (size_t)(d + 1));
+    rc |= dev_alloc(h, &e.eac, (size_t)(5 * K)); rc |= dev_alloc(h, &e.eac_n, (size_t)K);
+    rc |= dev_alloc(h, &e.traces, (cfg->record_flags & PTE_RECORD_TRACES) ? (size_t)(cfg->max_scans_per_round * (d + 1)) : 1, false);
     rc |= dev_alloc(h, &e.on_n, 1);
     const int64_t ipcap = (cfg->record_flags & PTE_RECORD_INDEX_PROCESS) ? cfg->max_scans_per_round * K : 1;
     rc |= dev_alloc(h, &e.index_process, (size_t)ipcap, false);
@@ -590,14 +600,19 @@ int pte_reduce(pte_engine *h) {
     s.acc_mean.assign(K, 0.0); s.acc_n.assign(K, 0); s.steps_sum.assign(K, 0.0); s.steps_n.assign(K, 0);
     const int64_t dd = d > 0 ? d : 1;
     std::vector<double> m2(dd);
-    s.on_mean.assign(dd, 0.0); s.on_var.assign(dd, 0.0);
+    s.on_mean.assign(d + 1, 0.0); s.on_var.assign(d + 1, 0.0); m2.assign(d + 1, 0.0);
+    s.eac_raw.assign(5 * K, 0.0); s.eac_n.assign(K, 0); s.eac_cor.assign(K, NAN);
 #define D2H(dst, src, n) HIP_OK(h, hipMemcpyAsync(dst, src, sizeof(*(dst)) * (n), hipMemcpyDeviceToHost, h->stream))
     D2H(swap_sum.data(), e.swap_sum, K); D2H(s.swap_n.data(), e.swap_n, K);
     D2H(s.lsr_up.data(), e.lsr_up, K);   D2H(s.lsr_dn.data(), e.lsr_dn, K);   D2H(s.lsr_n.data(), e.lsr_n, K);
     D2H(rs.data(), e.rt_restarts, K);     D2H(rr.data(), e.rt_trips, K);
     D2H(acc_sum.data(), e.expl_acc_sum, K); D2H(s.acc_n.data(), e.expl_acc_n, K);
     D2H(s.steps_sum.data(), e.expl_steps_sum, K); D2H(s.steps_n.data(), e.expl_steps_n, K);
-    D2H(s.on_mean.data(), e.on_mean, dd); D2H(m2.data(), e.on_m2, dd); D2H(&s.on_n, e.on_n, 1);
+    D2H(s.on_mean.data(), e.on_mean, d + 1); D2H(m2.data(), e.on_m2, d + 1); D2H(&s.on_n, e.on_n, 1);
+    D2H(s.eac_raw.data(), e.eac, 5 * K); D2H(s.eac_n.data(), e.eac_n, K);
+    s.traces_n = (h->cfg.record_flags & PTE_RECORD_TRACES) && h->c0 + K == h->N ? h->scans_in_round : 0;
+    s.traces.assign((size_t)(s.traces_n * (d + 1)), 0.0);
+    if (s.traces_n > 0) D2H(s.traces.data(), e.traces, (size_t)(s.traces_n * (d + 1)));
     std::vector<double> fsum(K), rsum(K);
     h->fac_mean.assign(K, 0.0); h->rev_mean.assign(K, 0.0); h->fac_n.assign(K, 0); h->rev_n.assign(K, 0);
     D2H(fsum.data(), e.am_fac_sum, K); D2H(h->fac_n.data(), e.am_fac_n, K);
@@ -617,7 +632,9 @@ int pte_reduce(pte_engine *h) {
     s.restarts = 0; s.trips = 0;
     for (int64_t i = 0; i < K; ++i) { s.restarts += rs[i]; s.trips += rr[i]; }
     for (int64_t i = 0; i < K; ++i) s.acc_mean[i] = s.acc_n[i] > 0 ? acc_sum[i] / (double)s.acc_n[i] : 0.0;
-    for (int64_t i = 0; i < dd; ++i) s.on_var[i] = s.on_n > 1 ? m2[i] / (double)(s.on_n - 1) : 1.0;
+    for (int64_t i = 0; i <= d; ++i) s.on_var[i] = s.on_n > 1 ? m2[i] / (double)(s.on_n - 1) : 1.0;
+    for (int64_t i = 0; i < K; ++i)       // cor(CovMatrix)[1,2]: the Bessel factors cancel
+        if (s.eac_n[i] > 1) s.eac_cor[i] = s.eac_raw[5 * i + 3] / std::sqrt(s.eac_raw[5 * i + 2] * s.eac_raw[5 * i + 4]);
     for (int64_t i = 0; i < K; ++i) {
         h->fac_mean[i] = h->fac_n[i] > 0 ? fsum[i] / (double)h->fac_n[i] : 0.0;
         h->rev_mean[i] = h->rev_n[i] > 0 ? rsum[i] / (double)h->rev_n[i] : 0.0;
@@ -694,6 +711,27 @@ int pte_get_online(const pte_engine *h, double *mean, double *variance, int64_t 
     if (!h) return 1;
     for (int64_t i = 0; i < h->d; ++i) { mean[i] = h->snap.on_mean[i]; variance[i] = h->snap.on_var[i]; }
     if (n) *n = h->snap.on_n;
+    return 0;
+}
+int pte_get_online_log_density(const pte_engine *h, double *mean, double *variance) {
+    if (!h || !mean || !variance) return 1;
+    *mean = h->snap.on_mean.size() > (size_t)h->d ? h->snap.on_mean[h->d] : 0.0;
+    *variance = h->snap.on_var.size() > (size_t)h->d ? h->snap.on_var[h->d] : 0.0;
+    return 0;
+}
+int pte_get_energy_ac1(const pte_engine *h, double *cor, int64_t *n, double *moments) {
+    if (!h) return 1;
+    for (int64_t i = 0; i < h->K && (size_t)i < h->snap.eac_n.size(); ++i) {
+        if (cor) cor[i] = h->snap.eac_cor[i];
+        if (n) n[i] = h->snap.eac_n[i];
+        if (moments) for (int k = 0; k < 5; ++k) moments[5 * i + k] = h->snap.eac_raw[5 * i + k];
+    }
+    return 0;
+}
+int pte_get_traces(const pte_engine *h, double *out, int64_t *n_scans) {
+    if (!h || !n_scans) return 1;
+    *n_scans = h->snap.traces_n;
+    if (out && !h->snap.traces.empty()) std::memcpy(out, h->snap.traces.data(), sizeof(double) * h->snap.traces.size());
     return 0;
 }
 int pte_get_replica_ids(const pte_engine *hc, int64_t *out) {

@@ -132,16 +132,20 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
 
     double x[E];
     if (c == 0 && e.N > 1) {
-        iid_refresh<NLU>(e, slot, e.sd[0], lane);        // sample_iid! at the reference (pigeons.jl:104-105)
+        const double lp0 = lp_before_explore(e, c, slot);
+        const double S0 = iid_refresh<NLU>(e, slot, e.sd[0], lane);   // sample_iid! at the reference (pigeons.jl:104-105)
         __threadfence_block();
+        double l20 = 0.0;
         if (TGT == TGT_FUNNEL) {
 #pragma unroll
             for (int j = 0; j < E; ++j) x[j] = T.valid(j) ? xrow[64 * j + lane] : 0.0;
-            const double l2 = T.funnel(x, nullptr);
-            if (lane == 0) e.suff2[slot] = l2;
+            l20 = T.funnel(x, nullptr);
+            if (lane == 0) e.suff2[slot] = l20;
         }
+        record_after_explore(e, cl, c, slot, lane, lp0, S0, l20);
         return;
     }
+    const double lp_before = lp_before_explore(e, c, slot);
 #pragma unroll
     for (int j = 0; j < E; ++j) x[j] = T.valid(j) ? xrow[64 * j + lane] : 0.0;
 
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         e.am_fac_sum[cl] += fac_sum;               e.am_fac_n[cl] += fac_n;
         e.am_rev_sum[cl] += (double)rev_sum;       e.am_rev_n[cl] += rev_n;
     }
-    if (c == e.N - 1 && (e.record_flags & 4u)) { __threadfence_block(); record_online(e, slot, lane); }
+    record_after_explore(e, cl, c, slot, lane, lp_before, S, l2);
 }
 
 }  // namespace pte

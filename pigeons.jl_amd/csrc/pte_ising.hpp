@@ -53,6 +53,7 @@ __global__ __launch_bounds__(64) void k_explore_ising(EngineDev e, IsingParams i
     double *xrow = e.x + (int64_t)slot * e.ld;
     uint64_t seed = e.rng[2 * slot];
     const uint64_t gamma = e.rng[2 * slot + 1];
+    const double lp_before = lp_before_explore(e, c, slot);
 
     if (c == 0 && e.N > 1) {
         // iid_bernoulli!: site s (row-major, i outer / j inner) <- rand(rng, Bool) = low bit of draw s+1
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(64) void k_explore_ising(EngineDev e, IsingParams i
         const long long spp = ising_recompute(spins, L, lane);
         for (int s = lane; s < d; s += 64) xrow[s] = spins[s] ? 1.0 : 0.0;
         if (lane == 0) { e.suff[slot] = (double)spp; e.rng[2 * slot] = seed; }
+        record_after_explore(e, cl, c, slot, lane, lp_before, (double)spp, 0.0);
         return;
     }
     for (int s = lane; s < d; s += 64) spins[s] = xrow[s] != 0.0 ? 1 : 0;
@@ -126,6 +128,7 @@ __global__ __launch_bounds__(64) void k_explore_ising(EngineDev e, IsingParams i
     if (lane == 0) printf("bytes c=%d spp=%lld\n", (int)c, spp);
 #endif
     if (lane == 0) { e.suff[slot] = (double)spp; e.rng[2 * slot] = seed + (uint64_t)p * gamma; }
+    record_after_explore(e, cl, c, slot, lane, lp_before, (double)spp, 0.0);
 }
 
 }  // namespace pte
@@ -151,6 +154,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
     double *xrow = e.x + (int64_t)slot * e.ld;
     uint64_t seed = e.rng[2 * slot];
     const uint64_t gamma = e.rng[2 * slot + 1];
+    const double lp_before = lp_before_explore(e, c, slot);
 
     if (c == 0 && e.N > 1) {
         for (int wd = lane; wd < NW; wd += 64) {
@@ -252,6 +256,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
     if (lane == 0) printf("bits c=%d spp=%lld\n", (int)c, spp);
 #endif
     if (lane == 0) { e.suff[slot] = (double)spp; e.rng[2 * slot] = seed; }
+    record_after_explore(e, cl, c, slot, lane, lp_before, (double)spp, 0.0);
 }
 
 }  // namespace pte

@@ -46,7 +46,9 @@ struct EngineDev {
     int64_t *rt_state; int64_t *rt_restarts; int64_t *rt_trips;   // [slot] round_trip
     double *expl_acc_sum; int64_t *expl_acc_n;             // [chain] explorer_acceptance_pr
     double *expl_steps_sum; int64_t *expl_steps_n;         // [chain] explorer_n_steps
-    double *on_mean; double *on_m2; int64_t *on_n;         // [d],[d],[1] target-chain online stats
+    double *on_mean; double *on_m2; int64_t *on_n;         // [d+1],[d+1],[1] target-chain online stats of [state; log density]
+    double *eac; int64_t *eac_n;                           // [5K],[K] energy_ac1: Welford (mean before, mean after, C_bb, C_ba, C_aa) per local chain
+    double *traces; int64_t trace_idx;                     // [max_scans][d+1] target-chain [state; log density]; row of the current scan
     int32_t *index_process;                                // [scan][slot]
     int32_t *error;                                        // [4] code, chain, coordinate, spare
     uint32_t record_flags;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(64) void k_init(EngineDev e, uint64_t master_seed, 
 // reference src/targets/toy_mvn_target.jl:15-21, src/explorers/ToyExplorer.jl:7-12) fused with
 // the evaluation of its swap statistic.
 template <int NLU>
-__device__ __forceinline__ void iid_refresh(const EngineDev &e, int slot, double sd, int lane) {
+__device__ __forceinline__ double iid_refresh(const EngineDev &e, int slot, double sd, int lane) {
     SeqRng r{e.rng[2 * slot], e.rng[2 * slot + 1]};
     double *xrow = e.x + (int64_t)slot * e.ld;
     const int B = (int)((e.d + 63) >> 6);
@@ -114,20 +116,72 @@ __device__ __forceinline__ void iid_refresh(const EngineDev &e, int slot, double
     }
     double S = upper_tree_root<NLU>(BS);
     if (lane == 0) { e.suff[slot] = S; e.rng[2 * slot] = r.seed; }
+    return S;
 }
 
 // Target-chain online statistics (reference src/pt/pigeons.jl:110-115,
-// src/recorders/OnlineStateRecorder.jl:87-96): per-coordinate Welford mean / M2.
-__device__ __forceinline__ void record_online(const EngineDev &e, int slot, int lane) {
+// src/recorders/OnlineStateRecorder.jl:87-96): per-coordinate Welford mean / M2 of the recorded sample
+// extract_sample(state::Array, lp) = [state; lp(state)] (src/pt/state.jl:79), so d + 1 entries.
+__device__ __forceinline__ void record_online(const EngineDev &e, int slot, int lane, double lp) {
     const double *xrow = e.x + (int64_t)slot * e.ld;
     int64_t n = e.on_n[0] + 1;
-    for (int64_t i = lane; i < e.d; i += 64) {
-        double v = xrow[i], mu = e.on_mean[i];
+    for (int64_t i = lane; i <= e.d; i += 64) {
+        double v = (i < e.d) ? xrow[i] : lp, mu = e.on_mean[i];
         double mu2 = mu + (v - mu) / (double)n;
         e.on_m2[i] += (v - mu) * (v - mu2);
         e.on_mean[i] = mu2;
     }
     if (lane == 0) e.on_n[0] = n;
+}
+
+// log_potentials[chain](state) from the swap statistics: S = sum x^2 (Ising: sum_pair_products), l2 = the
+// target log density of an interpolated path.  Same expressions as swap_log_ratio below.
+__device__ __forceinline__ double chain_lp(const EngineDev &e, int64_t c, double S, double l2) {
+    if (e.target == 2 || e.target == 3) {
+        const double ref = (e.target == 2) ? e.ref_nhp * S : 0.0 * S;
+        const double tgt = (e.target == 2) ? l2 : e.ising_beta * S;
+        const double b = e.beta[c];
+        return b == 0.0 ? ref : (b == 1.0 ? tgt : (1.0 - b) * ref + b * tgt);
+    }
+    return e.nhp[c] * S;
+}
+// explore!'s bookkeeping around the explorer (reference src/pt/pigeons.jl:101-143):
+//   before = eval_if_ac_requested  -> lp_before_explore at kernel entry (from the statistics of the last scan)
+//   process_ac! / :online / :traces -> record_after_explore at kernel exit, all lanes, S and l2 in registers
+__device__ __forceinline__ double lp_before_explore(const EngineDev &e, int64_t c, int slot) {
+    return (e.record_flags & 16u) ? chain_lp(e, c, e.suff[slot], e.suff2[slot]) : 0.0;
+}
+__device__ __forceinline__ void record_after_explore(const EngineDev &e, int64_t cl, int64_t c, int slot, int lane,
+                                                     double lp_before, double S, double l2) {
+    const unsigned f = e.record_flags;
+    if (!(f & (4u | 8u | 16u))) return;
+    const double lp = chain_lp(e, c, S, l2);
+    if ((f & 16u) && lane == 0) {                         // energy_ac1: (chain, SVector(before, after)) -> CovMatrix(2)
+        double *o = e.eac + 5 * cl;
+        const int64_t n = e.eac_n[cl] + 1;
+        const double db = lp_before - o[0], da = lp - o[1];
+        const double mb = o[0] + db / (double)n, ma = o[1] + da / (double)n;
+        o[2] += db * (lp_before - mb); o[3] += db * (lp - ma); o[4] += da * (lp - ma);
+        o[0] = mb; o[1] = ma; e.eac_n[cl] = n;
+    }
+    if (c == e.N - 1 && (f & (4u | 8u))) {
+        __threadfence_block();
+        if (f & 4u) record_online(e, slot, lane, lp);
+        if (f & 8u) {                                      // traces[(chain, scan)] = [state; lp]
+            const double *xrow = e.x + (int64_t)slot * e.ld;
+            double *row = e.traces + e.trace_idx * (e.d + 1);
+            for (int64_t i = lane; i < e.d; i += 64) row[i] = xrow[i];
+            if (lane == 0) row[e.d] = lp;
+        }
+    }
+}
+
+// the same at a chain of the MVN path, with explore!'s recorders around it
+template <int NLU>
+__device__ __forceinline__ void iid_refresh_recorded(const EngineDev &e, int64_t cl, int64_t c, int slot, double sd, int lane) {
+    const double lp0 = lp_before_explore(e, c, slot);
+    const double S = iid_refresh<NLU>(e, slot, sd, lane);
+    record_after_explore(e, cl, c, slot, lane, lp0, S, 0.0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -141,8 +195,7 @@ __global__ __launch_bounds__(64) void k_explore_toy(EngineDev e) {
     if (cl >= e.K) return;
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];
-    iid_refresh<NLU>(e, slot, e.sd[c], lane);
-    if (c == e.N - 1 && (e.record_flags & 4u)) { __threadfence_block(); record_online(e, slot, lane); }
+    iid_refresh_recorded<NLU>(e, cl, c, slot, e.sd[c], lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -215,9 +268,10 @@ __global__ __launch_bounds__(64) void k_explore_slice(EngineDev e, SliceParams s
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];
     if (c == 0 && e.N > 1) {
-        iid_refresh<NLU>(e, slot, e.sd[0], lane);
+        iid_refresh_recorded<NLU>(e, cl, c, slot, e.sd[0], lane);
         return;
     }
+    const double lp_before = lp_before_explore(e, c, slot);
     const int64_t d = e.d;
     double *xrow = e.x + (int64_t)slot * e.ld;
     const int B = (int)((d + 63) >> 6);
@@ -339,7 +393,7 @@ __global__ __launch_bounds__(64) void k_explore_slice(EngineDev e, SliceParams s
         e.expl_steps_sum[cl] += steps_sum; e.expl_steps_n[cl] += steps_n;
         e.expl_acc_sum[cl] += acc_sum;     e.expl_acc_n[cl] += acc_n;
     }
-    if (c == e.N - 1 && (e.record_flags & 4u)) { __threadfence_block(); record_online(e, slot, lane); }
+    record_after_explore(e, cl, c, slot, lane, lp_before, S, 0.0);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -56,9 +56,10 @@ __global__ __launch_bounds__(64) void k_explore_slice7(EngineDev e, SliceParams 
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];
     if (c == 0 && e.N > 1) {
-        iid_refresh<NLU>(e, slot, e.sd[0], lane);
+        iid_refresh_recorded<NLU>(e, cl, c, slot, e.sd[0], lane);
         return;
     }
+    const double lp_before = lp_before_explore(e, c, slot);
     const int64_t d = e.d;
     double *xrow = e.x + (int64_t)slot * e.ld;
     const int B = (int)((d + 63) >> 6);
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(64) void k_explore_slice7(EngineDev e, SliceParams 
         for (int i = 0; i < 8; ++i) e.on_m2[8 * cl + i] += (double)prof[i];   // debug builds only (needs d >= 8K)
 #endif
     }
-    if (c == e.N - 1 && (e.record_flags & 4u)) { __threadfence_block(); record_online(e, slot, lane); }
+    record_after_explore(e, cl, c, slot, lane, lp_before, S, 0.0);
 }
 
 }  // namespace pte

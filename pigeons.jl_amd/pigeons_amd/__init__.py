@@ -11,7 +11,8 @@ from .pt import (Inputs, PT, pigeons, toy_mvn_target, ScaledPrecisionNormalPath,
                  SliceSampler, ToyExplorer, AutoMALA, Funnel, IsingLogPotential, IsingMetropolis, ScaledPrecisionNormalLogPotential,
                  IdentityPreconditioner, DiagonalPreconditioner, MixDiagonalPreconditioner,
                  record_default, record_online,
-                 log_sum_ratio, swap_acceptance_pr, round_trip, index_process, online,
+                 log_sum_ratio, swap_acceptance_pr, round_trip, index_process, online, traces, energy_ac1,
+                 energy_ac1s, sample_array, sample_names, get_sample, mean, var,
                  timing_extrema, allocation_extrema, explorer_acceptance_pr, explorer_n_steps,
                  stepping_stone, stepping_stone_pair, n_round_trips, n_tempered_restarts,
                  global_barrier, last_round_max_time, analytic_lognormalization,

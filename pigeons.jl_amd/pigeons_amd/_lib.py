@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(PKG_ROOT, "lib", "libpte.so")
 
 TARGET_MVN_SCALED_PRECISION, TARGET_TEST_SWAPPER, TARGET_FUNNEL, TARGET_ISING = 0, 1, 2, 3
 EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA, EXPLORER_ISING_METROPOLIS = 0, 1, 2, 3, 4
-RECORD_ROUND_TRIP, RECORD_INDEX_PROCESS, RECORD_ONLINE = 1, 2, 4
+RECORD_ROUND_TRIP, RECORD_INDEX_PROCESS, RECORD_ONLINE, RECORD_TRACES, RECORD_ENERGY_AC1 = 1, 2, 4, 8, 16
 ABI_VERSION = 1
 
 
@@ -51,6 +51,7 @@ EXPORTS = [
     "pte_boundary_export", "pte_boundary_import", "pte_get_index_process_shard", "pte_get_replica_ids",
     "pte_get_stream", "pte_shard_message_bytes", "pte_shard_set_buffers", "pte_shard_scan_begin",
     "pte_shard_scan_finish", "pte_shard_sync",
+    "pte_get_online_log_density", "pte_get_energy_ac1", "pte_get_traces",
 ]
 
 _lib = None
@@ -110,6 +111,9 @@ def load():
     L.pte_get_index_process_shard.argtypes = [vp, ip, ip, ip]
     L.pte_get_replica_ids.argtypes = [vp, ip]
     L.pte_boundary_payload_bytes.restype = C.c_int64
+    L.pte_get_online_log_density.argtypes = [vp, dp, dp]
+    L.pte_get_energy_ac1.argtypes = [vp, dp, ip, dp]
+    L.pte_get_traces.argtypes = [vp, dp, ip]
     L.pte_get_stream.argtypes = [vp]
     L.pte_get_stream.restype = C.c_void_p
     L.pte_shard_message_bytes.argtypes = [vp]

@@ -195,6 +195,27 @@ class Engine:
         self._chk(self.L.pte_get_online(self.h, _dp(m), _dp(v), _ip(n)))
         return m[:self.d], v[:self.d], int(n[0])
 
+    def online_log_density(self):
+        """(mean, variance) of the last entry of the `online` sample [state; log density] (src/pt/state.jl:79)."""
+        m = np.zeros(1); v = np.zeros(1)
+        self._chk(self.L.pte_get_online_log_density(self.h, _dp(m), _dp(v)))
+        return float(m[0]), float(v[0])
+
+    def energy_ac1(self):
+        """energy_ac1s of the local chains: (cor[K], n[K], moments[K,5])."""
+        cor = np.zeros(self.K); n = np.zeros(self.K, dtype=np.int64); mom = np.zeros((self.K, 5))
+        self._chk(self.L.pte_get_energy_ac1(self.h, _dp(cor), _ip(n), _dp(mom)))
+        return cor, n, mom
+
+    def traces(self):
+        """[scan][d+1] = [state; log density] of the target chain over the last round (empty off the target shard)."""
+        n = np.zeros(1, dtype=np.int64)
+        self._chk(self.L.pte_get_traces(self.h, None, _ip(n)))
+        out = np.zeros((int(n[0]), self.d + 1))
+        if n[0]:
+            self._chk(self.L.pte_get_traces(self.h, _dp(out), _ip(n)))
+        return out
+
     # --- replica fields
     def states(self):
         x = np.zeros((self.K, max(self.d, 1)))

@@ -145,6 +145,8 @@ def swap_acceptance_pr(): return "swap_acceptance_pr"
 def round_trip(): return "round_trip"
 def index_process(): return "index_process"
 def online(): return "online"
+def traces(): return "traces"
+def energy_ac1(): return "energy_ac1"
 def timing_extrema(): return "timing_extrema"
 def allocation_extrema(): return "allocation_extrema"
 def explorer_acceptance_pr(): return "explorer_acceptance_pr"
@@ -157,8 +159,8 @@ def record_default():
 
 
 def record_online():
-    """src/pt/Inputs.jl:116-123 (energy_ac1 is not provided by the device engine)"""
-    return [log_sum_ratio, timing_extrema, allocation_extrema, round_trip, online]
+    """src/pt/Inputs.jl:116-123"""
+    return [log_sum_ratio, timing_extrema, allocation_extrema, round_trip, energy_ac1, online]
 
 
 @dataclass
@@ -205,6 +207,9 @@ class ReducedRecorders:
     am_factors: Any = None              # (mean[N], n[N])       src/explorers/AutoMALA.jl:277
     reversibility_rate: Any = None      # (mean[N], n[N])       src/explorers/AutoMALA.jl:294
     online: Any = None                  # (mean[d], var[d], n)
+    online_log_density: Any = None      # (mean, var): entry d+1 of the online sample [state; log density]
+    energy_ac1: Any = None              # (cor[N], n[N], moments[N,5]) keyed by chain      recorder.jl:113
+    traces: Any = None                  # float64 [scan][d+1], target chain               recorder.jl:27
     timing_extrema: Any = None          # {"round": seconds}
 
 
@@ -250,6 +255,12 @@ class PT:
             flags |= _lib.RECORD_INDEX_PROCESS
         if "online" in names:
             flags |= _lib.RECORD_ONLINE
+        if "traces" in names:
+            if getattr(inputs, "extended_traces", False):
+                raise NotImplementedError("extended_traces: the device engine records the target chain only")
+            flags |= _lib.RECORD_TRACES
+        if "energy_ac1" in names:
+            flags |= _lib.RECORD_ENERGY_AC1
         kw = dict(device=inputs.device, n_chains=N, seed=inputs.seed, record_flags=flags,
                   max_scans_per_round=2 ** inputs.n_rounds)
         if isinstance(target, ScaledPrecisionNormalPath):
@@ -338,6 +349,9 @@ def reduce_recorders(pt, elapsed=None):
         explorer_acceptance_pr=(am, an),
         explorer_n_steps=(ss, sn),
         online=eng.online(),
+        online_log_density=eng.online_log_density(),
+        energy_ac1=eng.energy_ac1(),
+        traces=eng.traces(),
         timing_extrema={"round": elapsed},
     )
     return r
@@ -387,6 +401,47 @@ def stepping_stone_pair(pt):
 
 def stepping_stone(pt):
     return T.stepping_stone(stepping_stone_pair(pt))
+
+
+def energy_ac1s(pt, skip_reference=False):
+    """src/recorders/recorder.jl:156-173: autocorrelation of the log density before / after an exploration
+    step, one entry per chain."""
+    cor = np.asarray(pt.reduced_recorders.energy_ac1[0])
+    return cor[1:] if (skip_reference and pt.inputs.n_chains > 1) else cor
+
+
+def sample_names(pt):
+    """src/pt/state.jl:60-63,91"""
+    d = pt.replicas.d
+    return ["param_%d" % (i + 1) for i in range(d)] + ["log_density"]
+
+
+def sample_array(pt):
+    """src/pt/process_sample.jl:19-32: [iteration, variable, target chain] of the last round's traces."""
+    tr = pt.reduced_recorders.traces
+    if tr is None or tr.size == 0:
+        raise ValueError("no traces recorded: pass record=[traces]")
+    return tr[:, :, None].copy()
+
+
+def get_sample(pt, chain=None, scan=None):
+    """src/pt/process_sample.jl get_sample(pt, chain[, scan]) for the target chain (1-based scan)."""
+    if chain is not None and chain != pt.inputs.n_chains:
+        raise ValueError("traces are recorded for the target chain only (extended_traces is not available)")
+    tr = pt.reduced_recorders.traces
+    return tr if scan is None else tr[scan - 1]
+
+
+def mean(pt):
+    """Statistics.mean(pt) (src/recorders/OnlineStateRecorder.jl:16): online mean of [state; log density]."""
+    r = pt.reduced_recorders
+    return np.concatenate([r.online[0], [r.online_log_density[0]]])
+
+
+def var(pt):
+    """Statistics.var(pt) (src/recorders/OnlineStateRecorder.jl:21)."""
+    r = pt.reduced_recorders
+    return np.concatenate([r.online[1], [r.online_log_density[1]]])
 
 
 def n_round_trips(pt):

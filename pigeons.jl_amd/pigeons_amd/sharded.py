@@ -49,16 +49,24 @@ def combine_reduced(parts, N, d):
     fm = cat([p["automala"][0] for p in parts]); fn = cat([p["automala"][1] for p in parts])
     rm = cat([p["automala"][2] for p in parts]); rn = cat([p["automala"][3] for p in parts])
     online = parts[-1]["online"]            # the last shard owns the target chain
+    eac = None
+    if all("eac" in p for p in parts):
+        eac = (cat([p["eac"][0] for p in parts]), cat([p["eac"][1] for p in parts]),
+               np.concatenate([np.asarray(p["eac"][2]).reshape(-1, 5) for p in parts]))
     return ReducedRecorders(swap_acceptance_pr=(sw_m, sw_n), log_sum_ratio=(up, un, dn, dnn),
                             round_trip=(restarts, trips), index_process=ip,
                             explorer_acceptance_pr=(am, an), explorer_n_steps=(ss, sn), online=online,
                             am_factors=(fm, fn), reversibility_rate=(rm, rn),
+                            online_log_density=parts[-1].get("online_lp"), energy_ac1=eac, traces=parts[-1].get("traces"),
                             timing_extrema={"round": None})
 
 
 def local_reduced(eng):
     eng.reduce()
-    return {"swap": eng.swap_acceptance(), "lsr": eng.log_sum_ratio(), "round_trip": eng.round_trip(),
+    extra = {}
+    if hasattr(eng, "energy_ac1") and hasattr(eng, "online_log_density"):
+        extra = {"eac": eng.energy_ac1(), "online_lp": eng.online_log_density(), "traces": eng.traces()}
+    return {**extra, "swap": eng.swap_acceptance(), "lsr": eng.log_sum_ratio(), "round_trip": eng.round_trip(),
             "explorer": eng.explorer_stats(), "ip": eng.index_process_shard(), "online": eng.online(),
             "automala": eng.automala_stats() if hasattr(eng, "automala_stats") else tuple(np.zeros(eng.K) for _ in range(4))}
 

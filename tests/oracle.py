@@ -30,6 +30,7 @@ class Config(C.Structure):
         ("record_round_trip", C.c_int32), ("record_index_process", C.c_int32),
         ("record_online", C.c_int32), ("n_threads", C.c_int32),
         ("rank", C.c_int32), ("world_size", C.c_int32),
+        ("record_traces", C.c_int32), ("record_energy_ac1", C.c_int32),
     ]
 
 
@@ -97,6 +98,12 @@ def lib():
     L.po_get_am_stats.argtypes = [C.c_void_p, dp, ip, dp, ip]
     L.po_get_online.restype = C.c_int64
     L.po_get_online.argtypes = [C.c_void_p, dp, dp]
+    L.po_get_online_lp.restype = None
+    L.po_get_online_lp.argtypes = [C.c_void_p, dp, dp, ip]
+    L.po_get_energy_ac1.restype = None
+    L.po_get_energy_ac1.argtypes = [C.c_void_p, dp, ip, dp]
+    L.po_get_traces.restype = C.c_int64
+    L.po_get_traces.argtypes = [C.c_void_p, dp]
     L.po_get_stepping_stone.argtypes = [C.c_void_p, dp]
     L.po_get_global_barrier.restype = C.c_double
     L.po_get_global_barrier.argtypes = [C.c_void_p]
@@ -264,6 +271,24 @@ class OraclePT:
         n = self.L.po_get_online(self.h, _dp(m), _dp(v))
         return m[:self.d], v[:self.d], int(n)
 
+    def online_lp(self):
+        m = np.zeros(1); v = np.zeros(1); n = np.zeros(1, dtype=np.int64)
+        self.L.po_get_online_lp(self.h, _dp(m), _dp(v), _ip(n))
+        return float(m[0]), float(v[0]), int(n[0])
+
+    def energy_ac1(self):
+        """(cor[N], n[N], raw[N,5] = b0, b1, A00, A01, A11)"""
+        cor = np.zeros(self.N); n = np.zeros(self.N, dtype=np.int64); raw = np.zeros((self.N, 5))
+        self.L.po_get_energy_ac1(self.h, _dp(cor), _ip(n), _dp(raw))
+        return cor, n, raw
+
+    def traces(self):
+        n = int(self.L.po_get_traces(self.h, None))
+        out = np.zeros((n, self.d + 1))
+        if n:
+            self.L.po_get_traces(self.h, _dp(out))
+        return out
+
     def stepping_stone_pair(self):
         p = np.zeros(2)
         self.L.po_get_stepping_stone(self.h, _dp(p))
@@ -307,6 +332,8 @@ class OracleShard(OraclePT):
             kw["record_round_trip"] = 1 if flags & 1 else 0
             kw["record_index_process"] = 1 if flags & 2 else 0
             kw["record_online"] = 1 if flags & 4 else 0
+            kw["record_traces"] = 1 if flags & 8 else 0
+            kw["record_energy_ac1"] = 1 if flags & 16 else 0
         kw.pop("device", None); kw.pop("max_scans_per_round", None)
         super().__init__(rank=rank, world_size=world_size, **kw)
         a = np.zeros(3, dtype=np.int64)
@@ -351,6 +378,13 @@ class OracleShard(OraclePT):
     def explorer_stats(self):
         sl = slice(self.c0, self.c0 + self.K)
         return tuple(a[sl] for a in super().explorer_stats())
+
+    def energy_ac1(self):
+        sl = slice(self.c0, self.c0 + self.K)
+        return tuple(a[sl] for a in super().energy_ac1())
+
+    def online_log_density(self):
+        return self.online_lp()[:2]
 
     def index_process_shard(self):
         n = int(self.L.po_shard_index_process(self.h, None, None)) if False else None

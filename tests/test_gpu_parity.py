@@ -588,3 +588,102 @@ def test_ising_bitpacked_kernel_equals_byte_kernel_and_oracle(P, L, N, monkeypat
         xs, cs, rs = x.replicas.states()
         xr, cr, rr = ref.states()
         assert np.array_equal(xs, xr) and np.array_equal(cs, cr) and np.array_equal(rs, rr)
+
+
+# ---------------------------------------------------------------------------------------------
+# target-chain sample recorders on the device -- traces ([state; log density]
+# per scan), online over the same d+1 entries, energy_ac1 (per-chain correlation of the log density
+# before / after explore!).
+# ---------------------------------------------------------------------------------------------
+def _check_sample_recorders(P, red, ref, rtol, N, exact_traces=True):
+    cor, cn, mom = red.energy_ac1
+    corr, cnr, rawr = ref.energy_ac1()
+    assert np.array_equal(cn, cnr)
+    ok = np.isfinite(corr)
+    np.testing.assert_allclose(cor[ok], corr[ok], rtol=max(rtol, 1e-7), atol=1e-9)   # A - b b' cancels ~1e3 * eps in the reference's form
+    np.testing.assert_allclose(mom[:, :2], rawr[:, :2], rtol=rtol)                   # running means of before / after
+    tr, trr = red.traces, ref.traces()
+    if trr.size:
+        assert tr.shape == trr.shape
+        if exact_traces:
+            np.testing.assert_allclose(tr, trr, rtol=1e-12, atol=1e-300)
+        else:
+            np.testing.assert_allclose(tr, trr, rtol=rtol, atol=1e-9)
+        lm, lv, ln = ref.online_lp()
+        if ln:
+            np.testing.assert_allclose(red.online_log_density, (lm, lv), rtol=max(rtol, 1e-9))
+
+
+@pytest.mark.parametrize("kind,N,d,rounds", [("slice", 6, 10, 6), ("slice", 5, 130, 4), ("toy", 7, 65, 5), ("slice", 1, 8, 5)])
+def test_traces_online_energy_ac1_parity_mvn(P, kind, N, d, rounds):
+    exp = {"toy": P.ToyExplorer(), "slice": P.SliceSampler()}[kind]
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.online, P.traces, P.energy_ac1]
+    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=exp, record=rec, show_report=False))
+    ref = O.OraclePT(n_chains=N, dim=d, explorer={"toy": O.EXPLORER_TOY, "slice": O.EXPLORER_SLICE}[kind], record_online=1,
+                     record_traces=1, record_energy_ac1=1)
+    for r in range(rounds):
+        assert P.next_round(pt)
+        red = P.run_one_round(pt); P.adapt(pt, red); pt.reduced_recorders = red
+        ref.run_round()
+        assert np.array_equal(red.index_process, ref.index_process())
+        _check_sample_recorders(P, red, ref, 1e-9, N)
+        # the reference's own assertions (test/test_traces.jl:16-27,50-58)
+        assert P.sample_array(pt).shape == (2 ** (r + 1), d + 1, 1)
+        assert len(P.sample_names(pt)) == d + 1 and "log_density" in P.sample_names(pt)
+        marginal = np.array([P.get_sample(pt, N, i + 1)[0] for i in range(2 ** (r + 1))])
+        assert abs(marginal.mean() - P.mean(pt)[0]) < 1e-10
+        assert np.array_equal(P.get_sample(pt, N)[:, 0], marginal)
+    assert len(P.energy_ac1s(pt)) == N and len(P.energy_ac1s(pt, True)) == max(N - 1, 1)
+
+
+@pytest.mark.parametrize("target,N,d,rounds,rtol", [("mvn", 5, 20, 6, 1e-9), ("funnel", 6, 8, 6, 1e-6), ("funnel", 4, 70, 4, 1e-6)])
+def test_traces_energy_ac1_parity_automala(P, target, N, d, rounds, rtol):
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.traces, P.energy_ac1]
+    if target == "mvn":
+        inp = P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=P.AutoMALA(), record=rec, show_report=False)
+        ref = O.OraclePT(n_chains=N, dim=d, explorer=O.EXPLORER_AUTOMALA, am_preconditioner=2, record_traces=1, record_energy_ac1=1)
+    else:
+        inp = P.Inputs(target=P.Funnel(d), reference=P.ScaledPrecisionNormalLogPotential(1.0 / 9.0, d), n_chains=N,
+                       n_rounds=rounds, explorer=P.AutoMALA(), record=rec, show_report=False)
+        ref = O.OraclePT(n_chains=N, dim=d, explorer=O.EXPLORER_AUTOMALA, target=O.TARGET_FUNNEL, p0=1.0 / 9.0, am_preconditioner=2,
+                         record_traces=1, record_energy_ac1=1)
+    pt = P.PT(inp)
+    for _ in range(rounds):
+        assert P.next_round(pt)
+        red = P.run_one_round(pt); P.adapt(pt, red)
+        ref.run_round()
+        assert np.array_equal(red.index_process, ref.index_process())
+        _check_sample_recorders(P, red, ref, rtol, N, exact_traces=False)
+
+
+def test_energy_ac1_parity_ising(P):
+    L, N, rounds = 8, 6, 6
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.energy_ac1]
+    pt = P.PT(P.Inputs(target=P.IsingLogPotential(0.6, L), n_chains=N, n_rounds=rounds, seed=2, record=rec, show_report=False))
+    ref = O.OraclePT(target=O.TARGET_ISING, explorer=O.EXPLORER_ISING, dim=L * L, p0=0.6, n_chains=N, seed=2, slice_n_passes=3,
+                     record_energy_ac1=1)
+    for _ in range(rounds):
+        assert P.next_round(pt)
+        red = P.run_one_round(pt); P.adapt(pt, red)
+        ref.run_round()
+        assert np.array_equal(red.index_process, ref.index_process())
+        cor, cn, mom = red.energy_ac1
+        corr, cnr, rawr = ref.energy_ac1()
+        assert np.array_equal(cn, cnr)
+        np.testing.assert_allclose(mom[:, :2], rawr[:, :2], rtol=1e-12, atol=1e-12)
+        ok = np.isfinite(corr)
+        np.testing.assert_allclose(cor[ok], corr[ok], rtol=1e-7, atol=1e-9)
+
+
+def test_sharded_traces_and_energy_ac1_equal_single_engine(P):
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.online, P.traces, P.energy_ac1]
+    mk = lambda: P.Inputs(target=P.toy_mvn_target(33), n_chains=8, n_rounds=4, explorer=P.SliceSampler(), record=rec, show_report=False)
+    one, many = P.PT(mk()), P.PT(mk(), n_shards=4, device_messages=True)
+    for _ in range(4):
+        assert P.next_round(one) and P.next_round(many)
+        ra = P.run_one_round(one); P.adapt(one, ra)
+        rb = P.run_one_round(many); P.adapt(many, rb)
+        assert np.array_equal(ra.traces, rb.traces)
+        for a, b in zip(ra.energy_ac1, rb.energy_ac1):
+            assert np.array_equal(a, b, equal_nan=True)
+        assert ra.online_log_density == rb.online_log_density

@@ -166,3 +166,43 @@ def test_threads_do_not_change_results():
     xa, ca, ra = a.states(); xb, cb, rb = b.states()
     assert np.array_equal(xa, xb) and np.array_equal(ca, cb) and np.array_equal(ra, rb)
     assert np.array_equal(a.index_process(), b.index_process())
+
+
+def test_traces_online_and_energy_ac1_recorders():
+    """SURVEY.md 8(f) rank 1.  Properties the reference's own tests assert (test/test_traces.jl:7-66):
+    sample matrix of the last round is (n_scans, d + 1); the mean of the traced marginal equals the online
+    mean (atol 1e-10); plus internal consistency of the restated OnlineStatsBase CovMatrix(2)."""
+    N, d = 6, 3
+    pt = O.OraclePT(n_chains=N, dim=d, seed=1, explorer=O.EXPLORER_SLICE, record_online=1, record_traces=1, record_energy_ac1=1)
+    for r in range(7):
+        pt.run_round()
+    tr = pt.traces()
+    assert tr.shape == (2 ** 7, d + 1)
+    np.testing.assert_allclose(tr[:, -1], -0.5 * 10.0 * np.sum(tr[:, :-1] ** 2, axis=1), rtol=1e-13)   # log_density column
+    m, v, n = pt.online()
+    assert n == 2 ** 7
+    np.testing.assert_allclose(m, tr[:, :-1].mean(axis=0), atol=1e-10)                                  # test_traces.jl:55
+    np.testing.assert_allclose(v, tr[:, :-1].var(axis=0, ddof=1), rtol=1e-10)
+    lm, lv, ln = pt.online_lp()
+    assert ln == 2 ** 7 and abs(lm - tr[:, -1].mean()) < 1e-10 and abs(lv - tr[:, -1].var(ddof=1)) < 1e-9
+    cor, cn, raw = pt.energy_ac1()
+    assert np.array_equal(cn, np.full(N, 2 ** 7))
+    assert np.all(np.abs(cor) <= 1.0) and abs(cor[0]) < 0.35          # the reference chain is refreshed i.i.d.
+    # "after" at the target chain is the traced log density: its running mean is the CovMatrix's b[2]
+    assert abs(raw[N - 1, 1] - tr[:, -1].mean()) < 1e-10
+
+
+def test_energy_ac1_merge_matches_numpy_corrcoef():
+    """GroupBy(Int, CovMatrix(2)) merged over replicas == the plain correlation of all (before, after) pairs at a chain."""
+    pt = O.OraclePT(n_chains=1, dim=4, seed=3, explorer=O.EXPLORER_SLICE, record_traces=1, record_energy_ac1=1)
+    for r in range(8):
+        prev_last = None
+        pt.run_round()
+    tr = pt.traces()                                  # single chain: after_t == before_{t+1}
+    cor, cn, raw = pt.energy_ac1()
+    after = tr[:, -1]
+    np.testing.assert_allclose(raw[0, 1], after.mean(), rtol=1e-12)
+    # before_t = after_{t-1} for t >= 1 within the round; the first "before" is the last "after" of the previous round
+    b = after[:-1]; a = after[1:]
+    approx = np.corrcoef(b, a)[0, 1]
+    assert abs(cor[0] - approx) < 0.05

@@ -16,13 +16,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _unsharded(N, d, explorer, scans_per_round):
-    ref = O.OraclePT(n_chains=N, dim=d, explorer=explorer, record_online=1)
+    ref = O.OraclePT(n_chains=N, dim=d, explorer=explorer, record_online=1, record_traces=1, record_energy_ac1=1)
     out = []
     for n in scans_per_round:
         ref.begin_round(); ref.run_scans(n); 
         ref.L.po_end_round(ref.h)
         out.append(dict(ip=ref.index_process(), rt=ref.round_trip(), swap=ref.swap_pr(), lsr=ref.log_sum_ratio(),
-                        expl=ref.explorer_stats(), sched=ref.schedule(), online=ref.online()))
+                        expl=ref.explorer_stats(), sched=ref.schedule(), online=ref.online(),
+                        eac=ref.energy_ac1(), traces=ref.traces(), online_lp=ref.online_lp()))
     return ref, out
 
 
@@ -32,8 +33,8 @@ def test_loopback_shards_equal_unsharded_oracle(N, d, G, explorer):
     from pigeons_amd import tempering as T
     scans = [2, 4, 8, 16]
     ref, want = _unsharded(N, d, explorer, scans)
-    shards = LoopbackShards([O.OracleShard(rank=g, world_size=G, n_chains=N, dim=d, explorer=explorer, record_online=1)
-                             for g in range(G)])
+    shards = LoopbackShards([O.OracleShard(rank=g, world_size=G, n_chains=N, dim=d, explorer=explorer, record_online=1,
+                                           record_traces=1, record_energy_ac1=1) for g in range(G)])
     for r, n in enumerate(scans):
         shards.run_scans(1, n)
         red = shards.reduce()
@@ -45,6 +46,10 @@ def test_loopback_shards_equal_unsharded_oracle(N, d, G, explorer):
         np.testing.assert_allclose(red.log_sum_ratio[0], w["lsr"][0], rtol=1e-12)
         np.testing.assert_allclose(red.log_sum_ratio[2], w["lsr"][2], rtol=1e-12)
         assert np.array_equal(red.explorer_n_steps[0], w["expl"][2])
+        assert np.array_equal(red.traces, w["traces"])                          # target-chain samples: the last shard's
+        assert np.array_equal(red.energy_ac1[1], w["eac"][1])
+        np.testing.assert_allclose(red.energy_ac1[0], w["eac"][0], rtol=1e-9)   # merge order differs
+        np.testing.assert_allclose(red.online_log_density, w["online_lp"][:2], rtol=1e-12)
         rej = T.rejections(*red.swap_acceptance_pr)
         old = shards.engines[0].schedule()
         new = T.optimal_schedule(rej, old, N)
