@@ -51,7 +51,8 @@ enum {
     PTE_EXPLORER_TOY      = 1,           /* ToyExplorer:  src/explorers/ToyExplorer.jl:5-14                */
     PTE_EXPLORER_SLICE    = 2,           /* SliceSampler: src/explorers/SliceSampler.jl:8-237              */
     PTE_EXPLORER_AUTOMALA = 3,           /* AutoMALA:     src/explorers/AutoMALA.jl:29-294                 */
-    PTE_EXPLORER_ISING_METROPOLIS = 4    /* IsingMetropolis: examples/ising.jl:91-116 (n_steps in slice_n_passes) */
+    PTE_EXPLORER_ISING_METROPOLIS = 4,   /* IsingMetropolis: examples/ising.jl:91-116 (n_steps in slice_n_passes) */
+    PTE_EXPLORER_MALA     = 5            /* MALA:         src/explorers/MALA.jl:19-105 (am_* fields; step size fixed) */
 };
 enum {                                   /* Inputs.record (src/pt/Inputs.jl:57-62)                         */
     PTE_RECORD_ROUND_TRIP    = 1u << 0,  /* round_trip     src/recorders/RoundTripRecorder.jl              */
@@ -91,7 +92,7 @@ typedef struct pte_config {
     /* chain sharding: this engine owns chains [rank*N/world, (rank+1)*N/world)                           */
     int32_t  rank;
     int32_t  world_size;
-    int32_t  reserved;
+    int32_t  explorer2;          /* Compose(explorer, explorer2), src/explorers/Compose.jl:5-19; PTE_EXPLORER_NONE = single explorer */
 } pte_config;
 
 typedef struct pte_engine pte_engine;

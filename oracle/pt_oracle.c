@@ -393,7 +393,7 @@ void po_default_config(po_config *c) {
     c->am_base_n_refresh = 3; c->am_exponent_n_refresh = 0.35; c->am_step_size = 1.0;
     c->am_preconditioner = 2; c->am_p0 = 1.0 / 3.0; c->am_p1 = 1.0 / 3.0;
     c->record_round_trip = 1; c->record_index_process = 1; c->record_online = 0;
-    c->record_traces = 0; c->record_energy_ac1 = 0;
+    c->record_traces = 0; c->record_energy_ac1 = 0; c->explorer2 = PO_EXPLORER_NONE;
     c->n_threads = 1;
     c->rank = 0; c->world_size = 1;
 }
@@ -766,28 +766,57 @@ static int am_auto_step_size(am_ctx *a, double step_size, double lower, double u
     *exponent_out = exponent;
     return 0;
 }
+/* build_preconditioner! (src/explorers/Preconditioner.jl:57-77) */
+static void am_build_preconditioner(po_pt *pt, po_replica *r, double *precond) {
+    const int64_t d = pt->d;
+    const po_config *cfg = &pt->cfg;
+    if (pt->target_std == NULL || cfg->am_preconditioner == 0) {
+        for (int64_t i = 0; i < d; i++) precond[i] = 1.0;
+    } else if (cfg->am_preconditioner == 1) {
+        for (int64_t i = 0; i < d; i++) precond[i] = pt->target_std[i] == 0.0 ? 1.0 : 1.0 / pt->target_std[i];
+    } else {
+        double u = po_rand(&r->rng);
+        if (u <= cfg->am_p0) {
+            for (int64_t i = 0; i < d; i++) precond[i] = pt->target_std[i] == 0.0 ? 1.0 : 1.0 / pt->target_std[i];
+        } else if (u <= cfg->am_p0 + cfg->am_p1) {
+            for (int64_t i = 0; i < d; i++) precond[i] = 1.0;
+        } else {
+            double mix = po_rand(&r->rng), rmix = 1.0 - mix;
+            for (int64_t i = 0; i < d; i++) precond[i] = pt->target_std[i] == 0.0 ? 1.0 : mix + rmix / pt->target_std[i];
+        }
+    }
+}
+/* mala! (src/explorers/MALA.jl:74-97): fixed step size, one leapfrog, always Metropolis-Hastings */
+static int mala_step(po_pt *pt, po_replica *r) {
+    const int64_t d = pt->d;
+    const po_config *cfg = &pt->cfg;
+    am_ctx a = { pt, r, r->chain, r->buf, r->buf + d, r->buf + 2 * d, r->buf + 3 * d, r->buf + 4 * d, r->buf + 5 * d, r->buf + 6 * d };
+    am_build_preconditioner(pt, r, a.precond);
+    const int n_refresh = cfg->am_base_n_refresh * (int)ceil(pow((double)d, cfg->am_exponent_n_refresh));
+    for (int it = 0; it < n_refresh; it++) {
+        memcpy(a.start, r->state, sizeof(double) * (size_t)d);
+        for (int64_t i = 0; i < d; i++) a.momentum[i] = po_randn(&r->rng);
+        const double init_joint_log = am_log_joint(&a);
+        if (!isfinite(init_joint_log)) { fail(pt, "MALA can only be called on a configuration of positive density."); return 1; }
+        am_leap_frog(&a, cfg->am_step_size);
+        for (int64_t i = 0; i < d; i++) a.momentum[i] = a.momentum[i] * -1.0;
+        const double e = exp(am_log_joint(&a) - init_joint_log);
+        double probability = e < 1.0 ? e : 1.0;
+        if (isnan(e)) probability = e;
+        mean_fit(&r->rec.expl_acc[a.chain], probability);
+        if (po_rand(&r->rng) < probability) { /* accept */ }
+        else memcpy(r->state, a.start, sizeof(double) * (size_t)d);
+        sum_fit(&r->rec.expl_steps[a.chain], 1.0);
+    }
+    return 0;
+}
 /* step! -> _extract_commons_and_run! (:84-104) -> auto_mala! (:106-182) */
 static int automala_step(po_pt *pt, po_replica *r) {
     const int64_t d = pt->d;
     const po_config *cfg = &pt->cfg;
     am_ctx a = { pt, r, r->chain, r->buf, r->buf + d, r->buf + 2 * d, r->buf + 3 * d, r->buf + 4 * d, r->buf + 5 * d, r->buf + 6 * d };
     const int use_mh = (pt->scan != 1);
-    /* build_preconditioner! (src/explorers/Preconditioner.jl:57-77) */
-    if (pt->target_std == NULL || cfg->am_preconditioner == 0) {
-        for (int64_t i = 0; i < d; i++) a.precond[i] = 1.0;
-    } else if (cfg->am_preconditioner == 1) {
-        for (int64_t i = 0; i < d; i++) a.precond[i] = pt->target_std[i] == 0.0 ? 1.0 : 1.0 / pt->target_std[i];
-    } else {
-        double u = po_rand(&r->rng);
-        if (u <= cfg->am_p0) {
-            for (int64_t i = 0; i < d; i++) a.precond[i] = pt->target_std[i] == 0.0 ? 1.0 : 1.0 / pt->target_std[i];
-        } else if (u <= cfg->am_p0 + cfg->am_p1) {
-            for (int64_t i = 0; i < d; i++) a.precond[i] = 1.0;
-        } else {
-            double mix = po_rand(&r->rng), rmix = 1.0 - mix;
-            for (int64_t i = 0; i < d; i++) a.precond[i] = pt->target_std[i] == 0.0 ? 1.0 : mix + rmix / pt->target_std[i];
-        }
-    }
+    am_build_preconditioner(pt, r, a.precond);
     const int n_refresh = cfg->am_base_n_refresh * (int)ceil(pow((double)d, cfg->am_exponent_n_refresh));
     for (int it = 0; it < n_refresh; it++) {
         memcpy(a.start, r->state, sizeof(double) * (size_t)d);
@@ -824,6 +853,9 @@ static int automala_step(po_pt *pt, po_replica *r) {
 static inline double lp_of_replica(const po_pt *pt, const po_replica *r) {   /* find_log_potential(replica, ...)(replica.state) */
     return pt->cfg.target == PO_TARGET_ISING ? ising_lp(pt, r->chain, r->aux) : lp_at_chain(pt, r->chain, r->state);
 }
+static inline int uses_gradient_sampler(const po_config *c) {
+    return c->explorer == PO_EXPLORER_AUTOMALA || c->explorer == PO_EXPLORER_MALA || c->explorer2 == PO_EXPLORER_AUTOMALA || c->explorer2 == PO_EXPLORER_MALA;
+}
 static int explore_replica_inner(po_pt *pt, po_replica *r);
 static int explore_replica(po_pt *pt, po_replica *r) {
     if (pt->cfg.target == PO_TARGET_TEST_SWAPPER) return 0;   /* state nothing, step! no-op (pair_swapper.jl:137-143) */
@@ -853,15 +885,20 @@ static int explore_replica_inner(po_pt *pt, po_replica *r) {
     if (is_reference(N, r->chain)) {
         mvn_sample_iid(pt, r);
     } else {
-        switch (pt->cfg.explorer) {
-        case PO_EXPLORER_TOY:   mvn_sample_iid(pt, r); break;
-        case PO_EXPLORER_SLICE: if (slice_step(pt, r)) return 1; break;
-        case PO_EXPLORER_AUTOMALA: if (automala_step(pt, r)) return 1; break;
-        case PO_EXPLORER_NONE:  break;
-        default: fail(pt, "oracle: explorer not implemented"); return 1;
+        const int32_t kinds[2] = { pt->cfg.explorer, pt->cfg.explorer2 };      /* step!(::Compose), Compose.jl:16-19 */
+        for (int k = 0; k < 2; k++) {
+            if (k == 1 && kinds[1] == PO_EXPLORER_NONE) break;
+            switch (kinds[k]) {
+            case PO_EXPLORER_TOY:   mvn_sample_iid(pt, r); break;
+            case PO_EXPLORER_SLICE: if (slice_step(pt, r)) return 1; break;
+            case PO_EXPLORER_AUTOMALA: if (automala_step(pt, r)) return 1; break;
+            case PO_EXPLORER_MALA:  if (mala_step(pt, r)) return 1; break;
+            case PO_EXPLORER_NONE:  break;
+            default: fail(pt, "oracle: explorer not implemented"); return 1;
+            }
         }
     }
-    if (is_target(N, r->chain) && (pt->cfg.record_online || (pt->cfg.explorer == PO_EXPLORER_AUTOMALA && pt->cfg.am_preconditioner != 0))) {
+    if (is_target(N, r->chain) && (pt->cfg.record_online || (uses_gradient_sampler(&pt->cfg) && pt->cfg.am_preconditioner != 0))) {
         for (int64_t i = 0; i < pt->d; i++) {       /* OnlineStateRecorder.jl:87-96 */
             mean_fit(&r->rec.on_mean[i], r->state[i]);
             var_fit(&r->rec.on_var[i], r->state[i]);
@@ -1114,15 +1151,15 @@ int po_end_round(po_pt *pt) {
         stepping_stone(pt);                                 /* report uses pre-adapt recorders */
         if (adapt_tempering(pt)) return 1;
     }
-    if (pt->cfg.explorer == PO_EXPLORER_AUTOMALA) {
-        /* adapt_explorer(::AutoMALA), src/explorers/AutoMALA.jl:70-79 */
+    if (uses_gradient_sampler(&pt->cfg)) {
+        /* adapt_explorer(::AutoMALA), src/explorers/AutoMALA.jl:70-79; (::MALA) MALA.jl:63-69 adapts the preconditioner only */
         if (pt->cfg.am_preconditioner != 0) {               /* adapt_preconditioner, Preconditioner.jl:54-55 */
             if (!pt->target_std) pt->target_std = (double *)calloc((size_t)(d > 0 ? d : 1), sizeof(double));
             for (int64_t i = 0; i < d; i++) pt->target_std[i] = sqrt(var_value(&pt->reduced.on_var[i]));
         }
         double acc = 0.0; int64_t cnt = 0;
         for (int64_t c = 0; c < N; c++) if (pt->reduced.am_factors[c].n > 0) { acc += pt->reduced.am_factors[c].mu; cnt++; }
-        if (cnt > 0) pt->step_size = pt->step_size * (acc / (double)cnt);
+        if (cnt > 0) pt->step_size = pt->step_size * (acc / (double)cnt);      /* no am_factors without AutoMALA */
     }
     return 0;
 }

@@ -44,7 +44,8 @@ double po_fc_eval(const double *x, const double *y, const double *m, const doubl
 
 /* ---- parallel tempering --------------------------------------------------- */
 enum { PO_TARGET_MVN = 0, PO_TARGET_TEST_SWAPPER = 1, PO_TARGET_FUNNEL = 2, PO_TARGET_ISING = 3 };
-enum { PO_EXPLORER_NONE = 0, PO_EXPLORER_TOY = 1, PO_EXPLORER_SLICE = 2, PO_EXPLORER_AUTOMALA = 3, PO_EXPLORER_ISING = 4 };
+enum { PO_EXPLORER_NONE = 0, PO_EXPLORER_TOY = 1, PO_EXPLORER_SLICE = 2, PO_EXPLORER_AUTOMALA = 3, PO_EXPLORER_ISING = 4,
+       PO_EXPLORER_MALA = 5 /* src/explorers/MALA.jl (am_* fields, fixed step size) */ };
 
 typedef struct po_config {
     int64_t  n_chains;
@@ -73,6 +74,8 @@ typedef struct po_config {
     int32_t  rank, world_size;
     /* traces (target chain [state; lp] per scan) and energy_ac1 */
     int32_t  record_traces, record_energy_ac1;
+    /* Compose(explorer, explorer2) (src/explorers/Compose.jl:5-19); 0 = single explorer */
+    int32_t  explorer2;
 } po_config;
 
 typedef struct po_pt po_pt;

@@ -216,6 +216,7 @@ void time_collect(pte_engine *h) {
     h->events.clear();
 }
 
+int launch_explorer_kind(pte_engine *h, int64_t scan, int kind);
 int launch_explore(pte_engine *h, int64_t scan) {
     (void)scan;
     const int64_t N = h->K;
@@ -223,7 +224,19 @@ int launch_explore(pte_engine *h, int64_t scan) {
         return fail(h, "traces buffer full: %lld scans since the last pte_reduce (max_scans_per_round = %lld)",
                     (long long)h->scans_in_round, (long long)h->cfg.max_scans_per_round);
     h->dev.trace_idx = h->scans_in_round;
-    switch (h->cfg.explorer) {
+    if (h->cfg.explorer2 == PTE_EXPLORER_NONE) { h->dev.compose_phase = 0; return launch_explorer_kind(h, scan, h->cfg.explorer); }
+    // Compose(first, second), src/explorers/Compose.jl:16-19: two kernels back to back on the replica's stream
+    h->dev.compose_phase = 1;
+    int rc = launch_explorer_kind(h, scan, h->cfg.explorer);
+    h->dev.compose_phase = 2;
+    if (!rc) rc = launch_explorer_kind(h, scan, h->cfg.explorer2);
+    h->dev.compose_phase = 0;
+    return rc;
+}
+
+int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
+    const int64_t N = h->K;
+    switch (kind) {
     case PTE_EXPLORER_NONE: return 0;
     case PTE_EXPLORER_TOY:
         time_begin(h, 0);
@@ -273,9 +286,11 @@ int launch_explore(pte_engine *h, int64_t scan) {
         time_end(h);
         break;
     }
+    case PTE_EXPLORER_MALA:
     case PTE_EXPLORER_AUTOMALA: {
         AmParams ap{};
-        ap.step_size = h->step_size; ap.n_refresh = h->am_n_refresh; ap.precond = h->cfg.am_preconditioner;
+        ap.mala = (kind == PTE_EXPLORER_MALA) ? 1 : 0;
+        ap.step_size = ap.mala ? h->cfg.am_step_size : h->step_size; ap.n_refresh = h->am_n_refresh; ap.precond = h->cfg.am_preconditioner;
         ap.p0 = h->cfg.am_p0; ap.p1 = h->cfg.am_p1;
         ap.target_std = h->have_target_std ? h->d_target_std : nullptr;
         ap.use_mh = (scan != 1) ? 1 : 0;                 // AutoMALA.jl:87,96-102
@@ -379,15 +394,22 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     } else if (cfg->explorer == PTE_EXPLORER_ISING_METROPOLIS) return fail(nullptr, "pte_create: IsingMetropolis needs the Ising target");
     if (!swapper && !funnel && !ising && cfg->target != PTE_TARGET_MVN_SCALED_PRECISION)
         return fail(nullptr, "pte_create: target %d has no device log-potential; use the reference CPU path", cfg->target);
-    if (funnel && cfg->explorer != PTE_EXPLORER_AUTOMALA)
-        return fail(nullptr, "pte_create: the funnel path is implemented for AutoMALA only; use the reference CPU path");
-    if (cfg->explorer == PTE_EXPLORER_AUTOMALA && (cfg->dim < 1 || cfg->dim > 1024))
-        return fail(nullptr, "pte_create: AutoMALA keeps the replica in registers, dim must be in 1..1024 (got %lld)", (long long)cfg->dim);
+    auto grad_based = [](int k) { return k == PTE_EXPLORER_AUTOMALA || k == PTE_EXPLORER_MALA; };
+    const bool uses_grad = grad_based(cfg->explorer) || grad_based(cfg->explorer2);
+    if (funnel && !(grad_based(cfg->explorer) && (cfg->explorer2 == PTE_EXPLORER_NONE || grad_based(cfg->explorer2))))
+        return fail(nullptr, "pte_create: the funnel path is implemented for AutoMALA / MALA only; use the reference CPU path");
+    if (uses_grad && (cfg->dim < 1 || cfg->dim > 1024))
+        return fail(nullptr, "pte_create: AutoMALA / MALA keep the replica in registers, dim must be in 1..1024 (got %lld)", (long long)cfg->dim);
+    if (cfg->explorer2 != PTE_EXPLORER_NONE) {           // Compose(first, second)
+        auto composable = [&](int k) { return k == PTE_EXPLORER_SLICE || grad_based(k); };
+        if (!composable(cfg->explorer) || !composable(cfg->explorer2))
+            return fail(nullptr, "pte_create: Compose is available for SliceSampler / AutoMALA / MALA (got %d, %d)", cfg->explorer, cfg->explorer2);
+    }
     if (!swapper && !ising && (cfg->dim < 1 || cfg->dim > 4096))
         return fail(nullptr, "pte_create: dim must be in 1..4096 (got %lld)", (long long)cfg->dim);
     if (swapper && cfg->explorer != PTE_EXPLORER_NONE)
         return fail(nullptr, "pte_create: TestSwapper has no explorer");
-    if (!swapper && !ising && cfg->explorer != PTE_EXPLORER_TOY && cfg->explorer != PTE_EXPLORER_SLICE && cfg->explorer != PTE_EXPLORER_AUTOMALA)
+    if (!swapper && !ising && cfg->explorer != PTE_EXPLORER_TOY && cfg->explorer != PTE_EXPLORER_SLICE && !grad_based(cfg->explorer))
         return fail(nullptr, "pte_create: explorer %d is not implemented on the device", cfg->explorer);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -442,6 +464,7 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.expl_steps_sum, (size_t)K); rc |= dev_alloc(h, &e.expl_steps_n, (size_t)K);
     rc |= dev_alloc(h, &e.on_mean, (size_t)(d + 1));   rc |= dev_alloc(h, &e.on_m2, (size_t)(d + 1));
     rc |= dev_alloc(h, &e.eac, (size_t)(5 * K)); rc |= dev_alloc(h, &e.eac_n, (size_t)K);
+    rc |= dev_alloc(h, &e.lp_stash, (size_t)K);
     rc |= dev_alloc(h, &e.traces, (cfg->record_flags & PTE_RECORD_TRACES) ? (size_t)(cfg->max_scans_per_round * (d + 1)) : 1, false);
     rc |= dev_alloc(h, &e.on_n, 1);
     const int64_t ipcap = (cfg->record_flags & PTE_RECORD_INDEX_PROCESS) ? cfg->max_scans_per_round * K : 1;
@@ -455,7 +478,7 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     h->step_size = cfg->am_step_size;
     // n_refresh = base_n_refresh * ceil(Int, dim^exponent_n_refresh)  (AutoMALA.jl:120)
     h->am_n_refresh = cfg->am_base_n_refresh * (int)std::ceil(std::pow((double)(d > 0 ? d : 1), cfg->am_exponent_n_refresh));
-    if (cfg->explorer == PTE_EXPLORER_AUTOMALA && cfg->am_preconditioner != 0) e.record_flags |= PTE_RECORD_ONLINE;   // _transformed_online (GradientBasedSampler.jl:19-25)
+    if (uses_grad && cfg->am_preconditioner != 0) e.record_flags |= PTE_RECORD_ONLINE;   // _transformed_online (GradientBasedSampler.jl:19-25)
     e.slot_of_chain = h->slot_map[0]; e.slot_of_chain_alt = h->slot_map[1]; h->slot_cur = 0;
 
     // equally_spaced_schedule (reference src/schedules/Schedule.jl:36-44)
@@ -547,7 +570,10 @@ int pte_get_schedule(const pte_engine *h, double *betas) {
 
 int pte_set_explorer_adaptation(pte_engine *h, double step_size, const double *target_std, int64_t dim) {
     if (!h) return 1;
-    if (h->cfg.explorer != PTE_EXPLORER_AUTOMALA) return 0;   // nothing to adapt for SliceSampler / ToyExplorer
+    {   // nothing to adapt for SliceSampler / ToyExplorer
+        auto gb = [](int k) { return k == PTE_EXPLORER_AUTOMALA || k == PTE_EXPLORER_MALA; };
+        if (!gb(h->cfg.explorer) && !gb(h->cfg.explorer2)) return 0;
+    }
     if (!(step_size > 0)) return fail(h, "pte_set_explorer_adaptation: step_size must be > 0");
     HIP_OK(h, hipSetDevice(h->cfg.device));
     h->step_size = step_size;

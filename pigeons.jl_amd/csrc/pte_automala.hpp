@@ -24,6 +24,7 @@ struct AmParams {
     double p0, p1;          // mix proportions
     const double *target_std;   // [d] or nullptr (== `nothing`: identity, no draw)
     int use_mh;             // scan != 1
+    int mala;               // 1: MALA (src/explorers/MALA.jl:74-97) -- fixed step size, one leapfrog, always MH
     double ref_prec;        // funnel: precision of the normal reference
     double log3;            // log(3.0) from the host libm
 };
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
 
     double x[E];
     if (c == 0 && e.N > 1) {
+        if (e.compose_phase == 2) return;
         const double lp0 = lp_before_explore(e, c, slot);
         const double S0 = iid_refresh<NLU>(e, slot, e.sd[0], lane);   // sample_iid! at the reference (pigeons.jl:104-105)
         __threadfence_block();
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
             l20 = T.funnel(x, nullptr);
             if (lane == 0) e.suff2[slot] = l20;
         }
-        record_after_explore(e, cl, c, slot, lane, lp0, S0, l20);
+        record_after_explore_impl(e, cl, c, slot, lane, lp0, S0, l20);
         return;
     }
     const double lp_before = lp_before_explore(e, c, slot);
@@ -246,6 +248,20 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         }
         const double init_joint = log_joint();
         if (!isfinite(init_joint)) { err = ERR_AM_DENSITY; break; }
+        if (ap.mala) {                                   // mala! (MALA.jl:79-96)
+            leap_frog(ap.step_size);
+#pragma unroll
+            for (int j = 0; j < E; ++j) p[j] = p[j] * -1.0;
+            const double ex = exp(log_joint() - init_joint);
+            const double probability = ex < 1.0 ? ex : (isnan(ex) ? ex : 1.0);
+            acc_sum += probability; acc_n += 1;
+            if (!(r.rand() < probability)) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) x[j] = xs[j];
+            }
+            steps_sum += 1; steps_n += 1;
+            continue;
+        }
         const double ua = r.rand(), ub = r.rand();
         const double lower = log(ua < ub ? ua : ub), upper = log(ua < ub ? ub : ua);
         const int proposed = auto_step_size(lower, upper);

@@ -49,6 +49,7 @@ struct EngineDev {
     double *on_mean; double *on_m2; int64_t *on_n;         // [d+1],[d+1],[1] target-chain online stats of [state; log density]
     double *eac; int64_t *eac_n;                           // [5K],[K] energy_ac1: Welford (mean before, mean after, C_bb, C_ba, C_aa) per local chain
     double *traces; int64_t trace_idx;                     // [max_scans][d+1] target-chain [state; log density]; row of the current scan
+    int compose_phase; double *lp_stash;                   // Compose(first, second): 0 single explorer, 1 first, 2 second kernel of the scan; [K] lp before the first
     int32_t *index_process;                                // [scan][slot]
     int32_t *error;                                        // [4] code, chain, coordinate, spare
     uint32_t record_flags;
@@ -148,11 +149,15 @@ __device__ __forceinline__ double chain_lp(const EngineDev &e, int64_t c, double
 // explore!'s bookkeeping around the explorer (reference src/pt/pigeons.jl:101-143):
 //   before = eval_if_ac_requested  -> lp_before_explore at kernel entry (from the statistics of the last scan)
 //   process_ac! / :online / :traces -> record_after_explore at kernel exit, all lanes, S and l2 in registers
+// Compose(first, second) (src/explorers/Compose.jl:16-19) runs two explorer kernels per scan: the first
+// stashes `before`, only the second records; the reference chain is refreshed (and recorded) by the first.
 __device__ __forceinline__ double lp_before_explore(const EngineDev &e, int64_t c, int slot) {
-    return (e.record_flags & 16u) ? chain_lp(e, c, e.suff[slot], e.suff2[slot]) : 0.0;
+    if (!(e.record_flags & 16u)) return 0.0;
+    if (e.compose_phase == 2) return e.lp_stash[c - e.c0];
+    return chain_lp(e, c, e.suff[slot], e.suff2[slot]);
 }
-__device__ __forceinline__ void record_after_explore(const EngineDev &e, int64_t cl, int64_t c, int slot, int lane,
-                                                     double lp_before, double S, double l2) {
+__device__ __forceinline__ void record_after_explore_impl(const EngineDev &e, int64_t cl, int64_t c, int slot, int lane,
+                                                          double lp_before, double S, double l2) {
     const unsigned f = e.record_flags;
     if (!(f & (4u | 8u | 16u))) return;
     const double lp = chain_lp(e, c, S, l2);
@@ -175,13 +180,19 @@ __device__ __forceinline__ void record_after_explore(const EngineDev &e, int64_t
         }
     }
 }
+__device__ __forceinline__ void record_after_explore(const EngineDev &e, int64_t cl, int64_t c, int slot, int lane,
+                                                     double lp_before, double S, double l2) {
+    if (e.compose_phase == 1) { if ((e.record_flags & 16u) && lane == 0) e.lp_stash[cl] = lp_before; return; }
+    record_after_explore_impl(e, cl, c, slot, lane, lp_before, S, l2);
+}
 
 // the same at a chain of the MVN path, with explore!'s recorders around it
 template <int NLU>
 __device__ __forceinline__ void iid_refresh_recorded(const EngineDev &e, int64_t cl, int64_t c, int slot, double sd, int lane) {
+    if (e.compose_phase == 2) return;                     // the first explorer's kernel already did
     const double lp0 = lp_before_explore(e, c, slot);
     const double S = iid_refresh<NLU>(e, slot, sd, lane);
-    record_after_explore(e, cl, c, slot, lane, lp0, S, 0.0);
+    record_after_explore_impl(e, cl, c, slot, lane, lp0, S, 0.0);
 }
 
 // ---------------------------------------------------------------------------------------------

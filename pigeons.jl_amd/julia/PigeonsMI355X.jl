@@ -36,7 +36,7 @@ Base.@kwdef mutable struct PteConfig
     am_preconditioner::Int32 = 2
     rank::Int32 = 0
     world_size::Int32 = 1
-    reserved::Int32 = 0
+    explorer2::Int32 = 0        # Compose(explorer, explorer2)
 end
 
 """Device-resident `replicas` (informal interface src/replicas/replicas.jl:11-40)."""

@@ -11,7 +11,7 @@ PKG_ROOT = os.path.dirname(_HERE)                       # .../pigeons.jl_amd
 LIB_PATH = os.path.join(PKG_ROOT, "lib", "libpte.so")
 
 TARGET_MVN_SCALED_PRECISION, TARGET_TEST_SWAPPER, TARGET_FUNNEL, TARGET_ISING = 0, 1, 2, 3
-EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA, EXPLORER_ISING_METROPOLIS = 0, 1, 2, 3, 4
+EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA, EXPLORER_ISING_METROPOLIS, EXPLORER_MALA = 0, 1, 2, 3, 4, 5
 RECORD_ROUND_TRIP, RECORD_INDEX_PROCESS, RECORD_ONLINE, RECORD_TRACES, RECORD_ENERGY_AC1 = 1, 2, 4, 8, 16
 ABI_VERSION = 1
 
@@ -31,7 +31,7 @@ class PteConfig(C.Structure):
         ("am_exponent_n_refresh", C.c_double), ("am_step_size", C.c_double),
         ("am_p0", C.c_double), ("am_p1", C.c_double),
         ("am_preconditioner", C.c_int32),
-        ("rank", C.c_int32), ("world_size", C.c_int32), ("reserved", C.c_int32),
+        ("rank", C.c_int32), ("world_size", C.c_int32), ("explorer2", C.c_int32),
     ]
 
 

@@ -129,6 +129,23 @@ class AutoMALA:
     estimated_target_std_deviations: Any = None
 
 
+@dataclass
+class MALA:
+    """src/explorers/MALA.jl:19-61 (the step size is NOT adapted; the preconditioner is)"""
+    base_n_refresh: int = 3
+    exponent_n_refresh: float = 0.35
+    step_size: float = 1.0
+    preconditioner: Any = field(default_factory=MixDiagonalPreconditioner)
+    estimated_target_std_deviations: Any = None
+
+
+@dataclass
+class Compose:
+    """src/explorers/Compose.jl:5-8: deterministic composition, e.g. Compose(SliceSampler(), AutoMALA())"""
+    first: Any = None
+    second: Any = None
+
+
 def default_explorer(target):
     if isinstance(target, ScaledPrecisionNormalPath):
         return ToyExplorer()           # src/targets/toy_mvn_target.jl:13
@@ -278,23 +295,34 @@ class PT:
         else:
             raise NotImplementedError(
                 "target %r has no device log-potential; use the reference CPU path (Pigeons.jl)" % (target,))
-        if explorer is None:
-            kw.update(explorer=_lib.EXPLORER_NONE)
-        elif isinstance(explorer, ToyExplorer):
-            kw.update(explorer=_lib.EXPLORER_TOY)
-        elif isinstance(explorer, SliceSampler):
-            kw.update(explorer=_lib.EXPLORER_SLICE, slice_w=explorer.w, slice_p=explorer.p,
-                      slice_n_passes=explorer.n_passes, slice_max_iter=explorer.max_iter)
-        elif isinstance(explorer, IsingMetropolis):
-            kw.update(explorer=_lib.EXPLORER_ISING_METROPOLIS, slice_n_passes=explorer.n_steps)
-        elif isinstance(explorer, AutoMALA):
-            pc = explorer.preconditioner
-            kind = 0 if isinstance(pc, IdentityPreconditioner) else 1 if isinstance(pc, DiagonalPreconditioner) else 2
-            kw.update(explorer=_lib.EXPLORER_AUTOMALA, am_base_n_refresh=explorer.base_n_refresh,
-                      am_exponent_n_refresh=explorer.exponent_n_refresh, am_step_size=explorer.step_size,
-                      am_preconditioner=kind, am_p0=getattr(pc, "p0", 0.0), am_p1=getattr(pc, "p1", 0.0))
+        def explorer_kw(ex):
+            if ex is None:
+                return dict(explorer=_lib.EXPLORER_NONE)
+            if isinstance(ex, ToyExplorer):
+                return dict(explorer=_lib.EXPLORER_TOY)
+            if isinstance(ex, SliceSampler):
+                return dict(explorer=_lib.EXPLORER_SLICE, slice_w=ex.w, slice_p=ex.p, slice_n_passes=ex.n_passes,
+                            slice_max_iter=ex.max_iter)
+            if isinstance(ex, IsingMetropolis):
+                return dict(explorer=_lib.EXPLORER_ISING_METROPOLIS, slice_n_passes=ex.n_steps)
+            if isinstance(ex, (AutoMALA, MALA)):
+                pc = ex.preconditioner
+                kind = 0 if isinstance(pc, IdentityPreconditioner) else 1 if isinstance(pc, DiagonalPreconditioner) else 2
+                return dict(explorer=_lib.EXPLORER_AUTOMALA if isinstance(ex, AutoMALA) else _lib.EXPLORER_MALA,
+                            am_base_n_refresh=ex.base_n_refresh, am_exponent_n_refresh=ex.exponent_n_refresh,
+                            am_step_size=ex.step_size, am_preconditioner=kind, am_p0=getattr(pc, "p0", 0.0),
+                            am_p1=getattr(pc, "p1", 0.0))
+            raise NotImplementedError("explorer %r is not available on the device" % (ex,))
+        if isinstance(explorer, Compose):
+            if isinstance(explorer.first, Compose) or isinstance(explorer.second, Compose):
+                raise NotImplementedError("nested Compose is not available on the device")
+            k1, k2 = explorer_kw(explorer.first), explorer_kw(explorer.second)
+            shared_keys = (set(k1) & set(k2)) - {"explorer"}
+            if any(k1[k] != k2[k] for k in shared_keys):
+                raise NotImplementedError("Compose of two samplers of the same family needs identical parameters on the device")
+            kw.update(k1); kw.update({k: v for k, v in k2.items() if k != "explorer"}); kw.update(explorer2=k2["explorer"])
         else:
-            raise NotImplementedError("explorer %r is not available on the device" % (explorer,))
+            kw.update(explorer_kw(explorer))
         make = engine_factory or Engine
         self.shards = None
         if n_shards > 1:
@@ -375,17 +403,28 @@ def adapt(pt, reduced):
 
 
 def adapt_explorer(pt, reduced):
-    """adapt_explorer(::AutoMALA, ...) (src/explorers/AutoMALA.jl:70-79, Preconditioner.jl:54-55)."""
-    ex = pt.shared.explorer
-    if not isinstance(ex, AutoMALA) or reduced.am_factors is None:
+    """adapt_explorer (src/explorers/AutoMALA.jl:70-79, MALA.jl:63-69, Compose.jl:10-14, Preconditioner.jl:54-55)."""
+    def adapt_one(ex):
+        if isinstance(ex, Compose):
+            return Compose(adapt_one(ex.first), adapt_one(ex.second))
+        if not isinstance(ex, (AutoMALA, MALA)) or reduced.am_factors is None:
+            return ex
+        std = None
+        if not isinstance(ex.preconditioner, IdentityPreconditioner):
+            std = np.sqrt(np.asarray(reduced.online[1], dtype=np.float64))
+        new_step = ex.step_size
+        if isinstance(ex, AutoMALA):
+            fm, fn = reduced.am_factors
+            present = np.asarray(fn) > 0
+            if present.any():
+                new_step = ex.step_size * float(np.mean(np.asarray(fm)[present]))
+        adapted.append((new_step, std))
+        return type(ex)(ex.base_n_refresh, ex.exponent_n_refresh, new_step, ex.preconditioner, std)
+    adapted = []
+    pt.shared.explorer = adapt_one(pt.shared.explorer)
+    if not adapted:
         return
-    fm, fn = reduced.am_factors
-    present = np.asarray(fn) > 0
-    new_step = ex.step_size * float(np.mean(np.asarray(fm)[present])) if present.any() else ex.step_size
-    std = None
-    if not isinstance(ex.preconditioner, IdentityPreconditioner):
-        std = np.sqrt(np.asarray(reduced.online[1], dtype=np.float64))
-    pt.shared.explorer = AutoMALA(ex.base_n_refresh, ex.exponent_n_refresh, new_step, ex.preconditioner, std)
+    new_step, std = adapted[-1]
     eng = pt.shards if pt.shards is not None else pt.replicas
     if hasattr(eng, "engines"):
         for e in eng.engines:

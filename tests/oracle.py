@@ -13,7 +13,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "_build", "libpt_oracle.so")
 
 TARGET_MVN, TARGET_TEST_SWAPPER, TARGET_FUNNEL, TARGET_ISING = 0, 1, 2, 3
-EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA, EXPLORER_ISING = 0, 1, 2, 3, 4
+EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA, EXPLORER_ISING, EXPLORER_MALA = 0, 1, 2, 3, 4, 5
 
 
 class Config(C.Structure):
@@ -30,7 +30,7 @@ class Config(C.Structure):
         ("record_round_trip", C.c_int32), ("record_index_process", C.c_int32),
         ("record_online", C.c_int32), ("n_threads", C.c_int32),
         ("rank", C.c_int32), ("world_size", C.c_int32),
-        ("record_traces", C.c_int32), ("record_energy_ac1", C.c_int32),
+        ("record_traces", C.c_int32), ("record_energy_ac1", C.c_int32), ("explorer2", C.c_int32),
     ]
 
 

@@ -419,6 +419,7 @@ def _check_am_round(P, pt, ref, rtol):
     assert P.next_round(pt)
     red = P.run_one_round(pt)
     P.adapt(pt, red)
+    pt.reduced_recorders = red
     ref.run_round()
     assert np.array_equal(red.index_process, ref.index_process())
     assert red.round_trip == ref.round_trip()
@@ -439,10 +440,13 @@ def _check_am_round(P, pt, ref, rtol):
     assert np.array_equal(n, nr)
     np.testing.assert_allclose(m, mr, rtol=rtol, atol=1e-300)
     np.testing.assert_allclose(pt.shared.tempering.schedule.grids, ref.schedule(), rtol=rtol)
-    np.testing.assert_allclose(pt.shared.explorer.step_size, ref.step_size(), rtol=1e-12)
+    ex = pt.shared.explorer
+    if hasattr(ex, "first"):                                               # Compose: the gradient-based component
+        ex = ex.first if hasattr(ex.first, "step_size") else ex.second
+    np.testing.assert_allclose(ex.step_size, ref.step_size(), rtol=1e-12)
     std = ref.target_std()
     if std is not None:
-        np.testing.assert_allclose(pt.shared.explorer.estimated_target_std_deviations, std, rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(ex.estimated_target_std_deviations, std, rtol=1e-6, atol=1e-12)
     x, chain, rng = pt.replicas.states()
     xr, cr, rr = ref.states()
     assert np.array_equal(chain, cr) and np.array_equal(rng, rr)
@@ -687,3 +691,91 @@ def test_sharded_traces_and_energy_ac1_equal_single_engine(P):
         for a, b in zip(ra.energy_ac1, rb.energy_ac1):
             assert np.array_equal(a, b, equal_nan=True)
         assert ra.online_log_density == rb.online_log_density
+
+
+# ---------------------------------------------------------------------------------------------
+# MALA (src/explorers/MALA.jl) and Compose (src/explorers/Compose.jl) --
+# the explorer set of the reference's own invariance matrix (test/test_parallelism_invariance.jl:19).
+# ---------------------------------------------------------------------------------------------
+def _explorer_pair(P, name):
+    """(device explorer object, oracle kwargs)"""
+    return {
+        "mala": (P.MALA(step_size=0.25), dict(explorer=O.EXPLORER_MALA, am_step_size=0.25, am_preconditioner=2)),
+        "mala_id": (P.MALA(step_size=0.4, preconditioner=P.IdentityPreconditioner(), base_n_refresh=5),
+                    dict(explorer=O.EXPLORER_MALA, am_step_size=0.4, am_preconditioner=0, am_base_n_refresh=5)),
+        "slice+automala": (P.Compose(P.SliceSampler(), P.AutoMALA()),
+                           dict(explorer=O.EXPLORER_SLICE, explorer2=O.EXPLORER_AUTOMALA, am_preconditioner=2)),
+        "automala+slice": (P.Compose(P.AutoMALA(), P.SliceSampler()),
+                           dict(explorer=O.EXPLORER_AUTOMALA, explorer2=O.EXPLORER_SLICE, am_preconditioner=2)),
+        "slice+mala": (P.Compose(P.SliceSampler(n_passes=1), P.MALA(step_size=0.3)),
+                       dict(explorer=O.EXPLORER_SLICE, explorer2=O.EXPLORER_MALA, slice_n_passes=1, am_step_size=0.3, am_preconditioner=2)),
+    }[name]
+
+
+@pytest.mark.parametrize("name,N,d,rounds", [("mala", 5, 10, 7), ("mala_id", 4, 70, 5), ("slice+automala", 4, 1, 8),
+                                             ("slice+automala", 6, 40, 5), ("automala+slice", 5, 12, 6), ("slice+mala", 5, 130, 4)])
+def test_mala_and_compose_parity_mvn(P, name, N, d, rounds):
+    ex, okw = _explorer_pair(P, name)
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.energy_ac1, P.traces]
+    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=ex, record=rec, show_report=False))
+    ref = O.OraclePT(n_chains=N, dim=d, record_energy_ac1=1, record_traces=1, **okw)
+    for _ in range(rounds):
+        _check_am_round(P, pt, ref, 1e-9) if "automala" in name else _check_mala_round(P, pt, ref, 1e-9)
+        _check_sample_recorders(P, pt.reduced_recorders, ref, 1e-9, N, exact_traces=False)
+
+
+def _check_mala_round(P, pt, ref, rtol):
+    assert P.next_round(pt)
+    red = P.run_one_round(pt)
+    P.adapt(pt, red)
+    pt.reduced_recorders = red
+    ref.run_round()
+    assert np.array_equal(red.index_process, ref.index_process())
+    assert red.round_trip == ref.round_trip()
+    am, an = red.explorer_acceptance_pr
+    ss, sn = red.explorer_n_steps
+    amr, anr, ssr, snr = ref.explorer_stats()
+    assert np.array_equal(an, anr) and np.array_equal(sn, snr) and np.array_equal(ss, ssr)
+    np.testing.assert_allclose(am, amr, rtol=rtol, atol=1e-300)
+    m, n = red.swap_acceptance_pr
+    mr, nr = ref.swap_pr()
+    assert np.array_equal(n, nr)
+    np.testing.assert_allclose(m, mr, rtol=rtol, atol=1e-300)
+    np.testing.assert_allclose(pt.shared.tempering.schedule.grids, ref.schedule(), rtol=rtol)
+    x, chain, rng = pt.replicas.states()
+    xr, cr, rr = ref.states()
+    assert np.array_equal(chain, cr) and np.array_equal(rng, rr)
+    np.testing.assert_allclose(x, xr, rtol=rtol, atol=1e-9 * rtol / 1e-6)
+
+
+def test_mala_funnel_parity(P):
+    N, d, rounds = 6, 8, 6
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio]
+    pt = P.PT(P.Inputs(target=P.Funnel(d), reference=P.ScaledPrecisionNormalLogPotential(1.0 / 9.0, d), n_chains=N, n_rounds=rounds,
+                       explorer=P.MALA(step_size=0.2), record=rec, show_report=False))
+    ref = O.OraclePT(n_chains=N, dim=d, explorer=O.EXPLORER_MALA, am_step_size=0.2, target=O.TARGET_FUNNEL, p0=1.0 / 9.0, am_preconditioner=2)
+    for _ in range(rounds):
+        _check_mala_round(P, pt, ref, 1e-6)
+
+
+def test_compose_rejects_what_the_device_cannot_run(P):
+    with pytest.raises((P.PteError, NotImplementedError)):
+        P.PT(P.Inputs(target=P.toy_mvn_target(4), n_chains=4, explorer=P.Compose(P.ToyExplorer(), P.SliceSampler()), show_report=False))
+    with pytest.raises((P.PteError, NotImplementedError)):
+        P.PT(P.Inputs(target=P.toy_mvn_target(4), n_chains=4, explorer=P.Compose(P.AutoMALA(), P.MALA(step_size=0.5)), show_report=False))
+
+
+def test_sharded_compose_equals_single_engine(P):
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.energy_ac1, P.traces]
+    mk = lambda: P.Inputs(target=P.toy_mvn_target(20), n_chains=8, n_rounds=4, explorer=P.Compose(P.SliceSampler(), P.AutoMALA()),
+                          record=rec, show_report=False)
+    one, many = P.PT(mk()), P.PT(mk(), n_shards=4, device_messages=True)
+    for _ in range(4):
+        assert P.next_round(one) and P.next_round(many)
+        ra = P.run_one_round(one); P.adapt(one, ra)
+        rb = P.run_one_round(many); P.adapt(many, rb)
+        assert np.array_equal(ra.index_process, rb.index_process) and np.array_equal(ra.traces, rb.traces)
+        for a, b in zip(ra.energy_ac1 + ra.explorer_acceptance_pr + ra.am_factors, rb.energy_ac1 + rb.explorer_acceptance_pr + rb.am_factors):
+            assert np.array_equal(a, b, equal_nan=True)
+    xa, ca, ga = one.replicas.states(); xb, cb, gb = many.shards.states()
+    assert np.array_equal(xa, xb) and np.array_equal(ca, cb) and np.array_equal(ga, gb)

@@ -206,3 +206,21 @@ def test_energy_ac1_merge_matches_numpy_corrcoef():
     b = after[:-1]; a = after[1:]
     approx = np.corrcoef(b, a)[0, 1]
     assert abs(cor[0] - approx) < 0.05
+
+
+@pytest.mark.parametrize("kw", [dict(explorer=O.EXPLORER_MALA, am_step_size=0.3),
+                                dict(explorer=O.EXPLORER_SLICE, explorer2=O.EXPLORER_AUTOMALA),
+                                dict(explorer=O.EXPLORER_SLICE, explorer2=O.EXPLORER_MALA, am_step_size=0.3)])
+def test_mala_and_compose_target_moments_and_logz(kw):
+    """SURVEY.md 8(f) rank 2.  Same analytic checks the reference applies to its explorers
+    (test/test_stepping_stone.jl:15-27, test/test_moments.jl): toy MVN, d = 4, target N(0, I/10)."""
+    d, N = 4, 6
+    pt = O.OraclePT(n_chains=N, dim=d, seed=1, record_online=1, **kw)
+    for _ in range(11):
+        pt.run_round()
+    m, v, n = pt.online()
+    assert n == 2 ** 11
+    assert np.all(np.abs(m) < 0.05) and np.all(np.abs(v - 0.1) < 0.02)
+    truth = 0.5 * d * math.log(1.0 / 10.0)         # log Z1/Z0 of exp(-prec/2 |x|^2), prec 1 -> 10
+    p = pt.stepping_stone_pair()
+    assert abs(p[0] - truth) < 0.2 and abs(p[1] - truth) < 0.2
