@@ -957,6 +957,18 @@ int pte_set_state(pte_engine *h, const double *state, const int64_t *chain, cons
         hipError_t e1 = hipStreamSynchronize(h->stream);
         hipFree(tmp);
         HIP_OK(h, e1);
+        if (h->cfg.target == PTE_TARGET_FUNNEL) {        // + the target log density of the interpolated path
+            const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
+            const double log3 = std::log(3.0);
+            switch (E) {
+            case 1: hipLaunchKernelGGL(k_refresh_funnel_stats<1>, dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, log3); break;
+            case 2: hipLaunchKernelGGL(k_refresh_funnel_stats<2>, dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, log3); break;
+            case 4: hipLaunchKernelGGL(k_refresh_funnel_stats<4>, dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, log3); break;
+            case 8: hipLaunchKernelGGL(k_refresh_funnel_stats<8>, dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, log3); break;
+            default: hipLaunchKernelGGL(k_refresh_funnel_stats<16>, dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, log3); break;
+            }
+            HIP_OK(h, hipStreamSynchronize(h->stream));
+        }
     }
     return 0;
 }

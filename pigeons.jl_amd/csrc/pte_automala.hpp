@@ -304,4 +304,22 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
     record_after_explore(e, cl, c, slot, lane, lp_before, S, l2);
 }
 
+// Swap statistics of every slot recomputed from the stored states (pte_set_state on an interpolated path):
+// suff = sum x^2 with the fixed tree, suff2 = the funnel's log density.
+template <int E>
+__global__ __launch_bounds__(64) void k_refresh_funnel_stats(EngineDev e, double log3) {
+    const int lane = lane_id();
+    const int64_t slot = blockIdx.x;
+    if (slot >= e.K) return;
+    AmTarget<E, TGT_FUNNEL> T;
+    T.d = e.d; T.lane = lane; T.log3 = log3;
+    const double *xrow = e.x + slot * e.ld;
+    double x[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) x[j] = T.valid(j) ? xrow[64 * j + lane] : 0.0;
+    const double S = sqr_norm_regs<E>(x);
+    const double l2 = T.funnel(x, nullptr);
+    if (lane == 0) { e.suff[slot] = S; e.suff2[slot] = l2; }
+}
+
 }  // namespace pte

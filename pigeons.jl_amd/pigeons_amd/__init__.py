@@ -17,5 +17,6 @@ from .pt import (Inputs, PT, pigeons, toy_mvn_target, ScaledPrecisionNormalPath,
                  stepping_stone, stepping_stone_pair, n_round_trips, n_tempered_restarts,
                  global_barrier, last_round_max_time, analytic_lognormalization,
                  analytic_cumulativebarrier, run_one_round, adapt, next_round, n_scans_in_round)
+from .checkpoint import write_checkpoint, load_checkpoint, latest_checkpoint_folder, increment_n_rounds
 from .tempering import (Schedule, equally_spaced_schedule, optimal_schedule,
                         FritschCarlsonMonotonicInterpolation, CommunicationBarriers, rejections)

@@ -1,0 +1,114 @@
+"""Checkpoint / resume of a device run (reference src/pt/checkpoint.jl:19-54,110-145,166-189).
+
+Same folder layout as the reference --
+    <exec_folder>/inputs.pkl
+    <exec_folder>/round=<r>/checkpoint/{shared.pkl, reduced_recorders.pkl, replica=<i>.npz, .signal/finished_replica=<i>}
+-- with Python pickles / npz in place of Julia's `.jls` serialisation (no Julia in the build image; the
+Julia glue would `serialize` the same fields: INTEGRATION.md).  A replica file holds what `Replica`
+holds (src/replicas/Replica.jl:5-30): state, chain, rng (seed, gamma), replica_index; everything is read
+back through `pte_get_state` / written through `pte_set_state`, so a resumed run continues bit for bit.
+"""
+import os
+import pickle
+
+import numpy as np
+
+
+def checkpoint_folder(exec_folder, round_):
+    return os.path.join(exec_folder, "round=%d" % round_, "checkpoint")
+
+
+def write_checkpoint(pt, exec_folder=None):
+    """write_checkpoint(pt) (checkpoint.jl:110-145): a no-op unless inputs.checkpoint (or a folder is given)."""
+    exec_folder = exec_folder or getattr(pt, "exec_folder", None)
+    if exec_folder is None or pt.shards is not None and not hasattr(pt.shards, "states"):
+        return None
+    r = pt.shared.iterators.round
+    folder = checkpoint_folder(exec_folder, r)
+    os.makedirs(os.path.join(folder, ".signal"), exist_ok=True)
+    eng = pt.shards if pt.shards is not None else pt.replicas
+    x, chain, rng = eng.states()                       # replica order
+    for i in range(len(chain)):
+        np.savez(os.path.join(folder, "replica=%d.npz" % (i + 1)), state=x[i], chain=np.int64(chain[i] + 1),
+                 rng=rng[i], replica_index=np.int64(i + 1))
+    with open(os.path.join(folder, "shared.pkl"), "wb") as f:
+        pickle.dump(pt.shared, f)
+    with open(os.path.join(folder, "reduced_recorders.pkl"), "wb") as f:
+        pickle.dump(pt.reduced_recorders, f)
+    if not os.path.exists(os.path.join(exec_folder, "inputs.pkl")):
+        with open(os.path.join(exec_folder, "inputs.pkl"), "wb") as f:
+            pickle.dump(pt.inputs, f)
+    for i in range(len(chain)):
+        open(os.path.join(folder, ".signal", "finished_replica=%d" % (i + 1)), "w").close()
+    pt.exec_folder = exec_folder
+    return folder
+
+
+def latest_checkpoint_folder(exec_folder):
+    """checkpoint.jl:56-72: the last round whose checkpoint is complete (all replicas signalled), 0 if none."""
+    try:
+        with open(os.path.join(exec_folder, "inputs.pkl"), "rb") as f:
+            inputs = pickle.load(f)
+    except OSError:
+        return 0
+    best = 0
+    for r in range(1, 64):
+        folder = checkpoint_folder(exec_folder, r)
+        if not os.path.isdir(folder):
+            continue
+        done = all(os.path.exists(os.path.join(folder, ".signal", "finished_replica=%d" % (i + 1))) for i in range(inputs.n_chains))
+        if done and os.path.exists(os.path.join(folder, "shared.pkl")):
+            best = r
+    return best
+
+
+def load_checkpoint(source_exec_folder, round=None, n_rounds_increment=0, **pt_kwargs):
+    """PT(source_exec_folder; round) (checkpoint.jl:19-54) [+ increment_n_rounds! :166-189]: a fresh engine whose
+    replicas, schedule and explorer adaptation are those of the checkpoint."""
+    from .pt import PT, AutoMALA, MALA, Compose
+    round = latest_checkpoint_folder(source_exec_folder) if round is None else round
+    if round == 0:
+        raise RuntimeError("No checkpoint found for %s (was checkpoint=True set?)" % source_exec_folder)
+    if round < 0:
+        raise ValueError("round should be positive")
+    folder = checkpoint_folder(source_exec_folder, round)
+    with open(os.path.join(source_exec_folder, "inputs.pkl"), "rb") as f:
+        inputs = pickle.load(f)
+    with open(os.path.join(folder, "shared.pkl"), "rb") as f:
+        shared = pickle.load(f)
+    with open(os.path.join(folder, "reduced_recorders.pkl"), "rb") as f:
+        reduced = pickle.load(f)
+    inputs.n_rounds += n_rounds_increment
+    inputs.explorer = shared.explorer                  # carries the adapted step size / std deviations
+    pt = PT(inputs, **pt_kwargs)
+    N = inputs.n_chains
+    reps = [np.load(os.path.join(folder, "replica=%d.npz" % (i + 1))) for i in range(N)]
+    x = np.stack([np.atleast_1d(r["state"]) for r in reps])
+    chain = np.array([int(r["chain"]) - 1 for r in reps], dtype=np.int64)
+    rng = np.stack([r["rng"] for r in reps]).astype(np.uint64)
+    pt.shared = shared
+    pt.reduced_recorders = reduced
+    eng = pt.replicas
+    if pt.shards is not None:
+        raise NotImplementedError("load a checkpoint into a single engine (sharded runs checkpoint through shards.states())")
+    eng.set_schedule(shared.tempering.schedule.grids)
+    eng.set_states(x if eng.d > 0 else None, chain, rng)
+
+    def grad_sampler(ex):
+        if isinstance(ex, Compose):
+            return grad_sampler(ex.first) or grad_sampler(ex.second)
+        return ex if isinstance(ex, (AutoMALA, MALA)) else None
+    gs = grad_sampler(shared.explorer)
+    if gs is not None:
+        eng.set_explorer_adaptation(gs.step_size, gs.estimated_target_std_deviations)
+    pt.exec_folder = None
+    return pt
+
+
+def increment_n_rounds(pt, increment):
+    """increment_n_rounds!(pt, k) (checkpoint.jl:166-172) for a live PT: device buffers are sized by n_rounds, so the
+    engine is rebuilt from the current replicas (same arithmetic from here on)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        write_checkpoint(pt, tmp)
+        return load_checkpoint(tmp, n_rounds_increment=increment)

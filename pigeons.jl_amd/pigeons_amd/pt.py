@@ -517,9 +517,15 @@ def report(pt):
 
 def pigeons(pt_or_none=None, **kwargs):
     """pigeons(; target, seed, n_rounds, n_chains, explorer, record, ...) -> PT  (src/api.jl:8-19)."""
+    exec_folder = kwargs.pop("exec_folder", None)
     pt = pt_or_none if pt_or_none is not None else PT(Inputs(**kwargs))
+    if exec_folder is not None:
+        pt.exec_folder = exec_folder
     while next_round(pt):
         reduced = run_one_round(pt)
         pt = adapt(pt, reduced)
         report(pt)
+        if pt.inputs.checkpoint and getattr(pt, "exec_folder", None):     # src/pt/pigeons.jl:20, checkpoint.jl:110-113
+            from .checkpoint import write_checkpoint
+            write_checkpoint(pt)
     return pt

@@ -779,3 +779,39 @@ def test_sharded_compose_equals_single_engine(P):
             assert np.array_equal(a, b, equal_nan=True)
     xa, ca, ga = one.replicas.states(); xb, cb, gb = many.shards.states()
     assert np.array_equal(xa, xb) and np.array_equal(ca, cb) and np.array_equal(ga, gb)
+
+
+# ---------------------------------------------------------------------------------------------
+# checkpoint / resume through pte_get_state / pte_set_state
+# (reference src/pt/checkpoint.jl; its own end-to-end check is "a resumed run equals an uninterrupted one",
+# test/test_checkpoint.jl, src/pt/checks.jl:52-78).
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["slice", "automala", "slice+automala", "funnel-automala", "ising"])
+def test_checkpoint_resume_equals_uninterrupted_run(P, tmp_path, name):
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.energy_ac1]
+    def mk(n_rounds):
+        if name == "funnel-automala":
+            return P.Inputs(target=P.Funnel(8), reference=P.ScaledPrecisionNormalLogPotential(1.0 / 9.0, 8), n_chains=6, n_rounds=n_rounds,
+                            explorer=P.AutoMALA(), record=rec, show_report=False, checkpoint=True)
+        if name == "ising":
+            return P.Inputs(target=P.IsingLogPotential(0.7, 8), n_chains=5, n_rounds=n_rounds, record=rec, show_report=False, checkpoint=True)
+        ex = {"slice": P.SliceSampler(), "automala": P.AutoMALA(), "slice+automala": P.Compose(P.SliceSampler(), P.AutoMALA())}[name]
+        return P.Inputs(target=P.toy_mvn_target(12), n_chains=6, n_rounds=n_rounds, explorer=ex, record=rec, show_report=False, checkpoint=True)
+    straight = P.pigeons(P.PT(mk(6)))
+    folder = str(tmp_path / "exec")
+    first = P.pigeons(P.PT(mk(3)), exec_folder=folder)
+    assert P.latest_checkpoint_folder(folder) == 3
+    assert first.shared.iterators.round == 3
+    resumed = P.load_checkpoint(folder, n_rounds_increment=3)          # PT(exec_folder) + increment_n_rounds!
+    assert resumed.shared.iterators.round == 3 and resumed.inputs.n_rounds == 6
+    resumed = P.pigeons(resumed)
+    ra, rb = straight.reduced_recorders, resumed.reduced_recorders
+    assert np.array_equal(ra.index_process, rb.index_process) and ra.round_trip == rb.round_trip
+    for a, b in zip(ra.swap_acceptance_pr + ra.log_sum_ratio + ra.energy_ac1, rb.swap_acceptance_pr + rb.log_sum_ratio + rb.energy_ac1):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert np.array_equal(straight.shared.tempering.schedule.grids, resumed.shared.tempering.schedule.grids)
+    xa, ca, ga = straight.replicas.states(); xb, cb, gb = resumed.replicas.states()
+    assert np.array_equal(xa, xb) and np.array_equal(ca, cb) and np.array_equal(ga, gb)
+    # a live PT can be extended as well (increment_n_rounds!(pt, k))
+    more = P.pigeons(P.increment_n_rounds(first, 3))
+    assert np.array_equal(more.reduced_recorders.index_process, ra.index_process)
