@@ -14,10 +14,7 @@
 #include "../../include/pte.h"
 #include "pte_kernels.hpp"
 #include "pte_slice2.hpp"
-#include "pte_slice3.hpp"
-#include "pte_slice4.hpp"
 #include "pte_slice5.hpp"
-#include "pte_slice6.hpp"
 #include "pte_slice7.hpp"
 #include "pte_automala.hpp"
 #include "pte_ising.hpp"
@@ -47,7 +44,7 @@ struct pte_engine {
     EngineDev dev{};
     hipStream_t stream = nullptr;
     int nlu = 0;
-    int slice_impl = 7, slice_m = 4;   // PTE_SLICE_IMPL=1 selects the plain sequential kernel (A/B + bisecting)
+    int slice_impl = 7, slice_m = 4;   // PTE_SLICE_IMPL = 1 plain sequential | 2 lane-batched tree path | 5 tree-free batches | 7 offset speculation (default)
     int64_t N = 0, d = 0;          // global chains, state dimension
     int64_t K = 0, c0 = 0;         // local chains [c0, c0+K)
     int world = 1, rank = 0;
@@ -252,30 +249,12 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
             S7Tune tn{2, 8, 2};
             if (const char *t = std::getenv("PTE_S7_BUDGETS")) std::sscanf(t, "%d,%d,%d", &tn.bud_d, &tn.bud_s, &tn.bud_a);
             DISPATCH_NLU(h->nlu, k_explore_slice7, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, tn);
-        } else if (h->slice_impl == 3) {
-            DISPATCH_NLU(h->nlu, k_explore_slice3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
-        } else if (h->slice_impl == 6 && h->slice_m == 3) {
-            DISPATCH_NLU_M(h->nlu, k_explore_slice6, 3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
-        } else if (h->slice_impl == 6 && h->slice_m == 5) {
-            DISPATCH_NLU_M(h->nlu, k_explore_slice6, 5, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
-        } else if (h->slice_impl == 6) {
-            DISPATCH_NLU_M(h->nlu, k_explore_slice6, 4, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_impl == 5 && h->slice_m == 3) {
             DISPATCH_NLU_M(h->nlu, k_explore_slice5, 3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_impl == 5 && h->slice_m == 6) {
             DISPATCH_NLU_M(h->nlu, k_explore_slice5, 6, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
-        } else if (h->slice_impl == 5 && h->slice_m == 5) {
-            DISPATCH_NLU_M(h->nlu, k_explore_slice5, 5, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_impl == 5) {
             DISPATCH_NLU_M(h->nlu, k_explore_slice5, 4, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
-        } else if (h->slice_impl == 4 && h->slice_m == 3) {
-            DISPATCH_NLU_M(h->nlu, k_explore_slice4, 3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
-        } else if (h->slice_impl == 4 && h->slice_m == 6) {
-            DISPATCH_NLU_M(h->nlu, k_explore_slice4, 6, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
-        } else if (h->slice_impl == 4 && h->slice_m == 5) {
-            DISPATCH_NLU_M(h->nlu, k_explore_slice4, 5, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
-        } else if (h->slice_impl == 4) {
-            DISPATCH_NLU_M(h->nlu, k_explore_slice4, 4, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_m == 3) {
             DISPATCH_NLU_M(h->nlu, k_explore_slice2, 3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_m == 6) {

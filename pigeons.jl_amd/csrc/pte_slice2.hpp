@@ -15,70 +15,9 @@
 //    coordinate falls back to the sequential procedure of the reference (doubling, acceptance
 //    check of Neal's doubling scheme, further shrinkage), restarted from the same stream position.
 #pragma once
-#include "pte_kernels.hpp"
+#include "pte_slice_common.hpp"
 
 namespace pte {
-
-struct DrawBuf {
-    uint64_t seed, gamma;   // uniform: stream state before draw #0 of the buffer
-    double unit;            // per lane: rand() of draw #lane
-    double ex;              // per lane: randexp() fast-path value of draw #lane
-    uint64_t exok;          // uniform: bit l set <=> draw #l passes the exponential ziggurat fast test
-    int p;                  // uniform: next unread draw
-
-    __device__ __forceinline__ void fill(int lane, const double *s_we, const unsigned long long *s_ke) {
-        uint64_t r = mix64(seed + (uint64_t)(lane + 1) * gamma);
-        unit = u52_to_unit(r);
-        uint64_t ri = r & MASK52;
-        int idx = (int)(ri & 0xFF);
-        ex = (double)ri * s_we[idx];
-        exok = ballot64(ri < s_ke[idx]);
-        p = 0;
-    }
-    __device__ __forceinline__ void init(uint64_t s, uint64_t g, int lane, const double *s_we, const unsigned long long *s_ke) {
-        seed = s; gamma = g;
-        fill(lane, s_we, s_ke);
-    }
-    // make sure draws p .. p+k-1 are in the buffer
-    __device__ __forceinline__ void ensure(int k, int lane, const double *s_we, const unsigned long long *s_ke) {
-        if (p + k > 64) { seed += (uint64_t)p * gamma; fill(lane, s_we, s_ke); }
-    }
-    __device__ __forceinline__ double rand(int lane, const double *s_we, const unsigned long long *s_ke) {
-        ensure(1, lane, s_we, s_ke);
-        double u = readlane_f64(unit, p);
-        p += 1;
-        return u;
-    }
-    // randexp(rng): fast path from the buffer, slow path sequentially on the same stream
-    __device__ __forceinline__ double randexp(int lane, const double *s_we, const unsigned long long *s_ke) {
-        ensure(1, lane, s_we, s_ke);
-        if ((exok >> p) & 1ull) {
-            double v = readlane_f64(ex, p);
-            p += 1;
-            return v;
-        }
-        SeqRng s{seed + (uint64_t)(p + 1) * gamma, gamma};
-        double v = randexp_from_raw(s, mix64(s.seed));
-        seed = s.seed;
-        fill(lane, s_we, s_ke);
-        return v;
-    }
-    // randexp(rng) when the caller has already ensured the draw is buffered (k more are wanted after it)
-    __device__ __forceinline__ double randexp_ensured(int k_after, int lane, const double *s_we, const unsigned long long *s_ke) {
-        if (__builtin_expect((exok >> p) & 1ull, 1)) {
-            double v = readlane_f64(ex, p);
-            p += 1;
-            return v;
-        }
-        SeqRng s{seed + (uint64_t)(p + 1) * gamma, gamma};
-        double v = randexp_from_raw(s, mix64(s.seed));
-        seed = s.seed;
-        fill(lane, s_we, s_ke);          // p = 0: a full buffer of 64 draws >= k_after
-        (void)k_after;
-        return v;
-    }
-    __device__ __forceinline__ uint64_t final_seed() const { return seed + (uint64_t)p * gamma; }
-};
 
 template <int NLU, int M>
 __global__ __launch_bounds__(64) void k_explore_slice2(EngineDev e, SliceParams sp) {

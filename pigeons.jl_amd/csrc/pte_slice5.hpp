@@ -18,9 +18,9 @@
 // re-established at every block boundary and written out as the swap statistic.
 //
 // Per coordinate the wave therefore runs: 3 draws read from the pre-converted buffer, the
-// threshold, and batches of M shrinkage proposals evaluated by M lanes (as slice2/slice4).
+// threshold, and batches of M shrinkage proposals evaluated by M lanes (as slice2).
 #pragma once
-#include "pte_slice4.hpp"
+#include "pte_slice_common.hpp"
 
 namespace pte {
 

@@ -1,4 +1,4 @@
-"""Debug-only: build libpte with -DPTE_PROFILE_SECTIONS (s_memtime stamps inside k_explore_slice4) and print
+"""Debug-only: build libpte with -DPTE_PROFILE_SECTIONS (s_memtime stamps inside k_explore_slice5) and print
 where a replica-step's cycles go."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -3,7 +3,7 @@ mkdir -p gpurun_out
 python -m pytest tests -m gpu -q -x -k "${1:-slice or quickstart or sharded or full_size}" 2>&1 | tail -8 > gpurun_out/tests.log
 cat gpurun_out/tests.log
 run() { echo "== $1"; env $1 python bench.py --steps 32 --warmup 8 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'])"; }
-run "PTE_SLICE_IMPL=6 PTE_SLICE_M=3"
-run "PTE_SLICE_IMPL=6 PTE_SLICE_M=4"
-run "PTE_SLICE_IMPL=6 PTE_SLICE_M=5"
-run "PTE_SLICE_IMPL=5 PTE_SLICE_M=4"
+run "PTE_SLICE_IMPL=1"
+run "PTE_SLICE_IMPL=2"
+run "PTE_SLICE_IMPL=5"
+run "PTE_SLICE_IMPL=7"
