@@ -128,7 +128,7 @@ def main():
     bytes_per_replica = 16 * d + 32 if args.explorer == "slice" else 8 * d + 32
     alg_bytes = bytes_per_replica * n_chains
     ex_avg_ms = ex_ms / max(ex_n, 1)
-    impl = os.environ.get("PTE_SLICE_IMPL", "7")
+    impl = os.environ.get("PTE_SLICE_IMPL", "8")
     kernel_name = {"slice": "k_explore_slice" + ("" if impl == "1" else impl), "toy": "k_explore_toy"}[args.explorer]
     traffic = None
     try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this kernel at this workload

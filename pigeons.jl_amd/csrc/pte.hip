@@ -16,6 +16,7 @@
 #include "pte_slice2.hpp"
 #include "pte_slice5.hpp"
 #include "pte_slice7.hpp"
+#include "pte_slice8.hpp"
 #include "pte_automala.hpp"
 #include "pte_ising.hpp"
 
@@ -44,7 +45,7 @@ struct pte_engine {
     EngineDev dev{};
     hipStream_t stream = nullptr;
     int nlu = 0;
-    int slice_impl = 7, slice_m = 4;   // PTE_SLICE_IMPL = 1 plain sequential | 2 lane-batched tree path | 5 tree-free batches | 7 offset speculation (default)
+    int slice_impl = 8, slice_m = 4;   // PTE_SLICE_IMPL = 1 plain sequential | 2 lane-batched tree path | 5 tree-free batches | 7 offset speculation, loops | 8 the same, straight-line (default)
     int64_t N = 0, d = 0;          // global chains, state dimension
     int64_t K = 0, c0 = 0;         // local chains [c0, c0+K)
     int world = 1, rank = 0;
@@ -249,6 +250,8 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
             S7Tune tn{2, 8, 2};
             if (const char *t = std::getenv("PTE_S7_BUDGETS")) std::sscanf(t, "%d,%d,%d", &tn.bud_d, &tn.bud_s, &tn.bud_a);
             DISPATCH_NLU(h->nlu, k_explore_slice7, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, tn);
+        } else if (h->slice_impl == 8) {
+            DISPATCH_NLU(h->nlu, k_explore_slice8, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_impl == 5 && h->slice_m == 3) {
             DISPATCH_NLU_M(h->nlu, k_explore_slice5, 3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_impl == 5 && h->slice_m == 6) {

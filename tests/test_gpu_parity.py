@@ -146,7 +146,7 @@ def test_slice_sampler_parity_d1024(P):
         _check_round(P, pt, ref)
 
 
-@pytest.mark.parametrize("impl", ["1", "2", "5", "7"])
+@pytest.mark.parametrize("impl", ["1", "2", "5", "7", "8"])
 @pytest.mark.parametrize("N,d,rounds,seed", [(7, 64, 4, 2), (4, 65, 4, 3), (5, 3, 6, 1), (6, 200, 3, 7), (3, 1024, 2, 1)])
 def test_every_slice_kernel_version_matches_oracle(P, monkeypatch, impl, N, d, rounds, seed):
     """All SliceSampler kernels (PTE_SLICE_IMPL selects; the default is the fastest) are the same function."""

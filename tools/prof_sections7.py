@@ -6,7 +6,7 @@ lib = os.path.join(ROOT, "gpurun_out", "libpte_prof.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                 "-Wno-unused-value", "-DPTE_PROFILE_SECTIONS", *(["-DPTE_DEBUG_S7"] if os.environ.get("S7DBG") else []), "-o", lib, os.path.join(ROOT, "pigeons.jl_amd/csrc/pte.hip")], check=True)
-os.environ["PTE_SLICE_IMPL"] = "7"
+os.environ["PTE_SLICE_IMPL"] = os.environ.get("S_IMPL", "7")
 from pigeons_amd import _lib
 _lib.LIB_PATH = lib
 import numpy as np
