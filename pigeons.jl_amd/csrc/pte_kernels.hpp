@@ -103,14 +103,15 @@ __global__ __launch_bounds__(64) void k_init(EngineDev e, uint64_t master_seed, 
 // reference src/targets/toy_mvn_target.jl:15-21, src/explorers/ToyExplorer.jl:7-12) fused with
 // the evaluation of its swap statistic.
 template <int NLU>
-__device__ __forceinline__ double iid_refresh(const EngineDev &e, int slot, double sd, int lane) {
+__device__ __forceinline__ double iid_refresh(const EngineDev &e, int slot, double sd, int lane,
+                                              const double *wi = ZIG_WI, const unsigned long long *ki = nullptr) {
     SeqRng r{e.rng[2 * slot], e.rng[2 * slot + 1]};
     double *xrow = e.x + (int64_t)slot * e.ld;
     const int B = (int)((e.d + 63) >> 6);
     double BS = 0.0;
     for (int b = 0; b < B; ++b) {
         int nl = (int)min((int64_t)64, e.d - 64 * (int64_t)b);
-        double v = wave_randn_block(r, lane, nl) / sd;
+        double v = wave_randn_block(r, lane, nl, wi, ki) / sd;
         if (lane < nl) xrow[64 * b + lane] = v; else v = 0.0;
         double s = wave_tree_sum64(v * v);
         if (lane == b) BS = s;
@@ -188,10 +189,11 @@ __device__ __forceinline__ void record_after_explore(const EngineDev &e, int64_t
 
 // the same at a chain of the MVN path, with explore!'s recorders around it
 template <int NLU>
-__device__ __forceinline__ void iid_refresh_recorded(const EngineDev &e, int64_t cl, int64_t c, int slot, double sd, int lane) {
+__device__ __forceinline__ void iid_refresh_recorded(const EngineDev &e, int64_t cl, int64_t c, int slot, double sd, int lane,
+                                                     const double *wi = ZIG_WI, const unsigned long long *ki = nullptr) {
     if (e.compose_phase == 2) return;                     // the first explorer's kernel already did
     const double lp0 = lp_before_explore(e, c, slot);
-    const double S = iid_refresh<NLU>(e, slot, sd, lane);
+    const double S = iid_refresh<NLU>(e, slot, sd, lane, wi, ki);
     record_after_explore_impl(e, cl, c, slot, lane, lp0, S, 0.0);
 }
 
@@ -201,12 +203,16 @@ __device__ __forceinline__ void iid_refresh_recorded(const EngineDev &e, int64_t
 // ---------------------------------------------------------------------------------------------
 template <int NLU>
 __global__ __launch_bounds__(64) void k_explore_toy(EngineDev e) {
+    __shared__ double s_wi[256];                          // ziggurat tables in LDS: the per-lane lookups are gathers
+    __shared__ unsigned long long s_ki[256];
     const int lane = lane_id();
+    for (int i = lane; i < 256; i += 64) { s_wi[i] = ZIG_WI[i]; s_ki[i] = ZIG_KI[i]; }
+    __syncthreads();
     const int64_t cl = blockIdx.x;
     if (cl >= e.K) return;
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];
-    iid_refresh_recorded<NLU>(e, cl, c, slot, e.sd[c], lane);
+    iid_refresh_recorded<NLU>(e, cl, c, slot, e.sd[c], lane, s_wi, s_ki);
 }
 
 // ---------------------------------------------------------------------------------------------
