@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                     fin = fin || (lane == 0 && dx < 0.0);
                 }
                 // W > thr2 at the last step (widths only shrink) rules out isapprox(Lbar, Rbar) at every step
-                bool valid = active && !(E != E) && dbl_ok && fin && (W > thr2);
+                bool valid = active && !(E != E) && dbl_ok && fin && (W > thr2) && n <= cap_iters;   // (max_iter < S8_BS: exact path raises)
 #ifdef PTE_PROFILE_SECTIONS
                 asm volatile("" :: "v"(xf), "v"(n), "v"(dmin));
 #endif

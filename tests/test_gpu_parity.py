@@ -815,3 +815,28 @@ def test_checkpoint_resume_equals_uninterrupted_run(P, tmp_path, name):
     # a live PT can be extended as well (increment_n_rounds!(pt, k))
     more = P.pigeons(P.increment_n_rounds(first, 3))
     assert np.array_equal(more.reduced_recorders.index_process, ra.index_process)
+
+
+@pytest.mark.parametrize("impl", ["1", "8"])
+def test_slice_parameters_off_the_defaults(P, monkeypatch, impl):
+    """w, p, n_passes away from the defaults (small p / w exercise the doubling budget and the exact path)."""
+    monkeypatch.setenv("PTE_SLICE_IMPL", impl)
+    for w, p, n_passes in [(0.5, 1, 2), (2.0, 3, 1), (30.0, 20, 2)]:
+        N, d, rounds = 5, 20, 4
+        rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.online]
+        pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=P.SliceSampler(w=w, p=p, n_passes=n_passes),
+                           record=rec, show_report=False))
+        ref = O.OraclePT(n_chains=N, dim=d, explorer=O.EXPLORER_SLICE, record_online=1, slice_w=w, slice_p=p, slice_n_passes=n_passes)
+        for _ in range(rounds):
+            _check_round(P, pt, ref)
+
+
+def test_slice_max_iter_error_is_raised_by_every_kernel(P, monkeypatch):
+    """slice_shrink!'s "Maximum number of iterations reached" (SliceSampler.jl:179-185) with max_iter below the speculation depth."""
+    for impl in ["1", "8"]:
+        monkeypatch.setenv("PTE_SLICE_IMPL", impl)
+        pt = P.PT(P.Inputs(target=P.toy_mvn_target(50), n_chains=4, n_rounds=6, explorer=P.SliceSampler(w=1000.0, max_iter=2),
+                           record=[P.log_sum_ratio], show_report=False))
+        with pytest.raises(P.PteError, match="Maximum number of iterations"):
+            for _ in range(6):
+                P.next_round(pt); P.run_one_round(pt)
