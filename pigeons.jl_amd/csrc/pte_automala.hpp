@@ -185,16 +185,28 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
     double acc_sum = 0.0; int acc_n = 0;
     int err = 0;
 
-    auto log_joint = [&]() -> double { return T.logdensity(x) - 0.5 * sqr_norm_regs<E>(p); };
-    // hamiltonian_dynamics! with n_steps = 1
-    auto leap_frog = [&](double eps) -> bool {
-        T.logdensity_and_gradient(x, g);
+    // The reference re-evaluates the log density / gradient at points where it already has them (the start point of
+    // every trial leapfrog of a step-size search; log_joint right after a leapfrog).  They are pure functions of
+    // the state, so the kernel evaluates each point once and reuses the bits: identical results, ~2.5x fewer funnel
+    // evaluations per auto_step_size call.
+    double g0[E];            // conditioned gradient at the current x (valid after grad_at_start, until x moves for good)
+    double lp0 = 0.0;        // log density at the current x
+    auto grad_at_start = [&]() {
+        lp0 = T.logdensity_and_gradient(x, g0);
+#pragma unroll
+        for (int j = 0; j < E; ++j) g0[j] = g0[j] / M[j];
+    };
+    auto kinetic = [&]() -> double { return 0.5 * sqr_norm_regs<E>(p); };
+    // hamiltonian_dynamics! with n_steps = 1 from a point whose conditioned gradient is g0; logp_out = log density
+    // at the new position (== what log_joint would recompute there)
+    auto leap_frog = [&](double eps, double &logp_out) -> bool {
         const double half = eps / 2;
 #pragma unroll
-        for (int j = 0; j < E; ++j) { g[j] = g[j] / M[j]; p[j] = p[j] + half * g[j]; }
+        for (int j = 0; j < E; ++j) p[j] = p[j] + half * g0[j];
 #pragma unroll
         for (int j = 0; j < E; ++j) x[j] = x[j] + eps * (p[j] / M[j]);
         const double logp = T.logdensity_and_gradient(x, g);
+        logp_out = logp;
 #pragma unroll
         for (int j = 0; j < E; ++j) g[j] = g[j] / M[j];
         const double cur = logp - 0.5 * sqr_norm_regs<E>(p);
@@ -204,15 +216,15 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         if (!isfinite(sqr_norm_regs<E>(p))) return false;
         return true;
     };
-    // auto_step_size (:184-214): returns the exponent
-    auto auto_step_size = [&](double lower, double upper) -> int {
+    // auto_step_size (:184-214): returns the exponent; h_before = log_joint at the start point (g0 / lp0 valid there)
+    auto auto_step_size = [&](double lower, double upper, double h_before) -> int {
 #pragma unroll
         for (int j = 0; j < E; ++j) { xb[j] = x[j]; pb[j] = p[j]; }
-        const double h_before = log_joint();
         double eps = ap.step_size;
         auto diff_at = [&](double ee) -> double {
-            leap_frog(ee);
-            const double h_after = log_joint();
+            double lpn;
+            leap_frog(ee, lpn);
+            const double h_after = lpn - kinetic();
 #pragma unroll
             for (int j = 0; j < E; ++j) { x[j] = xb[j]; p[j] = pb[j]; }
             return h_after - h_before;
@@ -246,13 +258,15 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
             p[j] = 0.0;
             if (nl > 0) { const double v = wave_randn_block(r, lane, nl); p[j] = lane < nl ? v : 0.0; }
         }
-        const double init_joint = log_joint();
+        grad_at_start();
+        const double init_joint = lp0 - kinetic();
         if (!isfinite(init_joint)) { err = ERR_AM_DENSITY; break; }
         if (ap.mala) {                                   // mala! (MALA.jl:79-96)
-            leap_frog(ap.step_size);
+            double lpn;
+            leap_frog(ap.step_size, lpn);
 #pragma unroll
             for (int j = 0; j < E; ++j) p[j] = p[j] * -1.0;
-            const double ex = exp(log_joint() - init_joint);
+            const double ex = exp((lpn - kinetic()) - init_joint);
             const double probability = ex < 1.0 ? ex : (isnan(ex) ? ex : 1.0);
             acc_sum += probability; acc_n += 1;
             if (!(r.rand() < probability)) {
@@ -264,19 +278,22 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         }
         const double ua = r.rand(), ub = r.rand();
         const double lower = log(ua < ub ? ua : ub), upper = log(ua < ub ? ub : ua);
-        const int proposed = auto_step_size(lower, upper);
+        const int proposed = auto_step_size(lower, upper, init_joint);
         if (err) break;
-        leap_frog(ap.step_size * ldexp(1.0, proposed));
+        double lp_moved;
+        leap_frog(ap.step_size * ldexp(1.0, proposed), lp_moved);
         if (ap.use_mh) {
 #pragma unroll
             for (int j = 0; j < E; ++j) p[j] = p[j] * -1.0;
-            const int reversed = auto_step_size(lower, upper);
+            grad_at_start();                              // at the proposed point
+            const double h_rev = lp0 - kinetic();
+            const int reversed = auto_step_size(lower, upper, h_rev);
             if (err) break;
             const bool passed = reversed == proposed;
             rev_sum += passed ? 1 : 0; rev_n += 1;
             double probability = 0.0;
             if (passed) {
-                const double ex = exp(log_joint() - init_joint);
+                const double ex = exp(h_rev - init_joint);      // final_joint_log == log_joint at the proposed point
                 probability = ex < 1.0 ? ex : (isnan(ex) ? ex : 1.0);
             }
             acc_sum += probability; acc_n += 1;
