@@ -59,6 +59,7 @@ enum {                                   /* Inputs.record (src/pt/Inputs.jl:57-6
     PTE_RECORD_INDEX_PROCESS = 1u << 1,  /* index_process  src/recorders/recorder.jl:81                    */
     PTE_RECORD_ONLINE        = 1u << 2,  /* online / _transformed_online (target chain mean, variance)     */
     PTE_RECORD_TRACES        = 1u << 3,  /* traces: [state; log density] of the target chain per scan (src/recorders/recorder.jl:27,39-43; src/pt/pigeons.jl:116-125) */
+    PTE_RECORD_TRACES_EXTENDED = 1u << 5, /* with PTE_RECORD_TRACES: inputs.extended_traces, every chain is traced (src/pt/pigeons.jl:116) */
     PTE_RECORD_ENERGY_AC1    = 1u << 4   /* energy_ac1: per-chain covariance of the log density before / after explore! (recorder.jl:113; pigeons.jl:134-143) */
 };
 
@@ -140,7 +141,8 @@ int pte_get_online_log_density(const pte_engine *h, double *mean, double *varian
 /* energy_ac1s(pt) (src/recorders/recorder.jl:156-173) for the local chains: cor[K] (NaN where n < 2), n[K],
  * moments[5K] = running (mean before, mean after, C_bb, C_ba, C_aa); NULL pointers are skipped. */
 int pte_get_energy_ac1(const pte_engine *h, double *cor, int64_t *n, double *moments);
-/* traces of the last round, out[scan][d+1]; *n_scans = 0 on shards that do not own the target chain. */
+/* traces of the last round, out[scan][d+1]; *n_scans = 0 on shards that do not own the target chain.
+ * With PTE_RECORD_TRACES_EXTENDED: out[scan][K][d+1], the K local chains in chain order, on every shard. */
 int pte_get_traces(const pte_engine *h, double *out, int64_t *n_scans);
 
 /* Replica fields in replica order (src/replicas/Replica.jl:5-30): state [N*d], chain [N],

@@ -856,6 +856,19 @@ static inline double lp_of_replica(const po_pt *pt, const po_replica *r) {   /* 
 static inline int uses_gradient_sampler(const po_config *c) {
     return c->explorer == PO_EXPLORER_AUTOMALA || c->explorer == PO_EXPLORER_MALA || c->explorer2 == PO_EXPLORER_AUTOMALA || c->explorer2 == PO_EXPLORER_MALA;
 }
+static inline int64_t traces_row_width(const po_pt *pt) { return (pt->cfg.record_traces == 2 ? pt->N : 1) * (pt->d + 1); }
+/* called from the serial part of a scan, before the (threaded) explore loop */
+static void traces_reserve(po_pt *pt) {
+    if (!pt->cfg.record_traces) return;
+    const int64_t t = pt->scan - 1, row = traces_row_width(pt);
+    if (t >= pt->traces_cap) {
+        const int64_t ncap = 2 * (t + 1);
+        pt->traces = (double *)realloc(pt->traces, sizeof(double) * (size_t)(ncap * row));
+        memset(pt->traces + pt->traces_cap * row, 0, sizeof(double) * (size_t)((ncap - pt->traces_cap) * row));
+        pt->traces_cap = ncap;
+    }
+    if (t + 1 > pt->traces_n) pt->traces_n = t + 1;
+}
 static int explore_replica_inner(po_pt *pt, po_replica *r);
 static int explore_replica(po_pt *pt, po_replica *r) {
     if (pt->cfg.target == PO_TARGET_TEST_SWAPPER) return 0;   /* state nothing, step! no-op (pair_swapper.jl:137-143) */
@@ -863,15 +876,13 @@ static int explore_replica(po_pt *pt, po_replica *r) {
     const double before = ac ? lp_of_replica(pt, r) : 0.0;    /* eval_if_ac_requested, pigeons.jl:134-137 */
     if (explore_replica_inner(pt, r)) return 1;
     if (ac) cov2_fit(&r->rec.eac[r->chain], before, lp_of_replica(pt, r));   /* process_ac!, :139-143 */
-    if (pt->cfg.record_traces && is_target(pt->N, r->chain) && pt->cfg.target != PO_TARGET_ISING) {   /* pigeons.jl:116-125 */
+    if (pt->cfg.record_traces && pt->cfg.target != PO_TARGET_ISING &&
+        (pt->cfg.record_traces == 2 || is_target(pt->N, r->chain))) {   /* pigeons.jl:116-125; == 2: inputs.extended_traces */
         const int64_t w = pt->d + 1, t = pt->scan - 1;
-        if (t >= pt->traces_cap) {                              /* only the replica at the target chain gets here */
-            pt->traces_cap = 2 * (t + 1);
-            pt->traces = (double *)realloc(pt->traces, sizeof(double) * (size_t)(pt->traces_cap * w));
-        }
-        memcpy(pt->traces + t * w, r->state, sizeof(double) * (size_t)pt->d);
-        pt->traces[t * w + pt->d] = lp_of_replica(pt, r);
-        if (t + 1 > pt->traces_n) pt->traces_n = t + 1;
+        const int64_t row = traces_row_width(pt);                /* capacity ensured by traces_reserve (serial) */
+        double *dst = pt->traces + t * row + (pt->cfg.record_traces == 2 ? r->chain * w : 0);
+        memcpy(dst, r->state, sizeof(double) * (size_t)pt->d);
+        dst[pt->d] = lp_of_replica(pt, r);
     }
     return 0;
 }
@@ -1050,6 +1061,7 @@ int po_run_scans(po_pt *pt, int64_t n_scans) {
     const int64_t N = pt->N;
     for (int64_t t = 0; t < n_scans; t++) {
         pt->scan += 1;
+        traces_reserve(pt);
         int nt = pt->cfg.n_threads > 1 ? pt->cfg.n_threads : 1;
         (void)nt;
         /* explore!: @threads static over replicas sorted by chain (pigeons.jl:82-85) */
@@ -1219,9 +1231,10 @@ void po_get_energy_ac1(const po_pt *pt, double *cor, int64_t *n, double *raw) {
         if (raw) { raw[5 * c] = o->b[0]; raw[5 * c + 1] = o->b[1]; raw[5 * c + 2] = o->A[0]; raw[5 * c + 3] = o->A[1]; raw[5 * c + 4] = o->A[2]; }
     }
 }
-/* traces of the last round: out[scan][d+1] = [state; log density] of the target chain; returns the number of scans */
+/* traces of the last round: out[scan][d+1] = [state; log density] of the target chain (record_traces == 2: out[scan][chain][d+1],
+ * all N chains; rows of chains held by other shards stay zero); returns the number of scans */
 int64_t po_get_traces(const po_pt *pt, double *out) {
-    if (out && pt->reduced_traces) memcpy(out, pt->reduced_traces, sizeof(double) * (size_t)(pt->reduced_traces_n * (pt->d + 1)));
+    if (out && pt->reduced_traces) memcpy(out, pt->reduced_traces, sizeof(double) * (size_t)(pt->reduced_traces_n * traces_row_width(pt)));
     return pt->reduced_traces_n;
 }
 void po_get_online_lp(const po_pt *pt, double *mean, double *var, int64_t *n) {
@@ -1265,6 +1278,7 @@ void po_shard_info(const po_pt *pt, int64_t *c0, int64_t *K, int64_t *n_pairs) {
 }
 int po_shard_explore(po_pt *pt, int64_t scan) {
     pt->scan = scan;
+    traces_reserve(pt);
     for (int64_t cl = 0; cl < pt->K; cl++)
         if (explore_replica(pt, &pt->replicas[pt->replica_of_chain[cl]])) return 1;
     return 0;

@@ -393,6 +393,11 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
         return fail(nullptr, "pte_create: TestSwapper has no explorer");
     if (!swapper && !ising && cfg->explorer != PTE_EXPLORER_TOY && cfg->explorer != PTE_EXPLORER_SLICE && !grad_based(cfg->explorer))
         return fail(nullptr, "pte_create: explorer %d is not implemented on the device", cfg->explorer);
+    if ((cfg->record_flags & PTE_RECORD_TRACES_EXTENDED) && !(cfg->record_flags & PTE_RECORD_TRACES))
+        return fail(nullptr, "pte_create: PTE_RECORD_TRACES_EXTENDED needs PTE_RECORD_TRACES");
+    if ((cfg->record_flags & PTE_RECORD_TRACES) &&
+        (double)cfg->max_scans_per_round * (double)((cfg->record_flags & PTE_RECORD_TRACES_EXTENDED) ? cfg->n_chains / cfg->world_size : 1) * (double)(cfg->dim + 1) * 8.0 > 64e9)
+        return fail(nullptr, "pte_create: the traces buffer (max_scans_per_round x chains x (dim+1) doubles) would exceed 64 GB");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, "pte_create: no HIP device available (this library has no CPU fallback)");
@@ -447,7 +452,8 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.on_mean, (size_t)(d + 1));   rc |= dev_alloc(h, &e.on_m2, (size_t)(d + 1));
     rc |= dev_alloc(h, &e.eac, (size_t)(5 * K)); rc |= dev_alloc(h, &e.eac_n, (size_t)K);
     rc |= dev_alloc(h, &e.lp_stash, (size_t)K);
-    rc |= dev_alloc(h, &e.traces, (cfg->record_flags & PTE_RECORD_TRACES) ? (size_t)(cfg->max_scans_per_round * (d + 1)) : 1, false);
+    const int64_t trace_rows = (cfg->record_flags & PTE_RECORD_TRACES_EXTENDED) ? K : 1;   // chains traced per scan
+    rc |= dev_alloc(h, &e.traces, (cfg->record_flags & PTE_RECORD_TRACES) ? (size_t)(cfg->max_scans_per_round * trace_rows * (d + 1)) : 1, false);
     rc |= dev_alloc(h, &e.on_n, 1);
     const int64_t ipcap = (cfg->record_flags & PTE_RECORD_INDEX_PROCESS) ? cfg->max_scans_per_round * K : 1;
     rc |= dev_alloc(h, &e.index_process, (size_t)ipcap, false);
@@ -618,9 +624,11 @@ int pte_reduce(pte_engine *h) {
     D2H(s.steps_sum.data(), e.expl_steps_sum, K); D2H(s.steps_n.data(), e.expl_steps_n, K);
     D2H(s.on_mean.data(), e.on_mean, d + 1); D2H(m2.data(), e.on_m2, d + 1); D2H(&s.on_n, e.on_n, 1);
     D2H(s.eac_raw.data(), e.eac, 5 * K); D2H(s.eac_n.data(), e.eac_n, K);
-    s.traces_n = (h->cfg.record_flags & PTE_RECORD_TRACES) && h->c0 + K == h->N ? h->scans_in_round : 0;
-    s.traces.assign((size_t)(s.traces_n * (d + 1)), 0.0);
-    if (s.traces_n > 0) D2H(s.traces.data(), e.traces, (size_t)(s.traces_n * (d + 1)));
+    const bool ext_traces = (h->cfg.record_flags & PTE_RECORD_TRACES_EXTENDED) != 0;
+    s.traces_n = (h->cfg.record_flags & PTE_RECORD_TRACES) && (ext_traces || h->c0 + K == h->N) ? h->scans_in_round : 0;
+    const size_t trace_words = (size_t)(s.traces_n * (ext_traces ? K : 1) * (d + 1));
+    s.traces.assign(trace_words, 0.0);
+    if (s.traces_n > 0) D2H(s.traces.data(), e.traces, trace_words);
     std::vector<double> fsum(K), rsum(K);
     h->fac_mean.assign(K, 0.0); h->rev_mean.assign(K, 0.0); h->fac_n.assign(K, 0); h->rev_n.assign(K, 0);
     D2H(fsum.data(), e.am_fac_sum, K); D2H(h->fac_n.data(), e.am_fac_n, K);

@@ -170,15 +170,16 @@ __device__ __forceinline__ void record_after_explore_impl(const EngineDev &e, in
         o[2] += db * (lp_before - mb); o[3] += db * (lp - ma); o[4] += da * (lp - ma);
         o[0] = mb; o[1] = ma; e.eac_n[cl] = n;
     }
-    if (c == e.N - 1 && (f & (4u | 8u))) {
+    if (c == e.N - 1 && (f & 4u)) {
         __threadfence_block();
         if (f & 4u) record_online(e, slot, lane, lp);
-        if (f & 8u) {                                      // traces[(chain, scan)] = [state; lp]
-            const double *xrow = e.x + (int64_t)slot * e.ld;
-            double *row = e.traces + e.trace_idx * (e.d + 1);
-            for (int64_t i = lane; i < e.d; i += 64) row[i] = xrow[i];
-            if (lane == 0) row[e.d] = lp;
-        }
+    }
+    if ((f & 8u) && (c == e.N - 1 || (f & 32u))) {         // traces[(chain, scan)] = [state; lp]; 32: inputs.extended_traces
+        __threadfence_block();
+        const double *xrow = e.x + (int64_t)slot * e.ld;
+        double *row = e.traces + ((f & 32u) ? (e.trace_idx * e.K + cl) : e.trace_idx) * (e.d + 1);
+        for (int64_t i = lane; i < e.d; i += 64) row[i] = xrow[i];
+        if (lane == 0) row[e.d] = lp;
     }
 }
 __device__ __forceinline__ void record_after_explore(const EngineDev &e, int64_t cl, int64_t c, int slot, int lane,

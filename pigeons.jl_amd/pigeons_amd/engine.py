@@ -211,7 +211,8 @@ class Engine:
         """[scan][d+1] = [state; log density] of the target chain over the last round (empty off the target shard)."""
         n = np.zeros(1, dtype=np.int64)
         self._chk(self.L.pte_get_traces(self.h, None, _ip(n)))
-        out = np.zeros((int(n[0]), self.d + 1))
+        ext = bool(int(self.cfg.record_flags) & _lib.RECORD_TRACES_EXTENDED)     # [scan][local chain][d+1]
+        out = np.zeros((int(n[0]), self.K, self.d + 1)) if ext else np.zeros((int(n[0]), self.d + 1))
         if n[0]:
             self._chk(self.L.pte_get_traces(self.h, _dp(out), _ip(n)))
         return out

@@ -273,9 +273,9 @@ class PT:
         if "online" in names:
             flags |= _lib.RECORD_ONLINE
         if "traces" in names:
-            if getattr(inputs, "extended_traces", False):
-                raise NotImplementedError("extended_traces: the device engine records the target chain only")
             flags |= _lib.RECORD_TRACES
+            if getattr(inputs, "extended_traces", False):
+                flags |= _lib.RECORD_TRACES_EXTENDED
         if "energy_ac1" in names:
             flags |= _lib.RECORD_ENERGY_AC1
         kw = dict(device=inputs.device, n_chains=N, seed=inputs.seed, record_flags=flags,
@@ -460,14 +460,18 @@ def sample_array(pt):
     tr = pt.reduced_recorders.traces
     if tr is None or tr.size == 0:
         raise ValueError("no traces recorded: pass record=[traces]")
+    if tr.ndim == 3:                                   # extended_traces: [scan][chain][var] -> [scan, var, chain]
+        return np.transpose(tr, (0, 2, 1)).copy()
     return tr[:, :, None].copy()
 
 
 def get_sample(pt, chain=None, scan=None):
     """src/pt/process_sample.jl get_sample(pt, chain[, scan]) for the target chain (1-based scan)."""
-    if chain is not None and chain != pt.inputs.n_chains:
-        raise ValueError("traces are recorded for the target chain only (extended_traces is not available)")
     tr = pt.reduced_recorders.traces
+    if tr.ndim == 3:                                   # extended_traces
+        tr = tr[:, (pt.inputs.n_chains if chain is None else chain) - 1, :]
+    elif chain is not None and chain != pt.inputs.n_chains:
+        raise ValueError("traces were recorded for the target chain only: pass extended_traces=True")
     return tr if scan is None else tr[scan - 1]
 
 

@@ -26,6 +26,15 @@ import numpy as np
 from .pt import ReducedRecorders
 
 
+def _combine_traces(parts):
+    trs = [p.get("traces") for p in parts]
+    if trs[-1] is None:
+        return None
+    if trs[-1].ndim == 3:                               # extended_traces: every shard traced its local chains
+        return np.concatenate(trs, axis=1)
+    return trs[-1]                                      # the last shard owns the target chain
+
+
 def combine_reduced(parts, N, d):
     """Assemble the global reduced recorders from the per-shard slices (ordered by rank)."""
     cat = lambda xs: np.concatenate([np.asarray(x) for x in xs]) if xs else np.zeros(0)
@@ -57,7 +66,7 @@ def combine_reduced(parts, N, d):
                             round_trip=(restarts, trips), index_process=ip,
                             explorer_acceptance_pr=(am, an), explorer_n_steps=(ss, sn), online=online,
                             am_factors=(fm, fn), reversibility_rate=(rm, rn),
-                            online_log_density=parts[-1].get("online_lp"), energy_ac1=eac, traces=parts[-1].get("traces"),
+                            online_log_density=parts[-1].get("online_lp"), energy_ac1=eac, traces=_combine_traces(parts),
                             timing_extrema={"round": None})
 
 

@@ -283,8 +283,10 @@ class OraclePT:
         return cor, n, raw
 
     def traces(self):
+        """[scan][d+1] of the target chain, or [scan][chain][d+1] with record_traces == 2 (extended_traces)."""
         n = int(self.L.po_get_traces(self.h, None))
-        out = np.zeros((n, self.d + 1))
+        ext = int(self.cfg.record_traces) == 2
+        out = np.zeros((n, self.N, self.d + 1)) if ext else np.zeros((n, self.d + 1))
         if n:
             self.L.po_get_traces(self.h, _dp(out))
         return out
@@ -332,7 +334,7 @@ class OracleShard(OraclePT):
             kw["record_round_trip"] = 1 if flags & 1 else 0
             kw["record_index_process"] = 1 if flags & 2 else 0
             kw["record_online"] = 1 if flags & 4 else 0
-            kw["record_traces"] = 1 if flags & 8 else 0
+            kw["record_traces"] = (2 if flags & 32 else 1) if flags & 8 else 0
             kw["record_energy_ac1"] = 1 if flags & 16 else 0
         kw.pop("device", None); kw.pop("max_scans_per_round", None)
         super().__init__(rank=rank, world_size=world_size, **kw)
@@ -385,6 +387,10 @@ class OracleShard(OraclePT):
 
     def online_log_density(self):
         return self.online_lp()[:2]
+
+    def traces(self):
+        t = super().traces()
+        return t[:, self.c0:self.c0 + self.K, :] if t.ndim == 3 else t
 
     def index_process_shard(self):
         n = int(self.L.po_shard_index_process(self.h, None, None)) if False else None

@@ -840,3 +840,23 @@ def test_slice_max_iter_error_is_raised_by_every_kernel(P, monkeypatch):
         with pytest.raises(P.PteError, match="Maximum number of iterations"):
             for _ in range(6):
                 P.next_round(pt); P.run_one_round(pt)
+
+
+@pytest.mark.parametrize("n_shards", [1, 5])
+def test_extended_traces_parity_and_reference_shape(P, n_shards):
+    """inputs.extended_traces (src/pt/pigeons.jl:116): every chain is traced.  Shape assertions of the reference's
+    test/test_traces.jl:7-27 (toy_mvn_target(3), 10 chains, 2 rounds: (4, 3 + 1, 10)) plus parity with the oracle."""
+    N, d, rounds = 10, 3, 2
+    inp = P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, record=[P.traces, P.index_process], extended_traces=True,
+                   show_report=False)
+    pt = P.PT(inp, n_shards=n_shards, device_messages=n_shards > 1)
+    ref = O.OraclePT(n_chains=N, dim=d, explorer=O.EXPLORER_TOY, record_traces=2)
+    for r in range(rounds):
+        assert P.next_round(pt)
+        red = P.run_one_round(pt); P.adapt(pt, red); pt.reduced_recorders = red
+        ref.run_round()
+        np.testing.assert_allclose(red.traces, ref.traces(), rtol=1e-13, atol=1e-300)
+    mtx = P.sample_array(pt)
+    assert mtx.shape == (4, d + 1, N)
+    assert np.array_equal(P.get_sample(pt, 3, 2), red.traces[1, 2, :])
+    assert np.array_equal(P.get_sample(pt, N), red.traces[:, N - 1, :])

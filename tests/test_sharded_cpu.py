@@ -108,3 +108,19 @@ def test_two_gloo_ranks_equal_unsharded_oracle(tmp_path):
     res = json.loads(outs[0][0].strip().splitlines()[-1])
     assert res["ok"], res
     assert sum(res["boundary_swaps"]) > 0
+
+
+def test_loopback_shards_extended_traces():
+    """extended_traces through the shard drivers: every shard traces its local chains, the reduction concatenates them."""
+    from pigeons_amd.sharded import LoopbackShards
+    N, d, G = 8, 3, 4
+    ref = O.OraclePT(n_chains=N, dim=d, explorer=O.EXPLORER_SLICE, record_traces=2)
+    shards = LoopbackShards([O.OracleShard(rank=g, world_size=G, n_chains=N, dim=d, explorer=O.EXPLORER_SLICE, record_traces=2)
+                             for g in range(G)])
+    for n in (2, 4, 8):
+        ref.begin_round(); ref.run_scans(n); ref.L.po_end_round(ref.h)
+        shards.run_scans(1, n)
+        red = shards.reduce()
+        assert red.traces.shape == (n, N, d + 1)
+        assert np.array_equal(red.traces, ref.traces())
+        shards.set_schedule(ref.schedule())
