@@ -199,7 +199,8 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
     auto kinetic = [&]() -> double { return 0.5 * sqr_norm_regs<E>(p); };
     // hamiltonian_dynamics! with n_steps = 1 from a point whose conditioned gradient is g0; logp_out = log density
     // at the new position (== what log_joint would recompute there)
-    auto leap_frog = [&](double eps, double &logp_out) -> bool {
+    // ke_out = 0.5 |p|^2 of the momentum it leaves behind (what log_joint would recompute next)
+    auto leap_frog = [&](double eps, double &logp_out, double &ke_out) -> bool {
         const double half = eps / 2;
 #pragma unroll
         for (int j = 0; j < E; ++j) p[j] = p[j] + half * g0[j];
@@ -209,11 +210,15 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         logp_out = logp;
 #pragma unroll
         for (int j = 0; j < E; ++j) g[j] = g[j] / M[j];
-        const double cur = logp - 0.5 * sqr_norm_regs<E>(p);
+        const double ke_mid = 0.5 * sqr_norm_regs<E>(p);
+        ke_out = ke_mid;
+        const double cur = logp - ke_mid;
         if (!isfinite(cur)) return false;
 #pragma unroll
         for (int j = 0; j < E; ++j) p[j] = p[j] + half * g[j];
-        if (!isfinite(sqr_norm_regs<E>(p))) return false;
+        const double sq = sqr_norm_regs<E>(p);
+        ke_out = 0.5 * sq;
+        if (!isfinite(sq)) return false;
         return true;
     };
     // auto_step_size (:184-214): returns the exponent; h_before = log_joint at the start point (g0 / lp0 valid there)
@@ -222,9 +227,9 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         for (int j = 0; j < E; ++j) { xb[j] = x[j]; pb[j] = p[j]; }
         double eps = ap.step_size;
         auto diff_at = [&](double ee) -> double {
-            double lpn;
-            leap_frog(ee, lpn);
-            const double h_after = lpn - kinetic();
+            double lpn, ken;
+            leap_frog(ee, lpn, ken);
+            const double h_after = lpn - ken;
 #pragma unroll
             for (int j = 0; j < E; ++j) { x[j] = xb[j]; p[j] = pb[j]; }
             return h_after - h_before;
@@ -262,11 +267,11 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         const double init_joint = lp0 - kinetic();
         if (!isfinite(init_joint)) { err = ERR_AM_DENSITY; break; }
         if (ap.mala) {                                   // mala! (MALA.jl:79-96)
-            double lpn;
-            leap_frog(ap.step_size, lpn);
+            double lpn, ken;
+            leap_frog(ap.step_size, lpn, ken);
 #pragma unroll
             for (int j = 0; j < E; ++j) p[j] = p[j] * -1.0;
-            const double ex = exp((lpn - kinetic()) - init_joint);
+            const double ex = exp((lpn - ken) - init_joint);          // |-p|^2 == |p|^2 bit for bit
             const double probability = ex < 1.0 ? ex : (isnan(ex) ? ex : 1.0);
             acc_sum += probability; acc_n += 1;
             if (!(r.rand() < probability)) {
@@ -280,13 +285,16 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         const double lower = log(ua < ub ? ua : ub), upper = log(ua < ub ? ub : ua);
         const int proposed = auto_step_size(lower, upper, init_joint);
         if (err) break;
-        double lp_moved;
-        leap_frog(ap.step_size * ldexp(1.0, proposed), lp_moved);
+        double lp_moved, ke_moved;
+        const bool moved_ok = leap_frog(ap.step_size * ldexp(1.0, proposed), lp_moved, ke_moved);
         if (ap.use_mh) {
 #pragma unroll
             for (int j = 0; j < E; ++j) p[j] = p[j] * -1.0;
-            grad_at_start();                              // at the proposed point
-            const double h_rev = lp0 - kinetic();
+            // log density and conditioned gradient at the proposed point: the leapfrog just computed them
+            lp0 = lp_moved;
+#pragma unroll
+            for (int j = 0; j < E; ++j) g0[j] = g[j];
+            const double h_rev = lp0 - (moved_ok ? ke_moved : kinetic());
             const int reversed = auto_step_size(lower, upper, h_rev);
             if (err) break;
             const bool passed = reversed == proposed;

@@ -124,9 +124,6 @@ __global__ __launch_bounds__(64) void k_explore_ising(EngineDev e, IsingParams i
     }
     __syncthreads();
     for (int s = lane; s < d; s += 64) xrow[s] = spins[s] ? 1.0 : 0.0;
-#ifdef PTE_DEBUG_ISING
-    if (lane == 0) printf("bytes c=%d spp=%lld\n", (int)c, spp);
-#endif
     if (lane == 0) { e.suff[slot] = (double)spp; e.rng[2 * slot] = seed + (uint64_t)p * gamma; }
     record_after_explore(e, cl, c, slot, lane, lp_before, (double)spp, 0.0);
 }
@@ -252,9 +249,6 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
     }
     __syncthreads();
     for (int s = lane; s < d; s += 64) xrow[s] = ((words[s >> 5] >> (s & 31)) & 1u) ? 1.0 : 0.0;
-#ifdef PTE_DEBUG_ISING
-    if (lane == 0) printf("bits c=%d spp=%lld\n", (int)c, spp);
-#endif
     if (lane == 0) { e.suff[slot] = (double)spp; e.rng[2 * slot] = seed; }
     record_after_explore(e, cl, c, slot, lane, lp_before, (double)spp, 0.0);
 }
