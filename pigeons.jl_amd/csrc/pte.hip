@@ -292,8 +292,13 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
     case PTE_EXPLORER_ISING_METROPOLIS: {
         IsingParams ip{(int)std::llround(std::sqrt((double)h->d)), h->cfg.slice_n_passes, h->cfg.target_params[0]};
         time_begin(h, 0);
-        if (ip.L % 32 == 0 && !std::getenv("PTE_ISING_BYTES"))
-            hipLaunchKernelGGL(k_explore_ising_bits, dim3((unsigned)N), dim3(64), (size_t)(h->d / 8), h->stream, h->dev, ip);
+        const char *impl = std::getenv("PTE_ISING_IMPL");      // "bytes" | "bits" | default: lane-speculative bit-packed sweep
+        if (ip.L % 32 == 0 && !std::getenv("PTE_ISING_BYTES") && !(impl && !std::strcmp(impl, "bytes"))) {
+            if (impl && !std::strcmp(impl, "bits"))
+                hipLaunchKernelGGL(k_explore_ising_bits, dim3((unsigned)N), dim3(64), (size_t)(h->d / 8), h->stream, h->dev, ip);
+            else
+                hipLaunchKernelGGL(k_explore_ising_spec, dim3((unsigned)N), dim3(64), (size_t)(h->d / 8), h->stream, h->dev, ip);
+        }
         else
             hipLaunchKernelGGL(k_explore_ising, dim3((unsigned)N), dim3(64), (size_t)h->d, h->stream, h->dev, ip);
         time_end(h);

@@ -253,4 +253,146 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
     record_after_explore(e, cl, c, slot, lane, lp_before, (double)spp, 0.0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_explore_ising_spec: the bit-packed sweep with the 64 lanes as hypotheses, the way k_explore_slice7/8
+// break the slice sampler's chain.  The outcome of site t depends on the sweep so far only through
+// (b, c): the NEW value b of its left neighbour and the number c of uniforms consumed since the chunk
+// started (which picks the uniform it would read).  For a chunk of 7 consecutive sites there are
+// sum_t 2 (t + 1) = 56 such hypotheses: lane t(t+1) + 2c + b evaluates site t under (c, b) in one vector
+// pass (neighbour count, delta, the filtered accept decision against the integer thresholds), and a
+// scalar chase of ~11 instructions per site walks through the true ones.  Guard-band decisions (and chains
+// whose filter is not valid) are taken by the exact arithmetic of the reference, with sum_pair_products
+// recomputed on demand; the final sum_pair_products is recomputed from the lattice by popcounts.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingParams ip) {
+    extern __shared__ unsigned words[];
+    const int lane = lane_id();
+    const int64_t cl = blockIdx.x;
+    if (cl >= e.K) return;
+    const int64_t c = e.c0 + cl;
+    const int slot = e.slot_of_chain[cl];
+    const int L = ip.L, d = L * L, W = L >> 5, NW = d >> 5;
+    double *xrow = e.x + (int64_t)slot * e.ld;
+    uint64_t seed = e.rng[2 * slot];
+    const uint64_t gamma = e.rng[2 * slot + 1];
+    const double lp_before = lp_before_explore(e, c, slot);
+    const bool refresh = (c == 0 && e.N > 1);
+
+    for (int wd = lane; wd < NW; wd += 64) {
+        unsigned v = 0;
+        if (refresh) { for (int t = 0; t < 32; ++t) v |= (unsigned)(mix64(seed + (uint64_t)(32 * wd + t + 1) * gamma) & 1ull) << t; }
+        else         { for (int t = 0; t < 32; ++t) v |= (xrow[32 * wd + t] != 0.0 ? 1u : 0u) << t; }
+        words[wd] = v;
+    }
+    if (refresh) seed += (uint64_t)d * gamma;
+    __syncthreads();
+    // recompute_sum_pair_products from the LDS lattice: every bond once (right + down neighbour products)
+    auto recompute = [&]() -> long long {
+        long long acc = 0;
+        for (int wd = lane; wd < NW; wd += 64) {
+            const int i = wd / W, wj = wd - i * W;
+            const unsigned cur = words[wd], dn = words[(i == L - 1 ? 0 : i + 1) * W + wj];
+            const unsigned nxt = words[i * W + (wj == W - 1 ? 0 : wj + 1)];
+            const unsigned right = (cur >> 1) | (nxt << 31);
+            acc += 64 - 2 * ((int)__popc(cur ^ right) + (int)__popc(cur ^ dn));
+        }
+        for (int k = 1; k < 64; k <<= 1) acc += __shfl_xor(acc, k, 64);
+        return acc;
+    };
+    if (!refresh) {
+        const double beta = e.beta[c], bt = ip.beta_target;
+        const double bb = beta * bt;
+        const double r4 = exp(-4.0 * bb), r8 = exp(-8.0 * bb);
+        auto hi32 = [](double v) { return (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(v)); };
+        auto lo32 = [](double v) { return (unsigned)__builtin_amdgcn_readfirstlane(__double2loint(v)); };
+        const double r4l = r4 * (1.0 - 1e-9), r4h = r4 * (1.0 + 1e-9), r8l = r8 * (1.0 - 1e-9), r8h = r8 * (1.0 + 1e-9);
+        const unsigned r4lo_h = hi32(r4l), r4hi_h = hi32(r4h), r8lo_h = hi32(r8l), r8hi_h = hi32(r8h);
+        const unsigned long long r4lo = ((unsigned long long)r4lo_h << 32) | lo32(r4l), r4hi = ((unsigned long long)r4hi_h << 32) | lo32(r4h);
+        const unsigned long long r8lo = ((unsigned long long)r8lo_h << 32) | lo32(r8l), r8hi = ((unsigned long long)r8hi_h << 32) | lo32(r8h);
+        const bool filter_ok = bb > 1e-6;
+        // this lane's hypothesis (lt, lc, lb): site lt of the chunk, lc uniforms consumed before it, left neighbour now lb
+        int lt = 0;
+        while ((lt + 1) * (lt + 2) <= lane) lt += 1;
+        const int lidx = lane - lt * (lt + 1);
+        const int lc = lidx >> 1;
+        const unsigned lb = (unsigned)(lidx & 1);
+        double unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma));
+        int p = 0;
+        for (int k = 0; k < ip.n_steps; ++k) {
+            for (int i = 0; i < L; ++i) {
+                const int rowu = ((i == 0 ? L : i) - 1) * W, rowd = (i == L - 1 ? 0 : i + 1) * W, row = i * W;
+                unsigned b = lds_word(words, row + W - 1) >> 31;             // left neighbour of (i, 0): (i, L-1), not yet updated
+                unsigned first_updated = 0;
+                for (int wj = 0; wj < W; ++wj) {
+                    unsigned cur = lds_word(words, row + wj);
+                    const unsigned up = lds_word(words, rowu + wj), dn = lds_word(words, rowd + wj);
+                    const unsigned rightbit = (wj == W - 1) ? (first_updated & 1u) : (lds_word(words, row + wj + 1) & 1u);
+                    const unsigned cur0 = cur;
+#pragma unroll
+                    for (int T0 = 0; T0 < 32; T0 += 7) {
+                        const int LEN = (32 - T0) < 7 ? (32 - T0) : 7;
+                        if (p + LEN > 64) { seed += (uint64_t)p * gamma; unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma)); p = 0; }
+                        // ---- vector pass: every (site, consumed, left) hypothesis of the chunk
+                        const int t = (T0 + lt) & 31;
+                        const unsigned rt31 = (W == 1) ? (cur & 1u) : rightbit;
+                        const unsigned sg = (cur >> t) & 1u;
+                        const unsigned rt = (T0 + lt == 31) ? rt31 : ((cur >> ((t + 1) & 31)) & 1u);
+                        const int nb = 2 * (int)(((up >> t) & 1u) + ((dn >> t) & 1u) + lb + rt) - 4;
+                        const int delta = (1 - 2 * (int)sg) * 2 * nb;
+                        const bool need = delta < 0;
+                        const unsigned uhi = (unsigned)__shfl(__double2hiint(unit), (p + lc) & 63, 64);
+                        const unsigned hi_h = delta == -4 ? r4hi_h : r8hi_h, lo_h = delta == -4 ? r4lo_h : r8lo_h;
+                        const bool rej = need && (uhi > hi_h);
+                        const bool amb = need && ((!rej && !(uhi < lo_h)) || !filter_ok);
+                        const int pk = (need ? 1 : 0) | (rej ? 0 : 2) | (amb ? 4 : 0);
+                        // ---- chase
+                        int cc = 0;
+#pragma unroll
+                        for (int s_ = 0; s_ < 7; ++s_) {
+                            if (s_ >= LEN) break;
+                            const int tt = T0 + s_;
+                            int q = __builtin_amdgcn_readlane(pk, s_ * (s_ + 1) + 2 * cc + (int)b);
+                            if (__builtin_expect(q & 4, 0)) {
+                                // guard band (or a chain where the filter is not valid): exact arithmetic of the reference
+                                if (lane == 0) words[row + wj] = cur;
+                                __syncthreads();
+                                const long long spp = recompute();
+                                const unsigned sgs = (cur >> tt) & 1u;
+                                const unsigned rts = tt == 31 ? rt31 : ((cur >> (tt + 1)) & 1u);
+                                const int nbs = 2 * (int)(((up >> tt) & 1u) + ((dn >> tt) & 1u) + b + rts) - 4;
+                                const int dl = (1 - 2 * (int)sgs) * 2 * nbs;
+                                const unsigned uh = (unsigned)__builtin_amdgcn_readlane(__double2hiint(unit), p + cc);
+                                const unsigned ul = (unsigned)__builtin_amdgcn_readlane(__double2loint(unit), p + cc);
+                                const unsigned long long ub = ((unsigned long long)uh << 32) | ul;
+                                const unsigned long long lo = dl == -4 ? r4lo : r8lo, hi = dl == -4 ? r4hi : r8hi;
+                                int rj, nd = 1;
+                                if (filter_ok && ub > hi) rj = 1;
+                                else if (filter_ok && ub < lo) rj = 0;
+                                else {
+                                    const double ratio = exp(ising_lp(beta, bt, (double)(spp + dl)) - ising_lp(beta, bt, (double)spp));
+                                    if (ratio < 1) rj = (__longlong_as_double((long long)ub) > ratio) ? 1 : 0;
+                                    else { rj = 0; nd = 0; }          // accept_ratio >= 1: the reference draws nothing
+                                }
+                                q = nd | (rj ? 0 : 2);
+                            }
+                            cur ^= (unsigned)((q >> 1) & 1) << tt;
+                            b = (cur >> tt) & 1u;
+                            cc += q & 1;
+                        }
+                        p += cc;
+                    }
+                    if (cur != cur0 && lane == 0) words[row + wj] = cur;
+                    if (wj == 0) first_updated = cur;
+                }
+            }
+        }
+        seed += (uint64_t)p * gamma;
+    }
+    __syncthreads();
+    const long long spp = recompute();
+    for (int s = lane; s < d; s += 64) xrow[s] = ((words[s >> 5] >> (s & 31)) & 1u) ? 1.0 : 0.0;
+    if (lane == 0) { e.suff[slot] = (double)spp; e.rng[2 * slot] = seed; }
+    record_after_explore(e, cl, c, slot, lane, lp_before, (double)spp, 0.0);
+}
+
 }  // namespace pte

@@ -573,25 +573,26 @@ def test_config5_ising_full_size_properties(P):
 
 @pytest.mark.parametrize("L,N", [(32, 5), (64, 4)])
 def test_ising_bitpacked_kernel_equals_byte_kernel_and_oracle(P, L, N, monkeypatch):
-    """L % 32 == 0 selects the bit-packed scalar kernel; PTE_ISING_BYTES forces the byte kernel."""
+    """L % 32 == 0 selects the lane-speculative bit-packed kernel; PTE_ISING_IMPL = bits / bytes select the scalar
+    bit-packed and the byte-lattice kernels.  All three are the same function."""
     mk = lambda: P.PT(P.Inputs(target=P.IsingLogPotential(0.5, L), n_chains=N, n_rounds=3, show_report=False, seed=7,
                                record=[P.round_trip, P.index_process, P.log_sum_ratio]))
-    a = mk()
-    monkeypatch.setenv("PTE_ISING_BYTES", "1")
-    b = mk()
-    monkeypatch.delenv("PTE_ISING_BYTES")
+    pts = {}
+    for impl in ("spec", "bits", "bytes"):
+        monkeypatch.setenv("PTE_ISING_IMPL", impl)
+        pts[impl] = mk()
     ref = O.OraclePT(target=O.TARGET_ISING, explorer=O.EXPLORER_ISING, dim=L * L, p0=0.5, n_chains=N, seed=7, slice_n_passes=3)
     for _ in range(3):
-        P.next_round(a); ra = P.run_one_round(a); P.adapt(a, ra)
-        monkeypatch.setenv("PTE_ISING_BYTES", "1")
-        P.next_round(b); rb = P.run_one_round(b); P.adapt(b, rb)
-        monkeypatch.delenv("PTE_ISING_BYTES")
         ref.run_round()
-        assert np.array_equal(ra.index_process, rb.index_process) and np.array_equal(ra.index_process, ref.index_process())
-    for x in (a, b):
+        for impl, x in pts.items():
+            monkeypatch.setenv("PTE_ISING_IMPL", impl)
+            P.next_round(x); r = P.run_one_round(x); P.adapt(x, r)
+            assert np.array_equal(r.index_process, ref.index_process()), impl
+            np.testing.assert_allclose(P.stepping_stone_pair(x), ref.stepping_stone_pair(), rtol=RTOL)
+    for impl, x in pts.items():
         xs, cs, rs = x.replicas.states()
         xr, cr, rr = ref.states()
-        assert np.array_equal(xs, xr) and np.array_equal(cs, cr) and np.array_equal(rs, rr)
+        assert np.array_equal(xs, xr) and np.array_equal(cs, cr) and np.array_equal(rs, rr), impl
 
 
 # ---------------------------------------------------------------------------------------------
