@@ -1,0 +1,31 @@
+"""One-off stress: the default SliceSampler kernel against the plain sequential kernel (PTE_SLICE_IMPL=1) on many
+seeds / shapes / parameters -- both on the GPU, so large sizes are cheap.  Everything must be bit-identical."""
+import os, sys, itertools
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "pigeons.jl_amd")]
+import numpy as np
+import pigeons_amd as P
+
+def run(impl, N, d, seed, rounds, w, p):
+    os.environ["PTE_SLICE_IMPL"] = impl
+    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, seed=seed, explorer=P.SliceSampler(w=w, p=p),
+                       record=[P.round_trip, P.index_process, P.log_sum_ratio, P.energy_ac1], show_report=False))
+    out = []
+    for _ in range(rounds):
+        P.next_round(pt); red = P.run_one_round(pt); P.adapt(pt, red)
+        out.append((red.index_process.copy(), red.swap_acceptance_pr[0].copy(), red.explorer_n_steps[0].copy(), red.energy_ac1[2].copy()))
+    return out, pt.replicas.states()
+
+bad = 0; n = 0
+shapes = [(64, 300), (33, 64), (16, 1000), (128, 129), (8, 4096), (50, 7)]
+params = [(10.0, 20), (1.0, 20), (0.2, 4), (100.0, 20)]
+for (N, d), (w, p), seed in itertools.product(shapes, params, range(1, 7)):
+    rounds = 4 if d >= 1000 else 5
+    a, sa = run("1", N, d, seed, rounds, w, p)
+    b, sb = run(os.environ.get("STRESS_IMPL", "8"), N, d, seed, rounds, w, p)
+    ok = all(np.array_equal(x, y) for ra, rb in zip(a, b) for x, y in zip(ra, rb)) and all(np.array_equal(x, y) for x, y in zip(sa, sb))
+    n += 1
+    if not ok:
+        bad += 1
+        print("MISMATCH", N, d, w, p, seed, flush=True)
+print("stress: %d configurations, %d mismatches" % (n, bad))
