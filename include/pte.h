@@ -94,6 +94,12 @@ typedef struct pte_config {
     int32_t  rank;
     int32_t  world_size;
     int32_t  explorer2;          /* Compose(explorer, explorer2), src/explorers/Compose.jl:5-19; PTE_EXPLORER_NONE = single explorer */
+    /* StabilizedPT with inputs.variational == nothing (src/tempering/StabilizedPT.jl:37-51, src/swap/VariationalDEO.jl):
+     * n_chains fixed-leg chains + n_chains_variational variational-leg chains, N = their sum (Inputs.jl:128); global
+     * chain order = variational leg reference -> target, then the fixed leg target -> reference; references at both
+     * ends, the two targets in the middle.  pte_set_schedule takes the N per-chain betas in that order
+     * (concatenate_log_potentials, StabilizedPT.jl:67-69).  0 = one leg (NonReversiblePT).  Single engine only. */
+    int64_t  n_chains_variational;
 } pte_config;
 
 typedef struct pte_engine pte_engine;
@@ -135,13 +141,14 @@ int pte_get_explorer_stats(const pte_engine *h, double *acceptance_mean /*N*/, i
                            double *n_steps_sum /*N*/, int64_t *n_steps_n /*N*/);
 int pte_get_automala_stats(const pte_engine *h, double *factor_mean /*N*/, int64_t *factor_n /*N*/,
                            double *reversibility_mean /*N*/, int64_t *reversibility_n /*N*/);
-int pte_get_online(const pte_engine *h, double *mean /*d*/, double *variance /*d*/, int64_t *n);
+int pte_get_online(const pte_engine *h, double *mean /*d*/, double *variance /*d*/, int64_t *n);   /* two legs: both target chains, merged */
 /* the (d+1)-th entry of the `online` sample extract_sample(state::Array, lp) = [state; lp(state)] (src/pt/state.jl:79) */
 int pte_get_online_log_density(const pte_engine *h, double *mean, double *variance);
 /* energy_ac1s(pt) (src/recorders/recorder.jl:156-173) for the local chains: cor[K] (NaN where n < 2), n[K],
  * moments[5K] = running (mean before, mean after, C_bb, C_ba, C_aa); NULL pointers are skipped. */
 int pte_get_energy_ac1(const pte_engine *h, double *cor, int64_t *n, double *moments);
-/* traces of the last round, out[scan][d+1]; *n_scans = 0 on shards that do not own the target chain.
+/* traces of the last round, out[scan][d+1] (two legs: out[scan][2][d+1], the variational leg's target first);
+ * *n_scans = 0 on shards that do not own the target chain.
  * With PTE_RECORD_TRACES_EXTENDED: out[scan][K][d+1], the K local chains in chain order, on every shard. */
 int pte_get_traces(const pte_engine *h, double *out, int64_t *n_scans);
 

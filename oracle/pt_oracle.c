@@ -371,6 +371,8 @@ struct po_pt {
     int64_t *reduced_ip;         /* [replica][scan]                               */
     int64_t  reduced_ip_cap;
     double   global_barrier;
+    double   global_barrier_var;  /* two legs: barrier of the variational leg (global_barrier is the fixed leg's) */
+    double  *sched_var, *sched_fix;   /* two legs: the legs' own schedules, reference -> target */
     double  *cb_x, *cb_y, *cb_m, *cb_c, *cb_d;  /* cumulative barrier interpolant */
     int      cb_valid;
     double   stepping_stone[2];
@@ -393,7 +395,7 @@ void po_default_config(po_config *c) {
     c->am_base_n_refresh = 3; c->am_exponent_n_refresh = 0.35; c->am_step_size = 1.0;
     c->am_preconditioner = 2; c->am_p0 = 1.0 / 3.0; c->am_p1 = 1.0 / 3.0;
     c->record_round_trip = 1; c->record_index_process = 1; c->record_online = 0;
-    c->record_traces = 0; c->record_energy_ac1 = 0; c->explorer2 = PO_EXPLORER_NONE;
+    c->record_traces = 0; c->record_energy_ac1 = 0; c->explorer2 = PO_EXPLORER_NONE; c->n_chains_variational = 0;
     c->n_threads = 1;
     c->rank = 0; c->world_size = 1;
 }
@@ -523,8 +525,23 @@ static int64_t partner_chain(int64_t N, int even, int64_t chain0) {
     if (proposed == N + 1) return N - 1;
     return proposed - 1;
 }
-static inline int is_reference(int64_t N, int64_t chain0) { return chain0 == 0 && N > 1; }  /* DEO.jl:13 */
-static inline int is_target(int64_t N, int64_t chain0) { return chain0 == N - 1; }          /* DEO.jl:14 */
+/* One leg: deo (DEO.jl:13-14).  Two legs (n_var > 0): variational_deo -- references at both ends, targets in the
+ * middle.  NB the reference has TWO target predicates: explore! asks the VariationalDEO (n_chains_var based,
+ * VariationalDEO.jl:20-21), swap! / round trips ask the VariationalOddEven (n_chains_fixed based, OddEven.jl:47-48). */
+#define NVAR(pt) ((pt)->cfg.n_chains_variational)
+#define NFIX(pt) ((pt)->cfg.n_chains)
+static inline int is_reference_pt(const po_pt *pt, int64_t c) {
+    if (NVAR(pt) > 0) return c == 0 || c == pt->N - 1;
+    return c == 0 && pt->N > 1;
+}
+static inline int is_target_explore(const po_pt *pt, int64_t c) {
+    if (NVAR(pt) > 0) return c == NVAR(pt) - 1 || c == NVAR(pt);
+    return c == pt->N - 1;
+}
+static inline int is_target_swap(const po_pt *pt, int64_t c) {
+    if (NVAR(pt) > 0) return c == NFIX(pt) - 1 || c == NFIX(pt);
+    return c == pt->N - 1;
+}
 
 
 /* ---- 2-D Ising model (reference examples/ising.jl) ------------------------------------------------
@@ -856,7 +873,9 @@ static inline double lp_of_replica(const po_pt *pt, const po_replica *r) {   /* 
 static inline int uses_gradient_sampler(const po_config *c) {
     return c->explorer == PO_EXPLORER_AUTOMALA || c->explorer == PO_EXPLORER_MALA || c->explorer2 == PO_EXPLORER_AUTOMALA || c->explorer2 == PO_EXPLORER_MALA;
 }
-static inline int64_t traces_row_width(const po_pt *pt) { return (pt->cfg.record_traces == 2 ? pt->N : 1) * (pt->d + 1); }
+static inline int64_t traces_row_width(const po_pt *pt) {   /* extended: all chains; two legs: the two target chains */
+    return (pt->cfg.record_traces == 2 ? pt->N : (pt->cfg.n_chains_variational > 0 ? 2 : 1)) * (pt->d + 1);
+}
 /* called from the serial part of a scan, before the (threaded) explore loop */
 static void traces_reserve(po_pt *pt) {
     if (!pt->cfg.record_traces) return;
@@ -877,10 +896,10 @@ static int explore_replica(po_pt *pt, po_replica *r) {
     if (explore_replica_inner(pt, r)) return 1;
     if (ac) cov2_fit(&r->rec.eac[r->chain], before, lp_of_replica(pt, r));   /* process_ac!, :139-143 */
     if (pt->cfg.record_traces && pt->cfg.target != PO_TARGET_ISING &&
-        (pt->cfg.record_traces == 2 || is_target(pt->N, r->chain))) {   /* pigeons.jl:116-125; == 2: inputs.extended_traces */
+        (pt->cfg.record_traces == 2 || is_target_explore(pt, r->chain))) {   /* pigeons.jl:116-125; == 2: inputs.extended_traces */
         const int64_t w = pt->d + 1, t = pt->scan - 1;
         const int64_t row = traces_row_width(pt);                /* capacity ensured by traces_reserve (serial) */
-        double *dst = pt->traces + t * row + (pt->cfg.record_traces == 2 ? r->chain * w : 0);
+        double *dst = pt->traces + t * row + (pt->cfg.record_traces == 2 ? r->chain * w : (r->chain == NVAR(pt) && NVAR(pt) > 0 ? w : 0));
         memcpy(dst, r->state, sizeof(double) * (size_t)pt->d);
         dst[pt->d] = lp_of_replica(pt, r);
     }
@@ -889,11 +908,11 @@ static int explore_replica(po_pt *pt, po_replica *r) {
 static int explore_replica_inner(po_pt *pt, po_replica *r) {
     const int64_t N = pt->N;
     if (pt->cfg.target == PO_TARGET_ISING) {
-        if (is_reference(N, r->chain)) ising_sample_iid(pt, r);
+        if (is_reference_pt(pt, r->chain)) ising_sample_iid(pt, r);
         else ising_step(pt, r);
         return 0;
     }
-    if (is_reference(N, r->chain)) {
+    if (is_reference_pt(pt, r->chain)) {
         mvn_sample_iid(pt, r);
     } else {
         const int32_t kinds[2] = { pt->cfg.explorer, pt->cfg.explorer2 };      /* step!(::Compose), Compose.jl:16-19 */
@@ -909,7 +928,7 @@ static int explore_replica_inner(po_pt *pt, po_replica *r) {
             }
         }
     }
-    if (is_target(N, r->chain) && (pt->cfg.record_online || (uses_gradient_sampler(&pt->cfg) && pt->cfg.am_preconditioner != 0))) {
+    if (is_target_explore(pt, r->chain) && (pt->cfg.record_online || (uses_gradient_sampler(&pt->cfg) && pt->cfg.am_preconditioner != 0))) {
         for (int64_t i = 0; i < pt->d; i++) {       /* OnlineStateRecorder.jl:87-96 */
             mean_fit(&r->rec.on_mean[i], r->state[i]);
             var_fit(&r->rec.on_var[i], r->state[i]);
@@ -965,7 +984,7 @@ static void half_swap(po_pt *pt, po_replica *r, const swap_stat_t *mine, const s
         }
         r->rec.ip[r->rec.ip_len++] = r->chain;
     }
-    if (pt->cfg.record_round_trip) round_trip_record(&r->rec.rt, is_reference(N, r->chain), is_target(N, r->chain));
+    if (pt->cfg.record_round_trip) round_trip_record(&r->rec.rt, is_reference_pt(pt, r->chain), is_target_swap(pt, r->chain));
     if (my_chain == partner) return;
     int do_swap = swap_decision(pt, my_chain, mine, partner, theirs);
     if (my_chain < partner && pt->cfg.target != PO_TARGET_TEST_SWAPPER) {
@@ -1000,12 +1019,19 @@ static int communicate(po_pt *pt) {
 /* ========================================================================== */
 /* round loop                                                                 */
 /* ========================================================================== */
+/* concatenate_log_potentials (StabilizedPT.jl:67-69): variational leg reference -> target, then the fixed leg reversed */
+static void assemble_betas(po_pt *pt) {
+    const int64_t nv = pt->cfg.n_chains_variational, nf = pt->cfg.n_chains;
+    for (int64_t i = 0; i < nv; i++) pt->betas[i] = pt->sched_var[i];
+    for (int64_t i = 0; i < nf; i++) pt->betas[nv + i] = pt->sched_fix[nf - 1 - i];
+}
 po_pt *po_create(const po_config *cfg) {
     po_pt *pt = (po_pt *)calloc(1, sizeof(po_pt));
     pt->cfg = *cfg;
-    const int64_t N = pt->N = cfg->n_chains;
+    const int64_t N = pt->N = cfg->n_chains + (cfg->n_chains_variational > 0 ? cfg->n_chains_variational : 0);   /* Inputs.jl:128 */
     const int64_t d = pt->d = (cfg->target == PO_TARGET_TEST_SWAPPER) ? 0 : cfg->dim;
     const int world = cfg->world_size > 0 ? cfg->world_size : 1;
+    if (world > 1 && cfg->n_chains_variational > 0) { snprintf(pt->err, sizeof pt->err, "oracle: two-leg tempering is not sharded"); pt->failed = 1; return pt; }
     const int64_t K = pt->K = N / world;
     pt->c0 = K * cfg->rank;
     pt->shard_stat = (swap_stat_t_fwd *)calloc((size_t)K, sizeof(swap_stat_t_fwd));
@@ -1013,7 +1039,14 @@ po_pt *po_create(const po_config *cfg) {
     pt->replica_of_chain = (int64_t *)calloc((size_t)N, sizeof(int64_t));
     pt->betas = (double *)calloc((size_t)N, sizeof(double));
     /* equally_spaced_schedule, src/schedules/Schedule.jl:36-44 (range elements i/(N-1)) */
-    if (N == 1) pt->betas[0] = 1.0;
+    if (cfg->n_chains_variational > 0) {                     /* StabilizedPT(inputs), StabilizedPT.jl:37-51 */
+        const int64_t nv = cfg->n_chains_variational, nf = cfg->n_chains;
+        pt->sched_var = (double *)calloc((size_t)nv, sizeof(double));
+        pt->sched_fix = (double *)calloc((size_t)nf, sizeof(double));
+        for (int64_t i = 0; i < nv; i++) pt->sched_var[i] = nv == 1 ? 1.0 : ((i == nv - 1) ? 1.0 : (double)i / (double)(nv - 1));
+        for (int64_t i = 0; i < nf; i++) pt->sched_fix[i] = nf == 1 ? 1.0 : ((i == nf - 1) ? 1.0 : (double)i / (double)(nf - 1));
+        assemble_betas(pt);
+    } else if (N == 1) pt->betas[0] = 1.0;
     else for (int64_t i = 0; i < N; i++) pt->betas[i] = (i == N - 1) ? 1.0 : (double)i / (double)(N - 1);
     pt->step_size = cfg->am_step_size;
     /* _create_locals, src/replicas/replicas.jl:87-98; split_slice, src/utils/misc.jl:21-31 */
@@ -1049,7 +1082,7 @@ void po_destroy(po_pt *pt) {
     free(pt->shard_stat); free(pt->shard_ip_replica); free(pt->shard_ip_chain);
     rec_free(&pt->reduced);
     free(pt->replicas); free(pt->replica_of_chain); free(pt->betas); free(pt->target_std);
-    free(pt->reduced_ip); free(pt->cb_x); free(pt->traces); free(pt->reduced_traces);
+    free(pt->reduced_ip); free(pt->cb_x); free(pt->traces); free(pt->reduced_traces); free(pt->sched_var); free(pt->sched_fix);
     free(pt);
 }
 
@@ -1081,21 +1114,23 @@ static void rejections(const po_pt *pt, double *r) {
         r[i] = 1.0 - (pt->reduced.swap_pr[i].n > 0 ? pt->reduced.swap_pr[i].mu : 0.5);
 }
 
-/* optimal_schedule(_generator), communication_barriers, adaptation.jl:56-93 */
-static int adapt_tempering(po_pt *pt) {
-    const int64_t N = pt->N;
+/* optimal_schedule(_generator), communication_barriers, adaptation.jl:56-93, for one leg: `sched` (n grid points,
+ * reference -> target) is replaced; rej[n-1] are the rejection rates of its pairs in the same order.  The cumulative
+ * barrier interpolant of the OLD schedule is kept in (cbx, cby, cbm, cbc, cbd) when cbx != NULL. */
+static int adapt_leg(po_pt *pt, int64_t N, const double *rej_in, double *sched, double *barrier_out,
+                     double *cbx, double *cby, double *cbm, double *cbc, double *cbd) {
     if (N == 1) return 0;                                   /* NonReversiblePT.jl:53-55 */
-    double *rej = (double *)malloc(sizeof(double) * (size_t)N * 8);
-    double *x = rej + N, *xn = x + N, *m = xn + N, *c = m + N, *dd = c + N, *newb = dd + N, *work = newb + N;
-    rejections(pt, rej);
+    double *rej = (double *)malloc(sizeof(double) * (size_t)N * 10);
+    double *x = rej + N, *xn = x + N, *m = xn + N, *c = m + N, *dd = c + N, *newb = dd + N, *work = newb + N, *tx = work + N, *ty = tx + N;
+    memcpy(rej, rej_in, sizeof(double) * (size_t)(N - 1));
     for (int64_t i = 0; i + 1 < N; i++) if (!(rej[i] >= 0.0)) { free(rej); fail(pt, "Bad intensities"); return 1; }
     /* communication_barriers on the OLD schedule */
-    pt->cb_x[0] = pt->betas[0]; pt->cb_y[0] = 0.0;
+    double *bx = cbx ? cbx : tx, *by = cby ? cby : ty;
+    bx[0] = sched[0]; by[0] = 0.0;
     double acc = 0.0;
-    for (int64_t i = 0; i + 1 < N; i++) { acc += rej[i]; pt->cb_x[i + 1] = pt->betas[i + 1]; pt->cb_y[i + 1] = acc; }
-    pt->global_barrier = acc;
-    po_fc_build(pt->cb_x, pt->cb_y, N, pt->cb_m, pt->cb_c, pt->cb_d);
-    pt->cb_valid = 1;
+    for (int64_t i = 0; i + 1 < N; i++) { acc += rej[i]; bx[i + 1] = sched[i + 1]; by[i + 1] = acc; }
+    *barrier_out = acc;
+    if (cbx) po_fc_build(cbx, cby, N, cbm, cbc, cbd);
     /* optimal_schedule_generator */
     int nudged = 0;
     for (;;) {
@@ -1113,20 +1148,44 @@ static int adapt_tempering(po_pt *pt) {
         }
         break;
     }
-    po_fc_build(xn, pt->betas, N, m, c, dd);
+    po_fc_build(xn, sched, N, m, c, dd);
     newb[0] = 0.0; newb[N - 1] = 1.0;
-    for (int64_t i = 1; i + 1 < N; i++) newb[i] = po_fc_eval(xn, pt->betas, m, c, dd, N, (double)i / (double)(N - 1));
+    for (int64_t i = 1; i + 1 < N; i++) newb[i] = po_fc_eval(xn, sched, m, c, dd, N, (double)i / (double)(N - 1));
     /* Schedule constructor asserts, src/schedules/Schedule.jl:19-23 */
     for (int64_t i = 0; i + 1 < N; i++) if (!(newb[i] < newb[i + 1])) { free(rej); fail(pt, "Invalid schedule"); return 1; }
-    memcpy(pt->betas, newb, sizeof(double) * (size_t)N);
+    memcpy(sched, newb, sizeof(double) * (size_t)N);
     free(rej);
     return 0;
+}
+static int adapt_tempering(po_pt *pt) {
+    const int64_t N = pt->N;
+    double *rej = (double *)malloc(sizeof(double) * (size_t)(N + 1));
+    rejections(pt, rej);
+    int rc;
+    if (pt->cfg.n_chains_variational > 0) {
+        /* adapt_tempering(::StabilizedPT), StabilizedPT.jl:53-65: each leg from its own pairs; the fixed leg's pairs are
+         * (N-1,N), (N-2,N-1), ... read from its reference towards the target (fixed_leg_indices(indexer)[2:end]) */
+        const int64_t nv = pt->cfg.n_chains_variational, nf = pt->cfg.n_chains;
+        double *rf = (double *)malloc(sizeof(double) * (size_t)(nf + 1));
+        for (int64_t k = 0; k + 1 < nf; k++) rf[k] = rej[N - 2 - k];
+        rc = adapt_leg(pt, nv, rej, pt->sched_var, &pt->global_barrier_var, NULL, NULL, NULL, NULL, NULL);
+        if (!rc) rc = adapt_leg(pt, nf, rf, pt->sched_fix, &pt->global_barrier, pt->cb_x, pt->cb_y, pt->cb_m, pt->cb_c, pt->cb_d);
+        if (!rc) { pt->cb_valid = 1; assemble_betas(pt); }
+        free(rf);
+    } else {
+        rc = adapt_leg(pt, N, rej, pt->betas, &pt->global_barrier, pt->cb_x, pt->cb_y, pt->cb_m, pt->cb_c, pt->cb_d);
+        if (!rc && N > 1) pt->cb_valid = 1;
+    }
+    free(rej);
+    return rc;
 }
 
 /* stepping_stone_pair, src/evidence/stepping_stone.jl:28-43 */
 static void stepping_stone(po_pt *pt) {
     double e1 = 0.0, e2 = 0.0;
-    for (int64_t i = 0; i + 1 < pt->N; i++) {
+    /* two legs: only the variational leg's keys (stepping_stone_keys(::StabilizedPT), stepping_stone.jl:53-65) */
+    const int64_t np = pt->cfg.n_chains_variational > 0 ? pt->cfg.n_chains_variational : pt->N;
+    for (int64_t i = 0; i + 1 < np; i++) {
         if (pt->reduced.lsr_up[i].n > 0) e1 += pt->reduced.lsr_up[i].value - log((double)pt->reduced.lsr_up[i].n);
         if (pt->reduced.lsr_dn[i].n > 0) e2 += pt->reduced.lsr_dn[i].value - log((double)pt->reduced.lsr_dn[i].n);
     }
@@ -1193,7 +1252,14 @@ void po_get_states(const po_pt *pt, double *x, int64_t *chain, uint64_t *rng) {
     }
 }
 void po_get_schedule(const po_pt *pt, double *b) { memcpy(b, pt->betas, sizeof(double) * (size_t)pt->N); }
-void po_set_schedule(po_pt *pt, const double *b) { memcpy(pt->betas, b, sizeof(double) * (size_t)pt->N); }
+void po_set_schedule(po_pt *pt, const double *b) {
+    memcpy(pt->betas, b, sizeof(double) * (size_t)pt->N);
+    if (pt->cfg.n_chains_variational > 0) {
+        const int64_t nv = pt->cfg.n_chains_variational, nf = pt->cfg.n_chains;
+        for (int64_t i = 0; i < nv; i++) pt->sched_var[i] = b[i];
+        for (int64_t i = 0; i < nf; i++) pt->sched_fix[nf - 1 - i] = b[nv + i];
+    }
+}
 void po_get_swap_pr(const po_pt *pt, double *mean, int64_t *n) {
     for (int64_t i = 0; i + 1 < pt->N; i++) { mean[i] = pt->reduced.swap_pr[i].mu; n[i] = pt->reduced.swap_pr[i].n; }
 }
@@ -1246,6 +1312,7 @@ int64_t po_get_online(const po_pt *pt, double *mean, double *var) {
 }
 void po_get_stepping_stone(const po_pt *pt, double *pair) { pair[0] = pt->stepping_stone[0]; pair[1] = pt->stepping_stone[1]; }
 double po_get_global_barrier(const po_pt *pt) { return pt->global_barrier; }
+double po_get_global_barrier_variational(const po_pt *pt) { return pt->global_barrier_var; }
 double po_cumulative_barrier(const po_pt *pt, double beta) {
     if (!pt->cb_valid) return NAN;
     return po_fc_eval(pt->cb_x, pt->cb_y, pt->cb_m, pt->cb_c, pt->cb_d, pt->N, beta);
@@ -1300,7 +1367,7 @@ int po_shard_swap_begin(po_pt *pt, int64_t scan, double *stats_out, int32_t *act
         pt->shard_stat[cl].log_ratio = st.log_ratio; pt->shard_stat[cl].uniform = st.uniform;
         pt->shard_ip_replica[pt->shard_ip_len + slot] = r->replica_index;
         pt->shard_ip_chain[pt->shard_ip_len + slot] = r->chain;
-        if (pt->cfg.record_round_trip) round_trip_record(&r->rec.rt, is_reference(N, r->chain), is_target(N, r->chain));
+        if (pt->cfg.record_round_trip) round_trip_record(&r->rec.rt, is_reference_pt(pt, r->chain), is_target_swap(pt, r->chain));
     }
     pt->shard_ip_len += K;
     stats_out[0] = pt->shard_stat[0].log_ratio; stats_out[1] = pt->shard_stat[0].uniform;

@@ -76,6 +76,9 @@ typedef struct po_config {
     int32_t  record_traces, record_energy_ac1;
     /* Compose(explorer, explorer2) (src/explorers/Compose.jl:5-19); 0 = single explorer */
     int32_t  explorer2;
+    /* StabilizedPT (src/tempering/StabilizedPT.jl) with the fixed reference on both legs
+       (inputs.variational == nothing): n_chains fixed-leg chains + n_chains_variational variational-leg chains */
+    int64_t  n_chains_variational;
 } po_config;
 
 typedef struct po_pt po_pt;
@@ -126,6 +129,7 @@ void    po_get_energy_ac1(const po_pt *pt, double *cor /*N*/, int64_t *n /*N*/, 
 int64_t po_get_traces(const po_pt *pt, double *out /*[scan][d+1]*/);              /* returns the number of scans */
 void    po_get_stepping_stone(const po_pt *pt, double *pair);                    /* 2        */
 double  po_get_global_barrier(const po_pt *pt);
+double  po_get_global_barrier_variational(const po_pt *pt);   /* StabilizedPT.jl:117-119 */
 double  po_cumulative_barrier(const po_pt *pt, double beta);
 double  po_get_step_size(const po_pt *pt);
 int64_t po_get_target_std(const po_pt *pt, double *out);                         /* d; returns 0 if `nothing` */

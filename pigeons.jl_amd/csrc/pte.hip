@@ -31,7 +31,7 @@ struct Snapshot {   // reduced recorders of the last round, host side
     std::vector<double> lsr_up, lsr_dn; std::vector<int64_t> lsr_n;
     int64_t restarts = 0, trips = 0;
     std::vector<double> acc_mean, steps_sum; std::vector<int64_t> acc_n, steps_n;
-    std::vector<double> on_mean, on_var; int64_t on_n = 0;   // d + 1 entries: [state; log density]
+    std::vector<double> on_mean, on_var; int64_t on_n = 0;   // d + 1 entries: [state; log density] (two legs: both targets merged)
     std::vector<double> eac_cor, eac_raw; std::vector<int64_t> eac_n;   // energy_ac1 per local chain
     std::vector<double> traces; int64_t traces_n = 0;        // [scan][d+1]
     std::vector<int32_t> ip_chain, ip_replica;   // [scan][slot]
@@ -165,11 +165,11 @@ int reset_recorders(pte_engine *h) {
     HIP_OK(h, hipMemsetAsync(e.am_rev_sum, 0, sizeof(double) * N, h->stream));
     HIP_OK(h, hipMemsetAsync(e.am_rev_n, 0, sizeof(int64_t) * N, h->stream));
     const int64_t dd = h->d > 0 ? h->d : 1;
-    HIP_OK(h, hipMemsetAsync(e.on_mean, 0, sizeof(double) * (h->d + 1), h->stream));
-    HIP_OK(h, hipMemsetAsync(e.on_m2, 0, sizeof(double) * (h->d + 1), h->stream));
+    HIP_OK(h, hipMemsetAsync(e.on_mean, 0, sizeof(double) * 2 * (h->d + 1), h->stream));
+    HIP_OK(h, hipMemsetAsync(e.on_m2, 0, sizeof(double) * 2 * (h->d + 1), h->stream));
     HIP_OK(h, hipMemsetAsync(e.eac, 0, sizeof(double) * 5 * N, h->stream));
     HIP_OK(h, hipMemsetAsync(e.eac_n, 0, sizeof(int64_t) * N, h->stream));
-    HIP_OK(h, hipMemsetAsync(e.on_n, 0, sizeof(int64_t), h->stream));
+    HIP_OK(h, hipMemsetAsync(e.on_n, 0, 2 * sizeof(int64_t), h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));   // `ninf` must outlive the copies
     h->scans_in_round = 0;
     return 0;
@@ -370,6 +370,8 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
                     cfg->struct_size, sizeof(pte_config), cfg->abi_version, PTE_ABI_VERSION);
     if (cfg->n_chains < 1) return fail(nullptr, "pte_create: n_chains must be >= 1");
     if (cfg->world_size < 1 || cfg->rank < 0 || cfg->rank >= cfg->world_size) return fail(nullptr, "pte_create: bad rank / world_size");
+    if (cfg->n_chains_variational < 0) return fail(nullptr, "pte_create: n_chains_variational must be >= 0");
+    if (cfg->n_chains_variational > 0 && cfg->world_size != 1) return fail(nullptr, "pte_create: two-leg tempering (n_chains_variational > 0) runs on a single engine");
     if (cfg->n_chains % cfg->world_size != 0) return fail(nullptr, "pte_create: n_chains (%lld) must be a multiple of world_size (%d)", (long long)cfg->n_chains, cfg->world_size);
     const bool swapper = cfg->target == PTE_TARGET_TEST_SWAPPER;
     const bool funnel = cfg->target == PTE_TARGET_FUNNEL;
@@ -410,7 +412,7 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
 
     pte_engine *h = new pte_engine();
     h->cfg = *cfg;
-    const int64_t N = h->N = cfg->n_chains;
+    const int64_t N = h->N = cfg->n_chains + cfg->n_chains_variational;      // Inputs.jl:128
     const int64_t d = h->d = swapper ? 0 : cfg->dim;
     h->world = cfg->world_size; h->rank = cfg->rank;
     const int64_t K = h->K = N / cfg->world_size;
@@ -454,12 +456,12 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.rt_trips, (size_t)K);
     rc |= dev_alloc(h, &e.expl_acc_sum, (size_t)K);   rc |= dev_alloc(h, &e.expl_acc_n, (size_t)K);
     rc |= dev_alloc(h, &e.expl_steps_sum, (size_t)K); rc |= dev_alloc(h, &e.expl_steps_n, (size_t)K);
-    rc |= dev_alloc(h, &e.on_mean, (size_t)(d + 1));   rc |= dev_alloc(h, &e.on_m2, (size_t)(d + 1));
+    rc |= dev_alloc(h, &e.on_mean, (size_t)(2 * (d + 1)));   rc |= dev_alloc(h, &e.on_m2, (size_t)(2 * (d + 1)));
     rc |= dev_alloc(h, &e.eac, (size_t)(5 * K)); rc |= dev_alloc(h, &e.eac_n, (size_t)K);
     rc |= dev_alloc(h, &e.lp_stash, (size_t)K);
-    const int64_t trace_rows = (cfg->record_flags & PTE_RECORD_TRACES_EXTENDED) ? K : 1;   // chains traced per scan
+    const int64_t trace_rows = (cfg->record_flags & PTE_RECORD_TRACES_EXTENDED) ? K : (cfg->n_chains_variational > 0 ? 2 : 1);   // chains traced per scan
     rc |= dev_alloc(h, &e.traces, (cfg->record_flags & PTE_RECORD_TRACES) ? (size_t)(cfg->max_scans_per_round * trace_rows * (d + 1)) : 1, false);
-    rc |= dev_alloc(h, &e.on_n, 1);
+    rc |= dev_alloc(h, &e.on_n, 2);
     const int64_t ipcap = (cfg->record_flags & PTE_RECORD_INDEX_PROCESS) ? cfg->max_scans_per_round * K : 1;
     rc |= dev_alloc(h, &e.index_process, (size_t)ipcap, false);
     rc |= dev_alloc(h, &e.ip_replica, (size_t)ipcap, false);
@@ -476,8 +478,16 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
 
     // equally_spaced_schedule (reference src/schedules/Schedule.jl:36-44)
     h->betas.resize(N);
-    if (N == 1) h->betas[0] = 1.0;
-    else for (int64_t i = 0; i < N; ++i) h->betas[i] = (i == N - 1) ? 1.0 : (double)i / (double)(N - 1);
+    auto equally_spaced = [](int64_t n, int64_t i) { return n == 1 ? 1.0 : ((i == n - 1) ? 1.0 : (double)i / (double)(n - 1)); };
+    if (cfg->n_chains_variational > 0) {       // StabilizedPT(inputs): both legs equally spaced, the fixed leg reversed
+        const int64_t nv = cfg->n_chains_variational, nf = cfg->n_chains;
+        for (int64_t i = 0; i < nv; ++i) h->betas[i] = equally_spaced(nv, i);
+        for (int64_t i = 0; i < nf; ++i) h->betas[nv + i] = equally_spaced(nf, nf - 1 - i);
+        e.ref2 = N - 1; e.tgt_a = nv - 1; e.tgt_b = nv; e.rt_tgt_a = nf - 1; e.rt_tgt_b = nf;
+    } else {
+        for (int64_t i = 0; i < N; ++i) h->betas[i] = equally_spaced(N, i);
+        e.ref2 = -1; e.tgt_a = e.tgt_b = e.rt_tgt_a = e.rt_tgt_b = N - 1;
+    }
     if (upload_ladder(h)) return bail(1);
     if (reset_recorders(h)) return bail(1);
     const double init_sd = swapper ? 1.0 : std::sqrt(cfg->target_params[1]);   // toy_mvn_target.jl:10-11
@@ -545,11 +555,16 @@ int pte_set_schedule(pte_engine *h, const double *betas, int64_t n) {
     if (!h || !betas) return 1;
     if (n != h->N) return fail(h, "pte_set_schedule: expected %lld grid points, got %lld", (long long)h->N, (long long)n);
     // Schedule constructor asserts (reference src/schedules/Schedule.jl:14-27)
-    if (n == 1) { if (betas[0] != 1.0) return fail(h, "Invalid schedule"); }
-    else {
-        if (betas[0] != 0.0 || betas[n - 1] != 1.0) return fail(h, "Invalid schedule: end points must be 0 and 1");
-        for (int64_t i = 0; i + 1 < n; ++i) if (!(betas[i] < betas[i + 1])) return fail(h, "Invalid schedule: not strictly increasing");
-    }
+    auto check_leg = [&](const double *b, int64_t m, int64_t stride) -> bool {   // grid of one leg, reference -> target
+        if (m == 1) return b[0] == 1.0;
+        if (b[0] != 0.0 || b[(m - 1) * stride] != 1.0) return false;
+        for (int64_t i = 0; i + 1 < m; ++i) if (!(b[i * stride] < b[(i + 1) * stride])) return false;
+        return true;
+    };
+    if (h->cfg.n_chains_variational > 0) {
+        const int64_t nv = h->cfg.n_chains_variational, nf = h->cfg.n_chains;
+        if (!check_leg(betas, nv, 1) || !check_leg(betas + n - 1, nf, -1)) return fail(h, "Invalid schedule (two legs: each leg must run 0 -> 1)");
+    } else if (!check_leg(betas, n, 1)) return fail(h, n == 1 ? "Invalid schedule" : "Invalid schedule: end points must be 0 and 1, strictly increasing");
     HIP_OK(h, hipSetDevice(h->cfg.device));
     h->betas.assign(betas, betas + n);
     return upload_ladder(h);
@@ -619,7 +634,8 @@ int pte_reduce(pte_engine *h) {
     s.acc_mean.assign(K, 0.0); s.acc_n.assign(K, 0); s.steps_sum.assign(K, 0.0); s.steps_n.assign(K, 0);
     const int64_t dd = d > 0 ? d : 1;
     std::vector<double> m2(dd);
-    s.on_mean.assign(d + 1, 0.0); s.on_var.assign(d + 1, 0.0); m2.assign(d + 1, 0.0);
+    s.on_mean.assign(2 * (d + 1), 0.0); s.on_var.assign(d + 1, 0.0); m2.assign(2 * (d + 1), 0.0);
+    int64_t on_n2[2] = {0, 0};
     s.eac_raw.assign(5 * K, 0.0); s.eac_n.assign(K, 0); s.eac_cor.assign(K, NAN);
 #define D2H(dst, src, n) HIP_OK(h, hipMemcpyAsync(dst, src, sizeof(*(dst)) * (n), hipMemcpyDeviceToHost, h->stream))
     D2H(swap_sum.data(), e.swap_sum, K); D2H(s.swap_n.data(), e.swap_n, K);
@@ -627,11 +643,11 @@ int pte_reduce(pte_engine *h) {
     D2H(rs.data(), e.rt_restarts, K);     D2H(rr.data(), e.rt_trips, K);
     D2H(acc_sum.data(), e.expl_acc_sum, K); D2H(s.acc_n.data(), e.expl_acc_n, K);
     D2H(s.steps_sum.data(), e.expl_steps_sum, K); D2H(s.steps_n.data(), e.expl_steps_n, K);
-    D2H(s.on_mean.data(), e.on_mean, d + 1); D2H(m2.data(), e.on_m2, d + 1); D2H(&s.on_n, e.on_n, 1);
+    D2H(s.on_mean.data(), e.on_mean, 2 * (d + 1)); D2H(m2.data(), e.on_m2, 2 * (d + 1)); D2H(on_n2, e.on_n, 2);
     D2H(s.eac_raw.data(), e.eac, 5 * K); D2H(s.eac_n.data(), e.eac_n, K);
     const bool ext_traces = (h->cfg.record_flags & PTE_RECORD_TRACES_EXTENDED) != 0;
     s.traces_n = (h->cfg.record_flags & PTE_RECORD_TRACES) && (ext_traces || h->c0 + K == h->N) ? h->scans_in_round : 0;
-    const size_t trace_words = (size_t)(s.traces_n * (ext_traces ? K : 1) * (d + 1));
+    const size_t trace_words = (size_t)(s.traces_n * (ext_traces ? K : (h->cfg.n_chains_variational > 0 ? 2 : 1)) * (d + 1));
     s.traces.assign(trace_words, 0.0);
     if (s.traces_n > 0) D2H(s.traces.data(), e.traces, trace_words);
     std::vector<double> fsum(K), rsum(K);
@@ -653,7 +669,22 @@ int pte_reduce(pte_engine *h) {
     s.restarts = 0; s.trips = 0;
     for (int64_t i = 0; i < K; ++i) { s.restarts += rs[i]; s.trips += rr[i]; }
     for (int64_t i = 0; i < K; ++i) s.acc_mean[i] = s.acc_n[i] > 0 ? acc_sum[i] / (double)s.acc_n[i] : 0.0;
-    for (int64_t i = 0; i <= d; ++i) s.on_var[i] = s.on_n > 1 ? m2[i] / (double)(s.on_n - 1) : 1.0;
+    {   // merge the two target chains' Welford sets (OnlineStats merge of Mean / Variance; one set when there is one leg)
+        const int64_t na = on_n2[0], nb = on_n2[1];
+        s.on_n = na + nb;
+        for (int64_t i = 0; i <= d; ++i) {
+            const double ma = s.on_mean[i], mb = s.on_mean[d + 1 + i];
+            double mean = ma, M2 = m2[i];
+            if (nb > 0) {
+                const double delta = mb - ma;
+                mean = na > 0 ? ma + delta * ((double)nb / (double)(na + nb)) : mb;
+                M2 = m2[i] + m2[d + 1 + i] + (na > 0 ? delta * delta * ((double)na * (double)nb / (double)(na + nb)) : 0.0);
+            }
+            s.on_mean[i] = mean;
+            s.on_var[i] = s.on_n > 1 ? M2 / (double)(s.on_n - 1) : 1.0;
+        }
+        s.on_mean.resize(d + 1);
+    }
     for (int64_t i = 0; i < K; ++i)       // cor(CovMatrix)[1,2]: the Bessel factors cancel
         if (s.eac_n[i] > 1) s.eac_cor[i] = s.eac_raw[5 * i + 3] / std::sqrt(s.eac_raw[5 * i + 2] * s.eac_raw[5 * i + 4]);
     for (int64_t i = 0; i < K; ++i) {

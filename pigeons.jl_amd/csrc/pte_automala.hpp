@@ -132,10 +132,10 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
     T.ref_nhp = -0.5 * ap.ref_prec; T.ref_nprec = -ap.ref_prec; T.log3 = ap.log3;
 
     double x[E];
-    if (c == 0 && e.N > 1) {
+    if (is_ref_chain(e, c)) {
         if (e.compose_phase == 2) return;
         const double lp0 = lp_before_explore(e, c, slot);
-        const double S0 = iid_refresh<NLU>(e, slot, e.sd[0], lane);   // sample_iid! at the reference (pigeons.jl:104-105)
+        const double S0 = iid_refresh<NLU>(e, slot, e.sd[c], lane);   // sample_iid! at the reference (pigeons.jl:104-105)
         __threadfence_block();
         double l20 = 0.0;
         if (TGT == TGT_FUNNEL) {

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void k_explore_ising(EngineDev e, IsingParams i
     const uint64_t gamma = e.rng[2 * slot + 1];
     const double lp_before = lp_before_explore(e, c, slot);
 
-    if (c == 0 && e.N > 1) {
+    if (is_ref_chain(e, c)) {
         // iid_bernoulli!: site s (row-major, i outer / j inner) <- rand(rng, Bool) = low bit of draw s+1
         for (int s = lane; s < d; s += 64) spins[s] = (unsigned char)(mix64(seed + (uint64_t)(s + 1) * gamma) & 1ull);
         seed += (uint64_t)d * gamma;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
     const uint64_t gamma = e.rng[2 * slot + 1];
     const double lp_before = lp_before_explore(e, c, slot);
 
-    if (c == 0 && e.N > 1) {
+    if (is_ref_chain(e, c)) {
         for (int wd = lane; wd < NW; wd += 64) {
             unsigned v = 0;
             for (int t = 0; t < 32; ++t) v |= (unsigned)(mix64(seed + (uint64_t)(32 * wd + t + 1) * gamma) & 1ull) << t;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
     }
     __syncthreads();
     long long spp;
-    if (c == 0 && e.N > 1) {
+    if (is_ref_chain(e, c)) {
         // recompute_sum_pair_products: every bond once = sum over sites of (right + down neighbour products)
         long long acc = 0;
         for (int wd = lane; wd < NW; wd += 64) {
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
     uint64_t seed = e.rng[2 * slot];
     const uint64_t gamma = e.rng[2 * slot + 1];
     const double lp_before = lp_before_explore(e, c, slot);
-    const bool refresh = (c == 0 && e.N > 1);
+    const bool refresh = is_ref_chain(e, c);
 
     for (int wd = lane; wd < NW; wd += 64) {
         unsigned v = 0;

@@ -49,6 +49,9 @@ struct EngineDev {
     double *on_mean; double *on_m2; int64_t *on_n;         // [d+1],[d+1],[1] target-chain online stats of [state; log density]
     double *eac; int64_t *eac_n;                           // [5K],[K] energy_ac1: Welford (mean before, mean after, C_bb, C_ba, C_aa) per local chain
     double *traces; int64_t trace_idx;                     // [max_scans][d+1] target-chain [state; log density]; row of the current scan
+    // StabilizedPT (two legs, src/tempering/StabilizedPT.jl): second reference chain (-1: one leg), the two target chains
+    // explore! asks for (VariationalDEO.jl:20-21) and the two swap! / round trips ask for (OddEven.jl:47-48)
+    int64_t ref2, tgt_a, tgt_b, rt_tgt_a, rt_tgt_b;
     int compose_phase; double *lp_stash;                   // Compose(first, second): 0 single explorer, 1 first, 2 second kernel of the scan; [K] lp before the first
     int32_t *index_process;                                // [scan][slot]
     int32_t *error;                                        // [4] code, chain, coordinate, spare
@@ -58,6 +61,9 @@ struct EngineDev {
 };
 
 struct SliceParams { double w; int p; int n_passes; int max_iter; };
+
+__device__ __forceinline__ bool is_ref_chain(const EngineDev &e, int64_t c) { return (c == 0 && e.N > 1) || c == e.ref2; }
+__device__ __forceinline__ bool is_tgt_chain(const EngineDev &e, int64_t c) { return c == e.tgt_a || c == e.tgt_b; }
 
 __device__ __forceinline__ void set_error(const EngineDev &e, int code, int chain, int coord) {
     if (atomicCAS(&e.error[0], 0, code) == 0) { e.error[1] = chain; e.error[2] = coord; }
@@ -124,16 +130,18 @@ __device__ __forceinline__ double iid_refresh(const EngineDev &e, int slot, doub
 // Target-chain online statistics (reference src/pt/pigeons.jl:110-115,
 // src/recorders/OnlineStateRecorder.jl:87-96): per-coordinate Welford mean / M2 of the recorded sample
 // extract_sample(state::Array, lp) = [state; lp(state)] (src/pt/state.jl:79), so d + 1 entries.
-__device__ __forceinline__ void record_online(const EngineDev &e, int slot, int lane, double lp) {
+// `which`: 0 / 1 = first / second target chain (two legs: one accumulator set each, merged on the host)
+__device__ __forceinline__ void record_online(const EngineDev &e, int slot, int lane, double lp, int which) {
     const double *xrow = e.x + (int64_t)slot * e.ld;
-    int64_t n = e.on_n[0] + 1;
+    double *mean = e.on_mean + which * (e.d + 1), *m2 = e.on_m2 + which * (e.d + 1);
+    int64_t n = e.on_n[which] + 1;
     for (int64_t i = lane; i <= e.d; i += 64) {
-        double v = (i < e.d) ? xrow[i] : lp, mu = e.on_mean[i];
+        double v = (i < e.d) ? xrow[i] : lp, mu = mean[i];
         double mu2 = mu + (v - mu) / (double)n;
-        e.on_m2[i] += (v - mu) * (v - mu2);
-        e.on_mean[i] = mu2;
+        m2[i] += (v - mu) * (v - mu2);
+        mean[i] = mu2;
     }
-    if (lane == 0) e.on_n[0] = n;
+    if (lane == 0) e.on_n[which] = n;
 }
 
 // log_potentials[chain](state) from the swap statistics: S = sum x^2 (Ising: sum_pair_products), l2 = the
@@ -170,14 +178,17 @@ __device__ __forceinline__ void record_after_explore_impl(const EngineDev &e, in
         o[2] += db * (lp_before - mb); o[3] += db * (lp - ma); o[4] += da * (lp - ma);
         o[0] = mb; o[1] = ma; e.eac_n[cl] = n;
     }
-    if (c == e.N - 1 && (f & 4u)) {
+    const bool tgt = is_tgt_chain(e, c);
+    const int which = (c == e.tgt_b && e.tgt_b != e.tgt_a) ? 1 : 0;
+    if (tgt && (f & 4u)) {
         __threadfence_block();
-        if (f & 4u) record_online(e, slot, lane, lp);
+        record_online(e, slot, lane, lp, which);
     }
-    if ((f & 8u) && (c == e.N - 1 || (f & 32u))) {         // traces[(chain, scan)] = [state; lp]; 32: inputs.extended_traces
+    if ((f & 8u) && (tgt || (f & 32u))) {                  // traces[(chain, scan)] = [state; lp]; 32: inputs.extended_traces
         __threadfence_block();
         const double *xrow = e.x + (int64_t)slot * e.ld;
-        double *row = e.traces + ((f & 32u) ? (e.trace_idx * e.K + cl) : e.trace_idx) * (e.d + 1);
+        const int64_t ntgt = (e.tgt_b != e.tgt_a) ? 2 : 1;
+        double *row = e.traces + ((f & 32u) ? (e.trace_idx * e.K + cl) : (e.trace_idx * ntgt + which)) * (e.d + 1);
         for (int64_t i = lane; i < e.d; i += 64) row[i] = xrow[i];
         if (lane == 0) row[e.d] = lp;
     }
@@ -285,8 +296,8 @@ __global__ __launch_bounds__(64) void k_explore_slice(EngineDev e, SliceParams s
     if (cl >= e.K) return;
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];
-    if (c == 0 && e.N > 1) {
-        iid_refresh_recorded<NLU>(e, cl, c, slot, e.sd[0], lane);
+    if (is_ref_chain(e, c)) {
+        iid_refresh_recorded<NLU>(e, cl, c, slot, e.sd[c], lane);
         return;
     }
     const double lp_before = lp_before_explore(e, c, slot);
@@ -480,7 +491,7 @@ __global__ __launch_bounds__(256) void k_swap(EngineDev e, int even, int64_t sca
             e.ip_replica[scan_idx * N + slot] = (int32_t)e.replica_id[slot];
         }
         if (e.record_flags & 1u) {     // RoundTripRecorder.jl:43-54
-            const bool is_ref = (c == 0 && N > 1), is_tgt = (c == N - 1);
+            const bool is_ref = is_ref_chain(e, c), is_tgt = (c == e.rt_tgt_a || c == e.rt_tgt_b);
             int64_t st = e.rt_state[slot];
             if (st == 0 && is_ref) e.rt_state[slot] = 1;
             else if (st == 1 && is_tgt) { e.rt_state[slot] = 2; e.rt_restarts[slot] += 1; }
@@ -544,7 +555,7 @@ __global__ __launch_bounds__(256) void k_swap_stats(EngineDev e, int even, int64
         e.ip_replica[scan_idx * e.K + slot] = (int32_t)e.replica_id[slot];
     }
     if (e.record_flags & 1u) {
-        const bool is_ref = (c == 0 && N > 1), is_tgt = (c == N - 1);
+        const bool is_ref = is_ref_chain(e, c), is_tgt = (c == e.rt_tgt_a || c == e.rt_tgt_b);
         int64_t st = e.rt_state[slot];
         if (st == 0 && is_ref) e.rt_state[slot] = 1;
         else if (st == 1 && is_tgt) { e.rt_state[slot] = 2; e.rt_restarts[slot] += 1; }

@@ -55,8 +55,8 @@ __global__ __launch_bounds__(64) void k_explore_slice7(EngineDev e, SliceParams 
     if (cl >= e.K) return;
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];
-    if (c == 0 && e.N > 1) {
-        iid_refresh_recorded<NLU>(e, cl, c, slot, e.sd[0], lane);
+    if (is_ref_chain(e, c)) {
+        iid_refresh_recorded<NLU>(e, cl, c, slot, e.sd[c], lane);
         return;
     }
     const double lp_before = lp_before_explore(e, c, slot);

@@ -37,6 +37,7 @@ Base.@kwdef mutable struct PteConfig
     rank::Int32 = 0
     world_size::Int32 = 1
     explorer2::Int32 = 0        # Compose(explorer, explorer2)
+    n_chains_variational::Int64 = 0   # StabilizedPT with variational == nothing
 end
 
 """Device-resident `replicas` (informal interface src/replicas/replicas.jl:11-40)."""

@@ -31,7 +31,7 @@ class PteConfig(C.Structure):
         ("am_exponent_n_refresh", C.c_double), ("am_step_size", C.c_double),
         ("am_p0", C.c_double), ("am_p1", C.c_double),
         ("am_preconditioner", C.c_int32),
-        ("rank", C.c_int32), ("world_size", C.c_int32), ("explorer2", C.c_int32),
+        ("rank", C.c_int32), ("world_size", C.c_int32), ("explorer2", C.c_int32), ("n_chains_variational", C.c_int64),
     ]
 
 

@@ -42,7 +42,7 @@ class Engine:
         if rc != 0:
             raise PteError(self.L.pte_last_error(None).decode())
         self.h = h
-        self.N = int(cfg.n_chains)
+        self.N = int(cfg.n_chains) + int(cfg.n_chains_variational)
         self.d = 0 if cfg.target == _lib.TARGET_TEST_SWAPPER else int(cfg.dim)
         a = np.zeros(3, dtype=np.int64)
         self.L.pte_shard_info(h, _ip(a[0:1]), _ip(a[1:2]), _ip(a[2:3]))
@@ -212,7 +212,8 @@ class Engine:
         n = np.zeros(1, dtype=np.int64)
         self._chk(self.L.pte_get_traces(self.h, None, _ip(n)))
         ext = bool(int(self.cfg.record_flags) & _lib.RECORD_TRACES_EXTENDED)     # [scan][local chain][d+1]
-        out = np.zeros((int(n[0]), self.K, self.d + 1)) if ext else np.zeros((int(n[0]), self.d + 1))
+        two = int(self.cfg.n_chains_variational) > 0                             # [scan][the two target chains][d+1]
+        out = np.zeros((int(n[0]), self.K if ext else 2, self.d + 1)) if (ext or two) else np.zeros((int(n[0]), self.d + 1))
         if n[0]:
             self._chk(self.L.pte_get_traces(self.h, _dp(out), _ip(n)))
         return out

@@ -239,6 +239,36 @@ class NonReversiblePT:
 
 
 @dataclass
+class StabilizedPT:
+    """src/tempering/StabilizedPT.jl:8-51 with inputs.variational == nothing (both legs keep the fixed reference).
+    Global chain order (1-based i): i <= n_var -> variational leg chain i; i > n_var -> fixed leg chain
+    n_fixed - (i - n_var) + 1 (create_replica_indexer, :86-104)."""
+    fixed_leg: NonReversiblePT
+    variational_leg: NonReversiblePT
+
+    @property
+    def n_fixed(self): return len(self.fixed_leg.schedule.grids)
+
+    @property
+    def n_var(self): return len(self.variational_leg.schedule.grids)
+
+    @property
+    def path(self): return self.fixed_leg.path
+
+    @property
+    def schedule(self):
+        """per-chain grid in global chain order (concatenate_log_potentials, :67-69)"""
+        return T.Schedule(np.concatenate([self.variational_leg.schedule.grids, self.fixed_leg.schedule.grids[::-1]]), check=False)
+
+    @property
+    def communication_barriers(self): return self.fixed_leg.communication_barriers      # global_barrier(::StabilizedPT), :115
+
+    def is_reference(self, chain): return chain == 1 or chain == self.n_fixed + self.n_var           # VariationalDEO.jl:20
+    def is_target(self, chain): return chain == self.n_var or chain == self.n_var + 1                # VariationalDEO.jl:21
+    def leg_of(self, chain): return "variational" if chain <= self.n_var else "fixed"                 # indexer.i2t
+
+
+@dataclass
 class Shared:
     """src/pt/Shared.jl:12-48"""
     iterators: Iterators
@@ -261,8 +291,15 @@ class PT:
         target = inputs.target
         explorer = inputs.explorer if inputs.explorer is not None else default_explorer(target)
         N = inputs.n_chains
-        sched = T.equally_spaced_schedule(N)
-        self.shared = Shared(Iterators(), NonReversiblePT(target, sched), explorer, [])
+        n_var = int(getattr(inputs, "n_chains_variational", 0) or 0)
+        if n_var > 0 and N > 0:                         # create_tempering, src/tempering/tempering.jl:64-70
+            if inputs.variational is not None:
+                raise NotImplementedError("variational references are not available on the device (use variational=None)")
+            tempering = StabilizedPT(NonReversiblePT(target, T.equally_spaced_schedule(N)),
+                                     NonReversiblePT(target, T.equally_spaced_schedule(n_var)))
+        else:
+            tempering = NonReversiblePT(target, T.equally_spaced_schedule(N))
+        self.shared = Shared(Iterators(), tempering, explorer, [])
         self.reduced_recorders = ReducedRecorders()
         names = {b() for b in inputs.record}
         flags = 0
@@ -278,7 +315,7 @@ class PT:
                 flags |= _lib.RECORD_TRACES_EXTENDED
         if "energy_ac1" in names:
             flags |= _lib.RECORD_ENERGY_AC1
-        kw = dict(device=inputs.device, n_chains=N, seed=inputs.seed, record_flags=flags,
+        kw = dict(device=inputs.device, n_chains=N, n_chains_variational=n_var, seed=inputs.seed, record_flags=flags,
                   max_scans_per_round=2 ** inputs.n_rounds)
         if isinstance(target, ScaledPrecisionNormalPath):
             kw.update(target=_lib.TARGET_MVN_SCALED_PRECISION, dim=target.dim,
@@ -394,6 +431,19 @@ def adapt(pt, reduced):
         return pt
     mean, n = reduced.swap_acceptance_pr
     rej = T.rejections(mean, n)
+    if isinstance(temp, StabilizedPT):
+        # adapt_tempering(::StabilizedPT) (StabilizedPT.jl:53-65): each leg from its own pairs; the fixed leg reads
+        # (N-1,N), (N-2,N-1), ... from its reference towards the target
+        nv, nf, Ntot = temp.n_var, temp.n_fixed, temp.n_var + temp.n_fixed
+        legs = []
+        for leg, r in ((temp.variational_leg, rej[:nv - 1]), (temp.fixed_leg, rej[Ntot - 2 - np.arange(nf - 1)] if nf > 1 else rej[:0])):
+            old = leg.schedule.grids
+            if len(old) == 1:
+                legs.append(leg); continue
+            legs.append(NonReversiblePT(leg.path, T.Schedule(T.optimal_schedule(r, old, len(old))), T.CommunicationBarriers(r, old)))
+        pt.shared.tempering = StabilizedPT(fixed_leg=legs[1], variational_leg=legs[0])
+        pt.replicas.set_schedule(pt.shared.tempering.schedule.grids)
+        return pt
     old = temp.schedule.grids
     new_sched = T.Schedule(T.optimal_schedule(rej, old, len(old)))
     barriers = T.CommunicationBarriers(rej, old)
@@ -435,6 +485,10 @@ def adapt_explorer(pt, reduced):
 
 def stepping_stone_pair(pt):
     up, un, dn, dnn = pt.reduced_recorders.log_sum_ratio
+    temp = pt.shared.tempering
+    if isinstance(temp, StabilizedPT):                 # only the variational leg's keys (stepping_stone.jl:53-65)
+        k = temp.n_var - 1
+        up, un, dn, dnn = up[:k], un[:k], dn[:k], dnn[:k]
     return T.stepping_stone_pair(up, un, dn, dnn)
 
 
@@ -497,6 +551,18 @@ def n_tempered_restarts(pt):
 
 def global_barrier(pt):
     return pt.shared.tempering.communication_barriers.globalbarrier
+
+
+def global_barrier_variational(pt):
+    """src/tempering/StabilizedPT.jl:117"""
+    return pt.shared.tempering.variational_leg.communication_barriers.globalbarrier
+
+
+def target_chains(pt):
+    """src/pt/process_sample.jl:41-44 (1-based chain indices)"""
+    temp = pt.shared.tempering
+    n = pt.replicas.N
+    return [i for i in range(1, n + 1) if (temp.is_target(i) if isinstance(temp, StabilizedPT) else i == n)]
 
 
 def last_round_max_time(pt):

@@ -12,8 +12,11 @@ import numpy as np
 class Schedule:
     """A partition of [0, 1] (src/schedules/Schedule.jl:5-30)."""
 
-    def __init__(self, grids):
+    def __init__(self, grids, check=True):
         grids = np.asarray(grids, dtype=np.float64).copy()
+        if not check:                                   # per-chain view of a two-leg ladder (0 -> 1 -> 0)
+            self.grids = grids
+            return
         if len(grids) == 1:
             assert grids[0] == 1.0
         else:

@@ -31,6 +31,7 @@ class Config(C.Structure):
         ("record_online", C.c_int32), ("n_threads", C.c_int32),
         ("rank", C.c_int32), ("world_size", C.c_int32),
         ("record_traces", C.c_int32), ("record_energy_ac1", C.c_int32), ("explorer2", C.c_int32),
+        ("n_chains_variational", C.c_int64),
     ]
 
 
@@ -187,7 +188,7 @@ class OraclePT:
                 raise AttributeError(k)
             setattr(self.cfg, k, v)
         self.h = self.L.po_create(C.byref(self.cfg))
-        self.N = int(self.cfg.n_chains)
+        self.N = int(self.cfg.n_chains) + max(int(self.cfg.n_chains_variational), 0)
         self.d = 0 if self.cfg.target == TARGET_TEST_SWAPPER else int(self.cfg.dim)
 
     def __del__(self):
@@ -286,7 +287,8 @@ class OraclePT:
         """[scan][d+1] of the target chain, or [scan][chain][d+1] with record_traces == 2 (extended_traces)."""
         n = int(self.L.po_get_traces(self.h, None))
         ext = int(self.cfg.record_traces) == 2
-        out = np.zeros((n, self.N, self.d + 1)) if ext else np.zeros((n, self.d + 1))
+        two = int(self.cfg.n_chains_variational) > 0          # [scan][the two target chains][d+1]
+        out = np.zeros((n, self.N if ext else 2, self.d + 1)) if (ext or two) else np.zeros((n, self.d + 1))
         if n:
             self.L.po_get_traces(self.h, _dp(out))
         return out
@@ -298,6 +300,11 @@ class OraclePT:
 
     def global_barrier(self):
         return float(self.L.po_get_global_barrier(self.h))
+
+    def global_barrier_variational(self):
+        self.L.po_get_global_barrier_variational.restype = C.c_double
+        self.L.po_get_global_barrier_variational.argtypes = [C.c_void_p]
+        return float(self.L.po_get_global_barrier_variational(self.h))
 
     def cumulative_barrier(self, beta):
         return float(self.L.po_cumulative_barrier(self.h, beta))

@@ -861,3 +861,62 @@ def test_extended_traces_parity_and_reference_shape(P, n_shards):
     assert mtx.shape == (4, d + 1, N)
     assert np.array_equal(P.get_sample(pt, 3, 2), red.traces[1, 2, :])
     assert np.array_equal(P.get_sample(pt, N), red.traces[:, N - 1, :])
+
+
+# ---------------------------------------------------------------------------------------------
+# SURVEY.md 8(f) rank 4 (without GaussianReference): StabilizedPT / VariationalDEO -- two legs sharing the target,
+# a reference at both ends (src/tempering/StabilizedPT.jl, src/swap/VariationalDEO.jl, src/swap/OddEven.jl:16-48).
+# ---------------------------------------------------------------------------------------------
+def test_two_references_double_the_restarts_kat(P):
+    """reference test/test_variational.jl:44-57 (test_two_references_2): TestSwapper(0.5), 5 chains, 15 rounds, seed 1;
+    with a second leg of 5 chains the tempered restarts double (|2 - ratio| <= 0.05)."""
+    kw = dict(target=P.TestSwapper(0.5), record=[P.round_trip], n_chains=5, n_rounds=15, seed=1, show_report=False)
+    pt = P.pigeons(**kw)
+    pt2 = P.pigeons(n_chains_variational=5, variational=None, **kw)
+    ratio = P.n_tempered_restarts(pt2) / P.n_tempered_restarts(pt)
+    assert abs(2.0 - ratio) <= 0.05
+    ref = O.OraclePT(target=O.TARGET_TEST_SWAPPER, p0=0.5, explorer=O.EXPLORER_NONE, seed=1, n_chains=5, n_chains_variational=5,
+                     record_index_process=0)
+    for _ in range(15):
+        ref.run_round()
+    assert pt2.reduced_recorders.round_trip == ref.round_trip()
+
+
+@pytest.mark.parametrize("explorer,nf,nv,d,rounds", [("slice", 6, 5, 4, 8), ("slice", 4, 4, 70, 5), ("automala", 5, 5, 6, 7), ("toy", 3, 7, 9, 6)])
+def test_two_leg_tempering_parity(P, explorer, nf, nv, d, rounds):
+    ex = {"slice": P.SliceSampler(), "automala": P.AutoMALA(), "toy": P.ToyExplorer()}[explorer]
+    oex = {"slice": O.EXPLORER_SLICE, "automala": O.EXPLORER_AUTOMALA, "toy": O.EXPLORER_TOY}[explorer]
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.online, P.energy_ac1, P.traces]
+    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=nf, n_chains_variational=nv, variational=None, n_rounds=rounds, explorer=ex,
+                       record=rec, show_report=False))
+    ref = O.OraclePT(n_chains=nf, n_chains_variational=nv, dim=d, explorer=oex, record_online=1, record_energy_ac1=1, record_traces=1,
+                     am_preconditioner=2)
+    N = nf + nv
+    temp = pt.shared.tempering
+    # reference test/test_two_legs.jl:29-40 (Issue #290): targets and references are disjoint and live on different legs
+    tg = P.target_chains(pt); rf = [i for i in range(1, N + 1) if temp.is_reference(i)]
+    assert not set(tg) & set(rf) and len({temp.leg_of(i) for i in tg}) == len(tg) == 2 and len({temp.leg_of(i) for i in rf}) == len(rf) == 2
+    for _ in range(rounds):
+        assert P.next_round(pt)
+        red = P.run_one_round(pt); P.adapt(pt, red); pt.reduced_recorders = red
+        ref.run_round()
+        assert np.array_equal(red.index_process, ref.index_process())
+        assert red.round_trip == ref.round_trip()
+        m, n = red.swap_acceptance_pr; mr, nr = ref.swap_pr()
+        assert np.array_equal(n, nr)
+        np.testing.assert_allclose(m, mr, rtol=RTOL, atol=1e-300)
+        np.testing.assert_allclose(pt.shared.tempering.schedule.grids, ref.schedule(), rtol=RTOL)
+        np.testing.assert_allclose(P.global_barrier(pt), ref.global_barrier(), rtol=RTOL)
+        np.testing.assert_allclose(P.global_barrier_variational(pt), ref.global_barrier_variational(), rtol=RTOL)
+        np.testing.assert_allclose(P.stepping_stone_pair(pt), ref.stepping_stone_pair(), rtol=RTOL)
+        om, ov, on = red.online; omr, ovr, onr = ref.online()
+        assert on == onr == 2 * 2 ** pt.shared.iterators.round
+        np.testing.assert_allclose(om, omr, rtol=1e-9, atol=1e-12); np.testing.assert_allclose(ov, ovr, rtol=1e-9)
+        assert red.traces.shape == (2 ** pt.shared.iterators.round, 2, d + 1)
+        np.testing.assert_allclose(red.traces, ref.traces(), rtol=1e-9, atol=1e-300)
+        cor, cn, mom = red.energy_ac1; corr, cnr, rawr = ref.energy_ac1()
+        assert np.array_equal(cn, cnr)
+        np.testing.assert_allclose(mom[:, :2], rawr[:, :2], rtol=1e-9)
+    x, chain, rng = pt.replicas.states(); xr, cr, rr = ref.states()
+    assert np.array_equal(chain, cr) and np.array_equal(rng, rr)
+    np.testing.assert_allclose(x, xr, rtol=1e-9, atol=1e-15)

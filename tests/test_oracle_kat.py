@@ -224,3 +224,31 @@ def test_mala_and_compose_target_moments_and_logz(kw):
     truth = 0.5 * d * math.log(1.0 / 10.0)         # log Z1/Z0 of exp(-prec/2 |x|^2), prec 1 -> 10
     p = pt.stepping_stone_pair()
     assert abs(p[0] - truth) < 0.2 and abs(p[1] - truth) < 0.2
+
+
+def test_two_references_double_the_restarts_kat():
+    """reference test/test_variational.jl:44-57: TestSwapper(0.5), n_chains = 5, 15 rounds, seed 1 -- a second leg of
+    5 chains (StabilizedPT with variational = nothing) doubles the tempered restarts: |2 - ratio| <= 0.05."""
+    def restarts(**kw):
+        pt = O.OraclePT(target=O.TARGET_TEST_SWAPPER, p0=0.5, explorer=O.EXPLORER_NONE, seed=1, record_index_process=0, **kw)
+        for _ in range(15):
+            pt.run_round()
+        return pt.round_trip()[0]
+    assert abs(2.0 - restarts(n_chains=5, n_chains_variational=5) / restarts(n_chains=5)) <= 0.05
+
+
+def test_two_leg_tempering_adapts_both_legs():
+    """reference test/test_two_legs.jl:19-27: both legs' global barriers agree with the one-leg barrier (rtol 0.1 there,
+    on a Turing target; here the analytic toy MVN, whose barrier is known: test_cumulative_barrier_kat)."""
+    one = O.OraclePT(n_chains=8, dim=4, explorer=O.EXPLORER_TOY)
+    two = O.OraclePT(n_chains=8, n_chains_variational=7, dim=4, explorer=O.EXPLORER_TOY)
+    for _ in range(11):
+        one.run_round(); two.run_round()
+    b1, b2f, b2v = one.global_barrier(), two.global_barrier(), two.global_barrier_variational()
+    assert abs(b2f - b1) / b1 < 0.1 and abs(b2v - b1) / b1 < 0.1
+    s = two.schedule()
+    assert s[0] == 0.0 and s[6] == 1.0 and s[7] == 1.0 and s[-1] == 0.0          # references at both ends, targets in the middle
+    assert np.all(np.diff(s[:7]) > 0) and np.all(np.diff(s[7:]) < 0)
+    truth = 0.5 * 4 * math.log(1.0 / 10.0)
+    p = two.stepping_stone_pair()                                                   # variational leg only
+    assert abs(p[0] - truth) < 0.2 and abs(p[1] - truth) < 0.2
