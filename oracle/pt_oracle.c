@@ -1251,6 +1251,16 @@ void po_get_states(const po_pt *pt, double *x, int64_t *chain, uint64_t *rng) {
         if (rng) { rng[2 * r] = pt->replicas[r].rng.seed; rng[2 * r + 1] = pt->replicas[r].rng.gamma; }
     }
 }
+/* restore replicas from a checkpoint (src/pt/checkpoint.jl:19-54): state, chain (0-based), rng in replica / slot order */
+void po_set_states(po_pt *pt, const double *x, const int64_t *chain, const uint64_t *rng) {
+    for (int64_t s = 0; s < pt->K; s++) {
+        po_replica *r = &pt->replicas[s];
+        if (x && pt->d > 0) memcpy(r->state, x + s * pt->d, sizeof(double) * (size_t)pt->d);
+        if (chain) { r->chain = chain[s]; pt->replica_of_chain[chain[s] - pt->c0] = s; }
+        if (rng) { r->rng.seed = rng[2 * s]; r->rng.gamma = rng[2 * s + 1]; }
+        if (x && pt->cfg.target == PO_TARGET_ISING) r->aux = ising_recompute(r->state, (int)llround(sqrt((double)pt->d)));
+    }
+}
 void po_get_schedule(const po_pt *pt, double *b) { memcpy(b, pt->betas, sizeof(double) * (size_t)pt->N); }
 void po_set_schedule(po_pt *pt, const double *b) {
     memcpy(pt->betas, b, sizeof(double) * (size_t)pt->N);

@@ -110,6 +110,7 @@ int64_t po_shard_index_process(const po_pt *pt, int64_t *replica, int64_t *chain
 
 /* State (replica order; local slot order for shards). rng: 2 words per replica (seed, gamma). */
 void po_get_states(const po_pt *pt, double *x, int64_t *chain, uint64_t *rng);
+void po_set_states(po_pt *pt, const double *x, const int64_t *chain, const uint64_t *rng);   /* NULLs are skipped */
 void po_get_schedule(const po_pt *pt, double *betas);
 void po_set_schedule(po_pt *pt, const double *betas);
 

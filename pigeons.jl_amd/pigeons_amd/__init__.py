@@ -15,7 +15,7 @@ from .pt import (Inputs, PT, pigeons, toy_mvn_target, ScaledPrecisionNormalPath,
                  energy_ac1s, sample_array, sample_names, get_sample, mean, var,
                  timing_extrema, allocation_extrema, explorer_acceptance_pr, explorer_n_steps,
                  stepping_stone, stepping_stone_pair, n_round_trips, n_tempered_restarts,
-                 global_barrier, global_barrier_variational, target_chains, StabilizedPT, last_round_max_time, analytic_lognormalization,
+                 global_barrier, global_barrier_variational, target_chains, StabilizedPT, last_round_max_time, report, analytic_lognormalization,
                  analytic_cumulativebarrier, run_one_round, adapt, next_round, n_scans_in_round)
 from .checkpoint import write_checkpoint, load_checkpoint, latest_checkpoint_folder, increment_n_rounds
 from .tempering import (Schedule, equally_spaced_schedule, optimal_schedule,
