@@ -154,6 +154,12 @@ int pte_get_traces(const pte_engine *h, double *out, int64_t *n_scans);
 
 /* Replica fields in replica order (src/replicas/Replica.jl:5-30): state [N*d], chain [N],
  * rng [2N] = (seed, gamma) of each SplittableRandom.  NULL pointers are skipped. */
+/* GaussianReference (src/variational/GaussianReference.jl:4-74) taking over the reference end of the interpolated
+ * path on the chains with uses[c] != 0 (update_reference! + update_path_variational, src/variational/variational.jl:28-41):
+ * log density -0.5 log(2 pi s^2) - (x - m)^2 / (2 s^2) per coordinate, gradient -(x - m) / s^2, sample_iid! = randn * s + m.
+ * Funnel target, single engine.  NULL mean / std deactivates. */
+int pte_set_variational_reference(pte_engine *h, const double *mean /*d*/, const double *std_dev /*d*/, int64_t dim,
+                                  const int32_t *uses /*N*/);
 int pte_get_state(const pte_engine *h, double *state, int64_t *chain, uint64_t *rng);
 int pte_set_state(pte_engine *h, const double *state, const int64_t *chain, const uint64_t *rng);
 

@@ -373,6 +373,7 @@ struct po_pt {
     double   global_barrier;
     double   global_barrier_var;  /* two legs: barrier of the variational leg (global_barrier is the fixed leg's) */
     double  *sched_var, *sched_fix;   /* two legs: the legs' own schedules, reference -> target */
+    double  *vmean, *vstd; int v_active;   /* GaussianReference of the variational leg, once activated */
     double  *cb_x, *cb_y, *cb_m, *cb_c, *cb_d;  /* cumulative barrier interpolant */
     int      cb_valid;
     double   stepping_stone[2];
@@ -395,7 +396,7 @@ void po_default_config(po_config *c) {
     c->am_base_n_refresh = 3; c->am_exponent_n_refresh = 0.35; c->am_step_size = 1.0;
     c->am_preconditioner = 2; c->am_p0 = 1.0 / 3.0; c->am_p1 = 1.0 / 3.0;
     c->record_round_trip = 1; c->record_index_process = 1; c->record_online = 0;
-    c->record_traces = 0; c->record_energy_ac1 = 0; c->explorer2 = PO_EXPLORER_NONE; c->n_chains_variational = 0;
+    c->record_traces = 0; c->record_energy_ac1 = 0; c->explorer2 = PO_EXPLORER_NONE; c->n_chains_variational = 0; c->variational_first_tuning_round = 0;
     c->n_threads = 1;
     c->rank = 0; c->world_size = 1;
 }
@@ -459,15 +460,30 @@ static double funnel_lp_grad(const double *z, int64_t d, double *g, double *term
  * MVN: ScaledPrecisionNormalPath is its own path (no interpolation).
  * FUNNEL: InterpolatingPath(ScaledPrecisionNormalLogPotential(p0, d), Funnel(d)) with the
  * LinearInterpolator (src/paths/InterpolatingPath.jl:25-27). */
+/* does chain's path start at the variational reference?  (the variational leg of StabilizedPT, or the only leg) */
+static inline int chain_uses_variational(const po_pt *pt, int64_t chain) {
+    return pt->v_active && (pt->cfg.n_chains_variational > 0 ? chain < pt->cfg.n_chains_variational : 1);
+}
+/* gaussian_logdensity, GaussianReference.jl:43-49 (sequential sum, as there) */
+static double gaussian_logdensity(const double *x, const double *mean, const double *sd, int64_t d) {
+    double log_pdf = 0.0;
+    for (int64_t i = 0; i < d; i++)
+        log_pdf += -0.5 * log(2.0 * M_PI * (sd[i] * sd[i])) - 1.0 / (2.0 * (sd[i] * sd[i])) * ((x[i] - mean[i]) * (x[i] - mean[i]));
+    return log_pdf;
+}
+/* the reference end of the interpolated (funnel) path at `chain` */
+static inline double path_ref_lp(const po_pt *pt, int64_t chain, const double *x) {
+    return chain_uses_variational(pt, chain) ? gaussian_logdensity(x, pt->vmean, pt->vstd, pt->d) : mvn_lp(pt->cfg.p0, x, pt->d);
+}
 static double lp_at_chain_buf(const po_pt *pt, int64_t chain, const double *x, double *scratch) {
     const double beta = pt->betas[chain];
     switch (pt->cfg.target) {
     case PO_TARGET_MVN: return mvn_lp(mvn_precision(pt, beta), x, pt->d);
     case PO_TARGET_FUNNEL: {
         /* InterpolatedLogPotential(x), src/paths/InterpolatedLogPotential.jl:9-16 */
-        if (beta == 0.0) return mvn_lp(pt->cfg.p0, x, pt->d);
+        if (beta == 0.0) return path_ref_lp(pt, chain, x);
         if (beta == 1.0) return funnel_lp_grad(x, pt->d, NULL, scratch);
-        double ref = mvn_lp(pt->cfg.p0, x, pt->d), tgt = funnel_lp_grad(x, pt->d, NULL, scratch);
+        double ref = path_ref_lp(pt, chain, x), tgt = funnel_lp_grad(x, pt->d, NULL, scratch);
         return (1.0 - beta) * ref + beta * tgt;
     }
     default: return NAN;
@@ -497,9 +513,12 @@ static double lp_grad_at_chain(const po_pt *pt, int64_t chain, const double *x, 
         return logdens;
     }
     double logdens = 0.0;
-    double l = mvn_lp(pt->cfg.p0, x, d);
+    double l = path_ref_lp(pt, chain, x);
     logdens += l * (1.0 - beta);
-    for (int64_t i = 0; i < d; i++) grad[i] = ((-pt->cfg.p0) * x[i]) * (1.0 - beta);
+    if (chain_uses_variational(pt, chain))      /* BufferedAD{GaussianReference}, GaussianReference.jl:66-73 */
+        for (int64_t i = 0; i < d; i++) grad[i] = (-1.0 / (pt->vstd[i] * pt->vstd[i]) * (x[i] - pt->vmean[i])) * (1.0 - beta);
+    else
+        for (int64_t i = 0; i < d; i++) grad[i] = ((-pt->cfg.p0) * x[i]) * (1.0 - beta);
     double *g2 = scratch, *terms = scratch + d;
     l = funnel_lp_grad(x, d, g2, terms);
     logdens += l * beta;
@@ -510,7 +529,7 @@ static double lp_grad_at_chain(const po_pt *pt, int64_t chain, const double *x, 
 static double lp_ad_at_chain(const po_pt *pt, int64_t chain, const double *x, double *scratch) {
     if (pt->cfg.target == PO_TARGET_MVN) return mvn_lp(mvn_precision(pt, pt->betas[chain]), x, pt->d);
     const double beta = pt->betas[chain];
-    double l1 = mvn_lp(pt->cfg.p0, x, pt->d), l2 = funnel_lp_grad(x, pt->d, NULL, scratch);
+    double l1 = path_ref_lp(pt, chain, x), l2 = funnel_lp_grad(x, pt->d, NULL, scratch);
     return (1.0 - beta) * l1 + beta * l2;
 }
 
@@ -608,6 +627,10 @@ static void fail(po_pt *pt, const char *msg) {
  * (src/targets/toy_mvn_target.jl:15-21, src/explorers/ToyExplorer.jl:7-12) */
 static void mvn_sample_iid(po_pt *pt, po_replica *r) {
     /* funnel path: sample_iid!(::InterpolatedLogPotential) -> the reference end point (src/targets/target.jl:93-98) */
+    if (pt->cfg.target == PO_TARGET_FUNNEL && chain_uses_variational(pt, r->chain)) {   /* sample_iid!(::GaussianReference), :33-40 */
+        for (int64_t i = 0; i < pt->d; i++) r->state[i] = po_randn(&r->rng) * pt->vstd[i] + pt->vmean[i];
+        return;
+    }
     double prec = pt->cfg.target == PO_TARGET_FUNNEL ? pt->cfg.p0 : mvn_precision(pt, pt->betas[r->chain]);
     double sd = sqrt(prec);
     for (int64_t i = 0; i < pt->d; i++) r->state[i] = po_randn(&r->rng) / sd;
@@ -928,7 +951,8 @@ static int explore_replica_inner(po_pt *pt, po_replica *r) {
             }
         }
     }
-    if (is_target_explore(pt, r->chain) && (pt->cfg.record_online || (uses_gradient_sampler(&pt->cfg) && pt->cfg.am_preconditioner != 0))) {
+    if (is_target_explore(pt, r->chain) && (pt->cfg.record_online || pt->cfg.variational_first_tuning_round > 0 ||
+                                            (uses_gradient_sampler(&pt->cfg) && pt->cfg.am_preconditioner != 0))) {
         for (int64_t i = 0; i < pt->d; i++) {       /* OnlineStateRecorder.jl:87-96 */
             mean_fit(&r->rec.on_mean[i], r->state[i]);
             var_fit(&r->rec.on_var[i], r->state[i]);
@@ -1082,7 +1106,7 @@ void po_destroy(po_pt *pt) {
     free(pt->shard_stat); free(pt->shard_ip_replica); free(pt->shard_ip_chain);
     rec_free(&pt->reduced);
     free(pt->replicas); free(pt->replica_of_chain); free(pt->betas); free(pt->target_std);
-    free(pt->reduced_ip); free(pt->cb_x); free(pt->traces); free(pt->reduced_traces); free(pt->sched_var); free(pt->sched_fix);
+    free(pt->reduced_ip); free(pt->cb_x); free(pt->traces); free(pt->reduced_traces); free(pt->sched_var); free(pt->sched_fix); free(pt->vmean); free(pt->vstd);
     free(pt);
 }
 
@@ -1222,6 +1246,14 @@ int po_end_round(po_pt *pt) {
         stepping_stone(pt);                                 /* report uses pre-adapt recorders */
         if (adapt_tempering(pt)) return 1;
     }
+    if (pt->cfg.variational_first_tuning_round > 0 && pt->round >= pt->cfg.variational_first_tuning_round &&
+        pt->cfg.target == PO_TARGET_FUNNEL) {
+        /* update_path_if_needed -> update_reference! (variational.jl:28-41, GaussianReference.jl:24-31): mean / std of
+         * the target chains' _transformed_online statistics; the path's reference becomes the GaussianReference */
+        if (!pt->vmean) { pt->vmean = (double *)calloc((size_t)d, sizeof(double)); pt->vstd = (double *)calloc((size_t)d, sizeof(double)); }
+        for (int64_t i = 0; i < d; i++) { pt->vmean[i] = pt->reduced.on_mean[i].mu; pt->vstd[i] = sqrt(var_value(&pt->reduced.on_var[i])); }
+        pt->v_active = 1;
+    }
     if (uses_gradient_sampler(&pt->cfg)) {
         /* adapt_explorer(::AutoMALA), src/explorers/AutoMALA.jl:70-79; (::MALA) MALA.jl:63-69 adapts the preconditioner only */
         if (pt->cfg.am_preconditioner != 0) {               /* adapt_preconditioner, Preconditioner.jl:54-55 */
@@ -1323,6 +1355,10 @@ int64_t po_get_online(const po_pt *pt, double *mean, double *var) {
 void po_get_stepping_stone(const po_pt *pt, double *pair) { pair[0] = pt->stepping_stone[0]; pair[1] = pt->stepping_stone[1]; }
 double po_get_global_barrier(const po_pt *pt) { return pt->global_barrier; }
 double po_get_global_barrier_variational(const po_pt *pt) { return pt->global_barrier_var; }
+int po_get_variational(const po_pt *pt, double *mean, double *std) {
+    if (pt->v_active) { memcpy(mean, pt->vmean, sizeof(double) * (size_t)pt->d); memcpy(std, pt->vstd, sizeof(double) * (size_t)pt->d); }
+    return pt->v_active;
+}
 double po_cumulative_barrier(const po_pt *pt, double beta) {
     if (!pt->cb_valid) return NAN;
     return po_fc_eval(pt->cb_x, pt->cb_y, pt->cb_m, pt->cb_c, pt->cb_d, pt->N, beta);

@@ -79,6 +79,10 @@ typedef struct po_config {
     /* StabilizedPT (src/tempering/StabilizedPT.jl) with the fixed reference on both legs
        (inputs.variational == nothing): n_chains fixed-leg chains + n_chains_variational variational-leg chains */
     int64_t  n_chains_variational;
+    /* GaussianReference (src/variational/GaussianReference.jl:4-74) on the funnel path: 0 = none, else its
+       first_tuning_round (default 6).  From that round on the variational leg (all chains when there is one leg)
+       runs InterpolatingPath(GaussianReference(mean, std of the target chains), target). */
+    int32_t  variational_first_tuning_round;
 } po_config;
 
 typedef struct po_pt po_pt;
@@ -130,7 +134,8 @@ void    po_get_energy_ac1(const po_pt *pt, double *cor /*N*/, int64_t *n /*N*/, 
 int64_t po_get_traces(const po_pt *pt, double *out /*[scan][d+1]*/);              /* returns the number of scans */
 void    po_get_stepping_stone(const po_pt *pt, double *pair);                    /* 2        */
 double  po_get_global_barrier(const po_pt *pt);
-double  po_get_global_barrier_variational(const po_pt *pt);   /* StabilizedPT.jl:117-119 */
+double  po_get_global_barrier_variational(const po_pt *pt);
+int     po_get_variational(const po_pt *pt, double *mean, double *std);   /* returns 1 when the reference is active */   /* StabilizedPT.jl:117-119 */
 double  po_cumulative_barrier(const po_pt *pt, double beta);
 double  po_get_step_size(const po_pt *pt);
 int64_t po_get_target_std(const po_pt *pt, double *out);                         /* d; returns 0 if `nothing` */

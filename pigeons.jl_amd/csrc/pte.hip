@@ -54,6 +54,8 @@ struct pte_engine {
     double *d_payload = nullptr;   // staging buffer for boundary export/import
     double *msg_send[2] = {nullptr, nullptr}, *msg_recv[2] = {nullptr, nullptr};   // device-resident exchange (caller-owned)
     int64_t *d_napplied = nullptr;  // [2] boundary swaps applied on the device path
+    double *d_vref = nullptr;       // [5 d] GaussianReference: mean, std, c0, i2, gf
+    int32_t *d_vuse = nullptr;      // [N]   chains whose path starts at it
     std::vector<double> betas;
     std::vector<void *> allocs;
     double *d_nhp = nullptr, *d_sd = nullptr, *d_nprec = nullptr, *d_beta = nullptr, *d_target_std = nullptr;
@@ -448,6 +450,9 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &h->d_beta, (size_t)N);
     rc |= dev_alloc(h, &h->d_target_std, (size_t)dd);
     rc |= dev_alloc(h, &e.suff2, (size_t)K);
+    rc |= dev_alloc(h, &e.suff3, (size_t)K);
+    rc |= dev_alloc(h, &h->d_vref, (size_t)(5 * (d > 0 ? d : 1)));
+    rc |= dev_alloc(h, &h->d_vuse, (size_t)N);
     rc |= dev_alloc(h, &e.am_fac_sum, (size_t)K); rc |= dev_alloc(h, &e.am_fac_n, (size_t)K);
     rc |= dev_alloc(h, &e.am_rev_sum, (size_t)K); rc |= dev_alloc(h, &e.am_rev_n, (size_t)K);
     rc |= dev_alloc(h, &e.swap_sum, (size_t)K);  rc |= dev_alloc(h, &e.swap_n, (size_t)K);
@@ -927,6 +932,52 @@ int pte_shard_sync(pte_engine *h, int64_t *boundary_swaps_out) {
     return rc;
 }
 
+namespace {
+int refresh_funnel_stats(pte_engine *h) {
+    const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
+    const double log3 = std::log(3.0);
+    const unsigned N = (unsigned)h->K;
+    switch (E) {
+    case 1: hipLaunchKernelGGL(k_refresh_funnel_stats<1>, dim3(N), dim3(64), 0, h->stream, h->dev, log3); break;
+    case 2: hipLaunchKernelGGL(k_refresh_funnel_stats<2>, dim3(N), dim3(64), 0, h->stream, h->dev, log3); break;
+    case 4: hipLaunchKernelGGL(k_refresh_funnel_stats<4>, dim3(N), dim3(64), 0, h->stream, h->dev, log3); break;
+    case 8: hipLaunchKernelGGL(k_refresh_funnel_stats<8>, dim3(N), dim3(64), 0, h->stream, h->dev, log3); break;
+    default: hipLaunchKernelGGL(k_refresh_funnel_stats<16>, dim3(N), dim3(64), 0, h->stream, h->dev, log3); break;
+    }
+    HIP_OK(h, hipGetLastError());
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+}  // namespace
+
+// update_reference! + update_path_variational (src/variational/variational.jl:28-41, GaussianReference.jl:24-31): from now on
+// the chains with uses[c] != 0 run InterpolatingPath(GaussianReference(mean, std), target).  mean = std = NULL deactivates.
+int pte_set_variational_reference(pte_engine *h, const double *mean, const double *std_dev, int64_t dim, const int32_t *uses) {
+    if (!h) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    EngineDev &e = h->dev;
+    if (!mean || !std_dev || !uses) { e.v_use = nullptr; return 0; }
+    if (h->cfg.target != PTE_TARGET_FUNNEL) return fail(h, "pte_set_variational_reference: only the interpolated (funnel) path has a replaceable reference");
+    if (h->world != 1) return fail(h, "pte_set_variational_reference: single engine only");
+    if (dim != h->d) return fail(h, "pte_set_variational_reference: expected %lld coordinates", (long long)h->d);
+    const int64_t d = h->d;
+    std::vector<double> buf((size_t)(5 * d));
+    for (int64_t i = 0; i < d; ++i) {
+        const double s = std_dev[i], s2 = s * s;
+        if (!(s > 0.0) || !std::isfinite(s) || !std::isfinite(mean[i])) return fail(h, "pte_set_variational_reference: bad mean / standard deviation at coordinate %lld", (long long)i);
+        buf[i] = mean[i]; buf[d + i] = s;
+        buf[2 * d + i] = -0.5 * std::log(2.0 * M_PI * s2);        // gaussian_logdensity, GaussianReference.jl:46
+        buf[3 * d + i] = 1.0 / (2.0 * s2);
+        buf[4 * d + i] = -1.0 / s2;                                // logdensity_and_gradient(::BufferedAD{GaussianReference}), :71
+    }
+    HIP_OK(h, hipMemcpyAsync(h->d_vref, buf.data(), sizeof(double) * buf.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipMemcpyAsync(h->d_vuse, uses, sizeof(int32_t) * h->N, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    e.v_mean = h->d_vref; e.v_std = h->d_vref + d; e.v_c0 = h->d_vref + 2 * d; e.v_i2 = h->d_vref + 3 * d; e.v_gf = h->d_vref + 4 * d;
+    e.v_use = h->d_vuse;
+    return refresh_funnel_stats(h);                                // suff3 of the current states
+}
+
 int pte_get_state(const pte_engine *hc, double *state, int64_t *chain, uint64_t *rng) {
     pte_engine *h = const_cast<pte_engine *>(hc);
     if (!h) return 1;
@@ -984,18 +1035,7 @@ int pte_set_state(pte_engine *h, const double *state, const int64_t *chain, cons
         hipError_t e1 = hipStreamSynchronize(h->stream);
         hipFree(tmp);
         HIP_OK(h, e1);
-        if (h->cfg.target == PTE_TARGET_FUNNEL) {        // + the target log density of the interpolated path
-            const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
-            const double log3 = std::log(3.0);
-            switch (E) {
-            case 1: hipLaunchKernelGGL(k_refresh_funnel_stats<1>, dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, log3); break;
-            case 2: hipLaunchKernelGGL(k_refresh_funnel_stats<2>, dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, log3); break;
-            case 4: hipLaunchKernelGGL(k_refresh_funnel_stats<4>, dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, log3); break;
-            case 8: hipLaunchKernelGGL(k_refresh_funnel_stats<8>, dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, log3); break;
-            default: hipLaunchKernelGGL(k_refresh_funnel_stats<16>, dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, log3); break;
-            }
-            HIP_OK(h, hipStreamSynchronize(h->stream));
-        }
+        if (h->cfg.target == PTE_TARGET_FUNNEL && refresh_funnel_stats(h)) return 1;   // + the target (and variational) log densities
     }
     return 0;
 }

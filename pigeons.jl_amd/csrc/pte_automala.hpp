@@ -58,6 +58,25 @@ struct AmTarget {
     int64_t d; int lane;
     double nhp, nprec;          // MVN: -0.5*prec, -prec of this chain
     double beta, omb, ref_nhp, ref_nprec, log3;   // funnel path
+    // GaussianReference end of the path (variational leg): per-coordinate constants in registers when `vr`
+    bool vr = false;
+    double vm[E], vc0[E], vi2[E], vgf[E];
+    __device__ __forceinline__ void load_variational(const EngineDev &e) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const bool ok = valid(j);
+            const int64_t i = 64 * (int64_t)j + lane;
+            vm[j] = ok ? e.v_mean[i] : 0.0; vc0[j] = ok ? e.v_c0[i] : 0.0; vi2[j] = ok ? e.v_i2[i] : 0.0; vgf[j] = ok ? e.v_gf[i] : 0.0;
+        }
+    }
+    // gaussian_logdensity (GaussianReference.jl:43-49) with the fixed tree in place of the sequential sum
+    __device__ __forceinline__ double variational_lp(const double (&x)[E]) const {
+        double t[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) { const double dx = x[j] - vm[j]; t[j] = valid(j) ? (vc0[j] - vi2[j] * (dx * dx)) : 0.0; }
+        return tree_sum_regs<E>(t);
+    }
+    __device__ __forceinline__ double ref_lp(const double (&x)[E], double S) const { return vr ? variational_lp(x) : ref_nhp * S; }
     __device__ __forceinline__ bool valid(int j) const { return 64 * (int64_t)j + lane < d; }
 
     // funnel: log density and (optionally) gradient; S = sum x^2 supplied by the caller
@@ -91,7 +110,7 @@ struct AmTarget {
     __device__ __forceinline__ double logdensity(const double (&x)[E]) const {
         const double S = sqr_norm_regs<E>(x);
         if (TGT == TGT_MVN) return nhp * S;
-        const double l1 = ref_nhp * S;
+        const double l1 = ref_lp(x, S);
         const double l2 = funnel(x, nullptr);
         return omb * l1 + beta * l2;
     }
@@ -104,13 +123,18 @@ struct AmTarget {
             return nhp * S;
         }
         double logdens = 0.0;
-        const double l1 = ref_nhp * S;
+        const double l1 = ref_lp(x, S);
         logdens += l1 * omb;
         double g2[E];
         const double l2 = funnel(x, &g2);
         logdens += l2 * beta;
+        if (vr) {                                    // BufferedAD{GaussianReference}: -1/s^2 (x - m)
 #pragma unroll
-        for (int j = 0; j < E; ++j) g[j] = (ref_nprec * x[j]) * omb + g2[j] * beta;
+            for (int j = 0; j < E; ++j) g[j] = (vgf[j] * (x[j] - vm[j])) * omb + g2[j] * beta;
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; ++j) g[j] = (ref_nprec * x[j]) * omb + g2[j] * beta;
+        }
         return logdens;
     }
 };
@@ -130,21 +154,42 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
     T.nhp = e.nhp[c]; T.nprec = e.nprec[c];
     T.beta = e.beta[c]; T.omb = 1.0 - T.beta;
     T.ref_nhp = -0.5 * ap.ref_prec; T.ref_nprec = -ap.ref_prec; T.log3 = ap.log3;
+    const bool v_on = (TGT == TGT_FUNNEL) && e.v_use != nullptr;      // a GaussianReference is active on this engine
+    if (v_on) { T.load_variational(e); T.vr = e.v_use[c] != 0; }
 
     double x[E];
     if (is_ref_chain(e, c)) {
         if (e.compose_phase == 2) return;
         const double lp0 = lp_before_explore(e, c, slot);
-        const double S0 = iid_refresh<NLU>(e, slot, e.sd[c], lane);   // sample_iid! at the reference (pigeons.jl:104-105)
-        __threadfence_block();
-        double l20 = 0.0;
-        if (TGT == TGT_FUNNEL) {
+        double S0;
+        if (v_on && T.vr) {
+            // sample_iid!(::GaussianReference) (GaussianReference.jl:33-40): x_i = randn * sd_i + mean_i, in draw order
+            SeqRng r0{e.rng[2 * slot], e.rng[2 * slot + 1]};
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const int nl = (int)max((int64_t)0, min((int64_t)64, d - 64 * (int64_t)j));
+                x[j] = 0.0;
+                if (nl > 0) {
+                    const double z = wave_randn_block(r0, lane, nl);
+                    x[j] = lane < nl ? z * e.v_std[64 * j + lane] + T.vm[j] : 0.0;
+                    if (lane < nl) xrow[64 * j + lane] = x[j];
+                }
+            }
+            S0 = sqr_norm_regs<E>(x);
+            if (lane == 0) { e.suff[slot] = S0; e.rng[2 * slot] = r0.seed; }
+        } else {
+            S0 = iid_refresh<NLU>(e, slot, e.sd[c], lane);            // sample_iid! at the reference (pigeons.jl:104-105)
+            __threadfence_block();
 #pragma unroll
             for (int j = 0; j < E; ++j) x[j] = T.valid(j) ? xrow[64 * j + lane] : 0.0;
+        }
+        double l20 = 0.0, l30 = 0.0;
+        if (TGT == TGT_FUNNEL) {
             l20 = T.funnel(x, nullptr);
             if (lane == 0) e.suff2[slot] = l20;
+            if (v_on) { l30 = T.variational_lp(x); if (lane == 0) e.suff3[slot] = l30; }
         }
-        record_after_explore_impl(e, cl, c, slot, lane, lp0, S0, l20);
+        record_after_explore_impl(e, cl, c, slot, lane, lp0, S0, l20, l30);
         return;
     }
     const double lp_before = lp_before_explore(e, c, slot);
@@ -315,18 +360,20 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
 #pragma unroll
     for (int j = 0; j < E; ++j) if (T.valid(j)) xrow[64 * j + lane] = x[j];
     const double S = sqr_norm_regs<E>(x);
-    double l2 = 0.0;
+    double l2 = 0.0, l3 = 0.0;
     if (TGT == TGT_FUNNEL) l2 = T.funnel(x, nullptr);
+    if (v_on) l3 = T.variational_lp(x);
     if (lane == 0) {
         e.suff[slot] = S;
         if (TGT == TGT_FUNNEL) e.suff2[slot] = l2;
+        if (v_on) e.suff3[slot] = l3;
         e.rng[2 * slot] = r.seed;
         e.expl_steps_sum[cl] += (double)steps_sum; e.expl_steps_n[cl] += steps_n;
         e.expl_acc_sum[cl] += acc_sum;             e.expl_acc_n[cl] += acc_n;
         e.am_fac_sum[cl] += fac_sum;               e.am_fac_n[cl] += fac_n;
         e.am_rev_sum[cl] += (double)rev_sum;       e.am_rev_n[cl] += rev_n;
     }
-    record_after_explore(e, cl, c, slot, lane, lp_before, S, l2);
+    record_after_explore(e, cl, c, slot, lane, lp_before, S, l2, l3);
 }
 
 // Swap statistics of every slot recomputed from the stored states (pte_set_state on an interpolated path):
@@ -345,6 +392,11 @@ __global__ __launch_bounds__(64) void k_refresh_funnel_stats(EngineDev e, double
     const double S = sqr_norm_regs<E>(x);
     const double l2 = T.funnel(x, nullptr);
     if (lane == 0) { e.suff[slot] = S; e.suff2[slot] = l2; }
+    if (e.v_use != nullptr) {
+        T.load_variational(e);
+        const double l3 = T.variational_lp(x);
+        if (lane == 0) e.suff3[slot] = l3;
+    }
 }
 
 }  // namespace pte

@@ -52,6 +52,10 @@ struct EngineDev {
     // StabilizedPT (two legs, src/tempering/StabilizedPT.jl): second reference chain (-1: one leg), the two target chains
     // explore! asks for (VariationalDEO.jl:20-21) and the two swap! / round trips ask for (OddEven.jl:47-48)
     int64_t ref2, tgt_a, tgt_b, rt_tgt_a, rt_tgt_b;
+    // GaussianReference of the variational leg (src/variational/GaussianReference.jl), null until activated:
+    // v_use[c] != 0 <=> chain c's path starts at it; per coordinate mean, std, c0 = -0.5 log(2 pi s^2),
+    // i2 = 1/(2 s^2), gf = -1/s^2 (computed on the host: same libm as the oracle); suff3[slot] = its log density
+    const int32_t *v_use; const double *v_mean, *v_std, *v_c0, *v_i2, *v_gf; double *suff3;
     int compose_phase; double *lp_stash;                   // Compose(first, second): 0 single explorer, 1 first, 2 second kernel of the scan; [K] lp before the first
     int32_t *index_process;                                // [scan][slot]
     int32_t *error;                                        // [4] code, chain, coordinate, spare
@@ -146,9 +150,10 @@ __device__ __forceinline__ void record_online(const EngineDev &e, int slot, int 
 
 // log_potentials[chain](state) from the swap statistics: S = sum x^2 (Ising: sum_pair_products), l2 = the
 // target log density of an interpolated path.  Same expressions as swap_log_ratio below.
-__device__ __forceinline__ double chain_lp(const EngineDev &e, int64_t c, double S, double l2) {
+__device__ __forceinline__ bool chain_uses_variational(const EngineDev &e, int64_t c) { return e.v_use != nullptr && e.v_use[c] != 0; }
+__device__ __forceinline__ double chain_lp(const EngineDev &e, int64_t c, double S, double l2, double l3 = 0.0) {
     if (e.target == 2 || e.target == 3) {
-        const double ref = (e.target == 2) ? e.ref_nhp * S : 0.0 * S;
+        const double ref = (e.target == 2) ? (chain_uses_variational(e, c) ? l3 : e.ref_nhp * S) : 0.0 * S;
         const double tgt = (e.target == 2) ? l2 : e.ising_beta * S;
         const double b = e.beta[c];
         return b == 0.0 ? ref : (b == 1.0 ? tgt : (1.0 - b) * ref + b * tgt);
@@ -163,13 +168,13 @@ __device__ __forceinline__ double chain_lp(const EngineDev &e, int64_t c, double
 __device__ __forceinline__ double lp_before_explore(const EngineDev &e, int64_t c, int slot) {
     if (!(e.record_flags & 16u)) return 0.0;
     if (e.compose_phase == 2) return e.lp_stash[c - e.c0];
-    return chain_lp(e, c, e.suff[slot], e.suff2[slot]);
+    return chain_lp(e, c, e.suff[slot], e.suff2[slot], e.v_use ? e.suff3[slot] : 0.0);
 }
 __device__ __forceinline__ void record_after_explore_impl(const EngineDev &e, int64_t cl, int64_t c, int slot, int lane,
-                                                          double lp_before, double S, double l2) {
+                                                          double lp_before, double S, double l2, double l3 = 0.0) {
     const unsigned f = e.record_flags;
     if (!(f & (4u | 8u | 16u))) return;
-    const double lp = chain_lp(e, c, S, l2);
+    const double lp = chain_lp(e, c, S, l2, l3);
     if ((f & 16u) && lane == 0) {                         // energy_ac1: (chain, SVector(before, after)) -> CovMatrix(2)
         double *o = e.eac + 5 * cl;
         const int64_t n = e.eac_n[cl] + 1;
@@ -194,9 +199,9 @@ __device__ __forceinline__ void record_after_explore_impl(const EngineDev &e, in
     }
 }
 __device__ __forceinline__ void record_after_explore(const EngineDev &e, int64_t cl, int64_t c, int slot, int lane,
-                                                     double lp_before, double S, double l2) {
+                                                     double lp_before, double S, double l2, double l3 = 0.0) {
     if (e.compose_phase == 1) { if ((e.record_flags & 16u) && lane == 0) e.lp_stash[cl] = lp_before; return; }
-    record_after_explore_impl(e, cl, c, slot, lane, lp_before, S, l2);
+    record_after_explore_impl(e, cl, c, slot, lane, lp_before, S, l2, l3);
 }
 
 // the same at a chain of the MVN path, with explore!'s recorders around it
@@ -438,10 +443,12 @@ __global__ __launch_bounds__(64) void k_explore_slice(EngineDev e, SliceParams s
 __device__ __forceinline__ double swap_log_ratio(const EngineDev &e, int slot, int64_t c, int64_t pc) {
     const double S = e.suff[slot];
     if (e.target == 2) {
-        const double ref = e.ref_nhp * S, tgt = e.suff2[slot];
+        const double tgt = e.suff2[slot];
+        const double refn = chain_uses_variational(e, pc) ? e.suff3[slot] : e.ref_nhp * S;   // each chain's own reference end
+        const double refd = chain_uses_variational(e, c) ? e.suff3[slot] : e.ref_nhp * S;
         const double bn = e.beta[pc], bd = e.beta[c];
-        const double num = bn == 0.0 ? ref : (bn == 1.0 ? tgt : (1.0 - bn) * ref + bn * tgt);
-        const double den = bd == 0.0 ? ref : (bd == 1.0 ? tgt : (1.0 - bd) * ref + bd * tgt);
+        const double num = bn == 0.0 ? refn : (bn == 1.0 ? tgt : (1.0 - bn) * refn + bn * tgt);
+        const double den = bd == 0.0 ? refd : (bd == 1.0 ? tgt : (1.0 - bd) * refd + bd * tgt);
         return num - den;
     }
     if (e.target == 3) {     // Ising: S holds sum_pair_products; ref = 0.0 * spp, target = beta_target * spp (examples/ising.jl:74)

@@ -8,7 +8,7 @@ pigeons.jl_amd/julia/PigeonsMI355X.jl.
 from ._lib import PteError, LIB_PATH
 from .engine import Engine
 from .pt import (Inputs, PT, pigeons, toy_mvn_target, ScaledPrecisionNormalPath, TestSwapper,
-                 SliceSampler, ToyExplorer, AutoMALA, MALA, Compose, Funnel, IsingLogPotential, IsingMetropolis, ScaledPrecisionNormalLogPotential,
+                 SliceSampler, ToyExplorer, AutoMALA, MALA, Compose, GaussianReference, InterpolatingPath, Funnel, IsingLogPotential, IsingMetropolis, ScaledPrecisionNormalLogPotential,
                  IdentityPreconditioner, DiagonalPreconditioner, MixDiagonalPreconditioner,
                  record_default, record_online,
                  log_sum_ratio, swap_acceptance_pr, round_trip, index_process, online, traces, energy_ac1,

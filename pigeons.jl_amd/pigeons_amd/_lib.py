@@ -51,7 +51,7 @@ EXPORTS = [
     "pte_boundary_export", "pte_boundary_import", "pte_get_index_process_shard", "pte_get_replica_ids",
     "pte_get_stream", "pte_shard_message_bytes", "pte_shard_set_buffers", "pte_shard_scan_begin",
     "pte_shard_scan_finish", "pte_shard_sync",
-    "pte_get_online_log_density", "pte_get_energy_ac1", "pte_get_traces",
+    "pte_get_online_log_density", "pte_get_energy_ac1", "pte_get_traces", "pte_set_variational_reference",
 ]
 
 _lib = None
@@ -114,6 +114,7 @@ def load():
     L.pte_get_online_log_density.argtypes = [vp, dp, dp]
     L.pte_get_energy_ac1.argtypes = [vp, dp, ip, dp]
     L.pte_get_traces.argtypes = [vp, dp, ip]
+    L.pte_set_variational_reference.argtypes = [vp, dp, dp, C.c_int64, C.POINTER(C.c_int32)]
     L.pte_get_stream.argtypes = [vp]
     L.pte_get_stream.restype = C.c_void_p
     L.pte_shard_message_bytes.argtypes = [vp]

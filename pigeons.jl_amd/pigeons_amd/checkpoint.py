@@ -56,7 +56,8 @@ def latest_checkpoint_folder(exec_folder):
         folder = checkpoint_folder(exec_folder, r)
         if not os.path.isdir(folder):
             continue
-        done = all(os.path.exists(os.path.join(folder, ".signal", "finished_replica=%d" % (i + 1))) for i in range(inputs.n_chains))
+        n_total = inputs.n_chains + int(getattr(inputs, "n_chains_variational", 0) or 0)          # Inputs.jl:128
+        done = all(os.path.exists(os.path.join(folder, ".signal", "finished_replica=%d" % (i + 1))) for i in range(n_total))
         if done and os.path.exists(os.path.join(folder, "shared.pkl")):
             best = r
     return best
@@ -81,7 +82,7 @@ def load_checkpoint(source_exec_folder, round=None, n_rounds_increment=0, **pt_k
     inputs.n_rounds += n_rounds_increment
     inputs.explorer = shared.explorer                  # carries the adapted step size / std deviations
     pt = PT(inputs, **pt_kwargs)
-    N = inputs.n_chains
+    N = pt.replicas.N
     reps = [np.load(os.path.join(folder, "replica=%d.npz" % (i + 1))) for i in range(N)]
     x = np.stack([np.atleast_1d(r["state"]) for r in reps])
     chain = np.array([int(r["chain"]) - 1 for r in reps], dtype=np.int64)
@@ -101,6 +102,14 @@ def load_checkpoint(source_exec_folder, round=None, n_rounds_increment=0, **pt_k
     gs = grad_sampler(shared.explorer)
     if gs is not None:
         eng.set_explorer_adaptation(gs.step_size, gs.estimated_target_std_deviations)
+    from .pt import InterpolatingPath, StabilizedPT, GaussianReference
+    temp = shared.tempering
+    leg = temp.variational_leg if isinstance(temp, StabilizedPT) else temp
+    if isinstance(leg.path, InterpolatingPath) and isinstance(leg.path.ref, GaussianReference):     # an activated variational reference
+        ref = leg.path.ref
+        uses = np.array([1 if (not isinstance(temp, StabilizedPT) or c < temp.n_var) else 0 for c in range(eng.N)], dtype=np.int32)
+        eng.set_variational_reference(ref.mean, ref.standard_deviation, uses)
+        pt.inputs.variational = ref
     pt.exec_folder = None
     return pt
 

@@ -80,6 +80,11 @@ class Engine:
             s = np.ascontiguousarray(target_std, dtype=np.float64)
             self._chk(self.L.pte_set_explorer_adaptation(self.h, step_size, _dp(s), len(s)))
 
+    def set_variational_reference(self, mean, std, uses):
+        m = np.ascontiguousarray(mean, dtype=np.float64); sd = np.ascontiguousarray(std, dtype=np.float64)
+        u = np.ascontiguousarray(uses, dtype=np.int32)
+        self._chk(self.L.pte_set_variational_reference(self.h, _dp(m), _dp(sd), len(m), u.ctypes.data_as(C.POINTER(C.c_int32))))
+
     # --- hot path
     def explore(self, scan):
         self._chk(self.L.pte_explore(self.h, scan))

@@ -66,6 +66,23 @@ class Funnel:
 
 
 @dataclass
+class GaussianReference:
+    """src/variational/GaussianReference.jl:4-17: mean-field Gaussian variational reference, refitted every round from
+    the target chains' online mean / standard deviation once `first_tuning_round` is reached."""
+    mean: Any = None
+    standard_deviation: Any = None
+    first_tuning_round: int = 6
+
+
+@dataclass
+class InterpolatingPath:
+    """src/paths/InterpolatingPath.jl: (1 - beta) ref + beta target; what update_path_variational builds
+    (src/variational/variational.jl:36-41)."""
+    ref: Any = None
+    target: Any = None
+
+
+@dataclass
 class IsingLogPotential:
     """2-D Ising model, p(state) ∝ exp(beta * sum of neighbour products) (reference examples/ising.jl:6-9,74).
     The reference distribution is IsingLogPotential(0.0, base_length) (ising.jl:77); states are
@@ -293,8 +310,6 @@ class PT:
         N = inputs.n_chains
         n_var = int(getattr(inputs, "n_chains_variational", 0) or 0)
         if n_var > 0 and N > 0:                         # create_tempering, src/tempering/tempering.jl:64-70
-            if inputs.variational is not None:
-                raise NotImplementedError("variational references are not available on the device (use variational=None)")
             tempering = StabilizedPT(NonReversiblePT(target, T.equally_spaced_schedule(N)),
                                      NonReversiblePT(target, T.equally_spaced_schedule(n_var)))
         else:
@@ -309,6 +324,10 @@ class PT:
             flags |= _lib.RECORD_INDEX_PROCESS
         if "online" in names:
             flags |= _lib.RECORD_ONLINE
+        if inputs.variational is not None:
+            if not isinstance(inputs.variational, GaussianReference) or not isinstance(target, Funnel):
+                raise NotImplementedError("the device engine has GaussianReference on the interpolated (funnel) path only")
+            flags |= _lib.RECORD_ONLINE                 # variational_recorder_builders: _transformed_online
         if "traces" in names:
             flags |= _lib.RECORD_TRACES
             if getattr(inputs, "extended_traces", False):
@@ -427,6 +446,7 @@ def adapt(pt, reduced):
     temp = pt.shared.tempering
     pt.reduced_recorders = reduced
     adapt_explorer(pt, reduced)
+    update_variational(pt, reduced)
     if isinstance(pt.inputs.target, TestSwapper) or len(temp.schedule.grids) == 1:
         return pt
     mean, n = reduced.swap_acceptance_pr
@@ -450,6 +470,27 @@ def adapt(pt, reduced):
     pt.shared.tempering = NonReversiblePT(temp.path, new_sched, barriers)
     (pt.shards if pt.shards is not None else pt.replicas).set_schedule(new_sched.grids)   # discretize on the device
     return pt
+
+
+def update_variational(pt, reduced):
+    """update_path_if_needed (src/variational/variational.jl:28-41): from first_tuning_round on, refit the
+    GaussianReference to the target chains' online statistics and put it at the reference end of the variational leg
+    (of the only leg when there is one)."""
+    var = pt.inputs.variational
+    if not isinstance(var, GaussianReference) or pt.shared.iterators.round < var.first_tuning_round:
+        return
+    mean, variance, _n = reduced.online
+    ref = GaussianReference(np.array(mean, dtype=np.float64), np.sqrt(np.asarray(variance, dtype=np.float64)), var.first_tuning_round)
+    pt.inputs.variational = ref
+    temp = pt.shared.tempering
+    N = pt.replicas.N
+    if isinstance(temp, StabilizedPT):
+        temp.variational_leg.path = InterpolatingPath(ref, pt.inputs.target)
+        uses = np.array([1 if c < temp.n_var else 0 for c in range(N)], dtype=np.int32)
+    else:
+        temp.path = InterpolatingPath(ref, pt.inputs.target)
+        uses = np.ones(N, dtype=np.int32)
+    pt.replicas.set_variational_reference(ref.mean, ref.standard_deviation, uses)
 
 
 def adapt_explorer(pt, reduced):

@@ -31,7 +31,7 @@ class Config(C.Structure):
         ("record_online", C.c_int32), ("n_threads", C.c_int32),
         ("rank", C.c_int32), ("world_size", C.c_int32),
         ("record_traces", C.c_int32), ("record_energy_ac1", C.c_int32), ("explorer2", C.c_int32),
-        ("n_chains_variational", C.c_int64),
+        ("n_chains_variational", C.c_int64), ("variational_first_tuning_round", C.c_int32),
     ]
 
 
@@ -300,6 +300,13 @@ class OraclePT:
 
     def global_barrier(self):
         return float(self.L.po_get_global_barrier(self.h))
+
+    def variational(self):
+        """(mean, std) of the active GaussianReference, or None"""
+        m = np.zeros(max(self.d, 1)); sd = np.zeros(max(self.d, 1))
+        self.L.po_get_variational.restype = C.c_int
+        self.L.po_get_variational.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        return (m[:self.d], sd[:self.d]) if self.L.po_get_variational(self.h, _dp(m), _dp(sd)) else None
 
     def global_barrier_variational(self):
         self.L.po_get_global_barrier_variational.restype = C.c_double

@@ -920,3 +920,63 @@ def test_two_leg_tempering_parity(P, explorer, nf, nv, d, rounds):
     x, chain, rng = pt.replicas.states(); xr, cr, rr = ref.states()
     assert np.array_equal(chain, cr) and np.array_equal(rng, rr)
     np.testing.assert_allclose(x, xr, rtol=1e-9, atol=1e-15)
+
+
+# ---------------------------------------------------------------------------------------------
+# GaussianReference (src/variational/GaussianReference.jl) on the interpolated funnel path: refitted every round
+# from the target chains' online statistics; the variational leg (or the only leg) starts at it.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nf,nv,d,explorer", [(5, 5, 4, "automala"), (6, 0, 6, "automala"), (4, 5, 70, "mala"), (0, 6, 5, "automala")])
+def test_gaussian_reference_parity_funnel(P, nf, nv, d, explorer):
+    rounds, first = 7, 3
+    ex = P.AutoMALA() if explorer == "automala" else P.MALA(step_size=0.2)
+    okw = dict(explorer=O.EXPLORER_AUTOMALA) if explorer == "automala" else dict(explorer=O.EXPLORER_MALA, am_step_size=0.2)
+    if nf == 0:                                          # variational leg only: one leg (create_tempering, tempering.jl:66-68)
+        n_chains, n_var = nv, 0
+    else:
+        n_chains, n_var = nf, nv
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.energy_ac1]
+    pt = P.PT(P.Inputs(target=P.Funnel(d), reference=P.ScaledPrecisionNormalLogPotential(1.0 / 9.0, d), n_chains=n_chains,
+                       n_chains_variational=n_var, variational=P.GaussianReference(first_tuning_round=first), n_rounds=rounds,
+                       explorer=ex, record=rec, show_report=False))
+    ref = O.OraclePT(n_chains=n_chains, n_chains_variational=n_var, dim=d, target=O.TARGET_FUNNEL, p0=1.0 / 9.0, am_preconditioner=2,
+                     variational_first_tuning_round=first, record_energy_ac1=1, **okw)
+    for r in range(1, rounds + 1):
+        assert P.next_round(pt)
+        red = P.run_one_round(pt); P.adapt(pt, red); pt.reduced_recorders = red
+        ref.run_round()
+        assert np.array_equal(red.index_process, ref.index_process()), r
+        assert red.round_trip == ref.round_trip()
+        m, n = red.swap_acceptance_pr; mr, nr = ref.swap_pr()
+        assert np.array_equal(n, nr)
+        np.testing.assert_allclose(m, mr, rtol=1e-6, atol=1e-300)
+        np.testing.assert_allclose(pt.shared.tempering.schedule.grids, ref.schedule(), rtol=1e-6)
+        np.testing.assert_allclose(P.stepping_stone_pair(pt), ref.stepping_stone_pair(), rtol=1e-6, atol=1e-9)
+        v = ref.variational()
+        temp = pt.shared.tempering
+        leg = temp.variational_leg if n_var > 0 else temp
+        if r >= first:
+            assert isinstance(leg.path.ref, P.GaussianReference)            # test/test_variational.jl:41
+            np.testing.assert_allclose(leg.path.ref.mean, v[0], rtol=1e-6, atol=1e-9)
+            np.testing.assert_allclose(leg.path.ref.standard_deviation, v[1], rtol=1e-6)
+        else:
+            assert v is None and not isinstance(leg.path, P.InterpolatingPath)
+        cor, cn, mom = red.energy_ac1; corr, cnr, rawr = ref.energy_ac1()
+        assert np.array_equal(cn, cnr)
+        np.testing.assert_allclose(mom[:, :2], rawr[:, :2], rtol=1e-6, atol=1e-9)
+    x, chain, rng = pt.replicas.states(); xr, cr, rr = ref.states()
+    assert np.array_equal(chain, cr) and np.array_equal(rng, rr)
+    np.testing.assert_allclose(x, xr, rtol=1e-6, atol=1e-9)
+
+
+def test_gaussian_reference_survives_a_checkpoint(P, tmp_path):
+    mk = lambda n: P.Inputs(target=P.Funnel(5), reference=P.ScaledPrecisionNormalLogPotential(1.0 / 9.0, 5), n_chains=5, n_chains_variational=4,
+                            variational=P.GaussianReference(first_tuning_round=2), n_rounds=n, explorer=P.AutoMALA(),
+                            record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False, checkpoint=True)
+    straight = P.pigeons(P.PT(mk(6)))
+    folder = str(tmp_path / "exec")
+    P.pigeons(P.PT(mk(3)), exec_folder=folder)
+    resumed = P.pigeons(P.load_checkpoint(folder, n_rounds_increment=3))
+    assert np.array_equal(straight.reduced_recorders.index_process, resumed.reduced_recorders.index_process)
+    for a, b in zip(straight.replicas.states(), resumed.replicas.states()):
+        assert np.array_equal(a, b)

@@ -31,6 +31,9 @@ class OracleEngine(O.OracleShard):
     def set_explorer_adaptation(self, step_size, target_std=None):
         O.OraclePT.set_explorer_adaptation(self, step_size, target_std)
 
+    def set_variational_reference(self, mean, std, uses):
+        raise NotImplementedError("the oracle refits its GaussianReference itself (po_end_round)")
+
 
 @pytest.fixture(scope="module")
 def P():

@@ -252,3 +252,20 @@ def test_two_leg_tempering_adapts_both_legs():
     truth = 0.5 * 4 * math.log(1.0 / 10.0)
     p = two.stepping_stone_pair()                                                   # variational leg only
     assert abs(p[0] - truth) < 0.2 and abs(p[1] - truth) < 0.2
+
+
+def test_gaussian_reference_on_the_funnel():
+    """GaussianReference (src/variational/GaussianReference.jl): activates at first_tuning_round, is refitted from the
+    target chains' online mean / std, and -- being a normalised density like the funnel -- brings log(Z1/Z0) to 0
+    (the stepping-stone check the reference applies in test/test_stepping_stone.jl:4-13 to its Turing target)."""
+    pt = O.OraclePT(n_chains=8, dim=2, explorer=O.EXPLORER_AUTOMALA, target=O.TARGET_FUNNEL, p0=1.0 / 9.0, am_preconditioner=2,
+                    variational_first_tuning_round=4, record_online=1)
+    for r in range(1, 12):
+        pt.run_round()
+        v = pt.variational()
+        assert (v is None) == (r < 4)
+    m, var, n = pt.online()
+    np.testing.assert_allclose(v[0], m, rtol=1e-13); np.testing.assert_allclose(v[1], np.sqrt(var), rtol=1e-13)
+    assert abs(v[0][0]) < 0.6 and abs(v[1][0] - 3.0) < 0.6                  # z[1] ~ Normal(0, 3)
+    p = pt.stepping_stone_pair()
+    assert abs(0.5 * (p[0] + p[1])) < 0.25
