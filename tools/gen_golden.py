@@ -69,6 +69,9 @@ RUNS = {
     "mala_mvn": dict(n_chains=5, dim=10, seed=1, explorer=O.EXPLORER_MALA, am_step_size=0.25, am_preconditioner=2, rounds=6),
     "compose_slice_automala": dict(n_chains=4, dim=1, seed=1, explorer=O.EXPLORER_SLICE, explorer2=O.EXPLORER_AUTOMALA,
                                    am_preconditioner=2, rounds=7),
+    "two_leg_slice": dict(n_chains=5, n_chains_variational=4, dim=6, seed=1, explorer=O.EXPLORER_SLICE, rounds=6),
+    "variational_funnel": dict(n_chains=5, n_chains_variational=4, dim=5, seed=2, explorer=O.EXPLORER_AUTOMALA, target=O.TARGET_FUNNEL,
+                               p0=1.0 / 9.0, am_preconditioner=2, variational_first_tuning_round=3, rounds=6),
     "ising": dict(n_chains=6, dim=64, seed=2, explorer=O.EXPLORER_ISING, target=O.TARGET_ISING, p0=0.6, slice_n_passes=3, rounds=6),
 }
 
