@@ -118,4 +118,24 @@ end
 set_schedule!(r::DeviceReplicas, schedule::Pigeons.Schedule) =
     check(r, ccall((:pte_set_schedule, libpte), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), r.handle, schedule.grids, length(schedule.grids)))
 
+# record = [...] symbols -> pte_config.record_flags (include/pte.h PTE_RECORD_*)
+record_flags(names) = UInt32(sum((
+    (:round_trip in names) * 1, (:index_process in names) * 2, (:online in names || :_transformed_online in names) * 4,
+    (:traces in names) * 8, (:energy_ac1 in names) * 16)))
+
+# Compose(first, second)  (src/explorers/Compose.jl:5-19) -> pte_config.explorer / explorer2
+explorer_code(::SliceSampler) = Int32(2)
+explorer_code(::Pigeons.AutoMALA) = Int32(3)
+explorer_code(::Pigeons.MALA) = Int32(5)
+explorer_codes(e::Pigeons.Compose) = (explorer_code(e.first), explorer_code(e.second))
+explorer_codes(e) = (explorer_code(e), Int32(0))
+
+# update_reference!(reduced_recorders, ::GaussianReference, state)  (src/variational/GaussianReference.jl:24-31)
+# followed by update_path_variational (src/variational/variational.jl:36-41): the variational leg's chains start at it
+function update_reference_on_device!(r::DeviceReplicas, variational::Pigeons.GaussianReference, uses::Vector{Int32})
+    m = variational.mean[:singleton_variable]; s = variational.standard_deviation[:singleton_variable]
+    check(r, ccall((:pte_set_variational_reference, libpte), Cint,
+                   (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}), r.handle, m, s, length(m), uses))
+end
+
 end # module
