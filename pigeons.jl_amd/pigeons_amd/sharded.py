@@ -188,11 +188,16 @@ class DistShard:
         self.stream_ordered = (self.on_device and dist.get_backend(group) == "nccl" and hasattr(engine, "shard_scan_begin")
                                and os.environ.get("PTE_DIST_HOST_DRIVEN", "0") != "1")
         if self.stream_ordered:
-            mw = engine.message_words()
-            self.msg = [torch.zeros(mw, dtype=torch.float64, device=self.device) for _ in range(4)]   # send_lo, recv_lo, send_hi, recv_hi
-            engine.shard_set_buffers(*[t.data_ptr() for t in self.msg])
-            self.stream = torch.cuda.ExternalStream(engine.stream_ptr(), device=self.device)
-            self.debug_sync = os.environ.get("PTE_DIST_SYNC", "0") == "1"
+            try:
+                mw = engine.message_words()
+                self.msg = [torch.zeros(mw, dtype=torch.float64, device=self.device) for _ in range(4)]   # send_lo, recv_lo, send_hi, recv_hi
+                engine.shard_set_buffers(*[t.data_ptr() for t in self.msg])
+                self.stream = torch.cuda.ExternalStream(engine.stream_ptr(), device=self.device)
+                self.debug_sync = os.environ.get("PTE_DIST_SYNC", "0") == "1"
+            except Exception as exc:                    # keep the run alive on the host-driven exchange (same results)
+                import warnings
+                warnings.warn("stream-ordered boundary exchange unavailable (%r); using the host-driven exchange" % (exc,))
+                self.stream_ordered = False
 
     def _run_scans_stream_ordered(self, first_scan, n_scans):
         e, torch, dist = self.e, self.torch, self.dist
