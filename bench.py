@@ -131,10 +131,12 @@ def main():
     impl = os.environ.get("PTE_SLICE_IMPL", "8")
     kernel_name = {"slice": "k_explore_slice" + ("" if impl == "1" else impl), "toy": "k_explore_toy"}[args.explorer]
     traffic = None
+    issue = None
     try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this kernel at this workload
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(kernel_name)
         if tj and d == 1024 and n_chains == 1024:
             traffic = tj["fetch_bytes"] + tj["write_bytes"]
+            issue = tj.get("issue")                   # what actually bounds the kernel: instruction issue of one wave per replica
     except Exception:
         traffic = None
     achieved = alg_bytes / (ex_avg_ms * 1e-3) / 1e9 if ex_avg_ms > 0 else 0.0
@@ -154,6 +156,7 @@ def main():
                      "traffic": traffic, "avg_launch_ms": ex_avg_ms, "launches": ex_n,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "swap_kernel_avg_launch_ms": sw_ms / max(sw_n, 1),
+                     "instruction_issue": issue,
                      "note": "SliceSampler is bound by the instruction issue of ONE wave per replica walking a sequential "
                              "decision chain (3*d coordinate updates, ~6.5 draws each), not by HBM; see DESIGN.md sec. 5"},
     }
