@@ -2,7 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
-#define REP 256
+#define REP 4096
 template <int MODE>
 __global__ __launch_bounds__(64) void k(double *out, uint64_t *cyc, double a, double b) {
     double x0 = a + threadIdx.x, x1 = a * 2 + threadIdx.x, x2 = a * 3, x3 = a * 4;
@@ -52,7 +52,20 @@ template <int MODE> void run(const char *name) {
     (void)hipMalloc(&out, 64 * 8); (void)hipMalloc(&cyc, 8);
     for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(k<MODE>, dim3(1), dim3(64), 0, 0, out, cyc, 1.0, 1.0000001); (void)hipDeviceSynchronize(); }
     uint64_t c; (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
-    printf("%-52s %.2f cycles per instruction (loop overhead included)\n", name, (double)c / REP / 8);
+    // the same with one wave on EVERY SIMD (1024 blocks), timed by wall clock: ns per instruction, independent of the counter's unit
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    float best = 1e30f;
+    for (int nb : {1024, 2048}) {
+        best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(a, 0);
+            for (int r2 = 0; r2 < 20; ++r2) hipLaunchKernelGGL(k<MODE>, dim3(nb), dim3(64), 0, 0, out, cyc, 1.0, 1.0000001);
+            (void)hipEventRecord(b, 0); (void)hipEventSynchronize(b);
+            float ms; (void)hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+        }
+        printf("%-52s %d blocks: %.2f ns per instruction per wave (20 launches)\n", name, nb, best * 1e6 / 20 / REP / 8);
+    }
+    printf("%-52s %.2f counter ticks per instruction, one wave on the chip\n", name, (double)c / REP / 8);
 }
 int main() {
     run<0>("v_add_f64 dependent"); run<1>("v_add_f64 4 independent chains"); run<2>("v_mul_f64 dependent");
