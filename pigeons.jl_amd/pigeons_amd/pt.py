@@ -541,7 +541,9 @@ def energy_ac1s(pt, skip_reference=False):
     """src/recorders/recorder.jl:156-173: autocorrelation of the log density before / after an exploration
     step, one entry per chain."""
     cor = np.asarray(pt.reduced_recorders.energy_ac1[0])
-    return cor[1:] if (skip_reference and pt.inputs.n_chains > 1) else cor
+    if not skip_reference or len(cor) <= 1:
+        return cor
+    return cor[1:-1] if isinstance(pt.shared.tempering, StabilizedPT) else cor[1:]     # is_reference: chain 1 (and N with two legs)
 
 
 def sample_names(pt):
@@ -612,15 +614,37 @@ def last_round_max_time(pt):
 
 
 def report(pt):
-    """One line of the reference's report table (src/pt/report.jl:8-20)."""
+    """One line of the reference's report table (all_reports(), src/pt/report.jl:8-26); an item whose recorder is
+    missing is skipped, as there."""
     it = pt.shared.iterators
-    row = {"scans": n_scans_in_round(it), "time(s)": last_round_max_time(pt)}
-    if not isinstance(pt.inputs.target, TestSwapper) and pt.inputs.n_chains > 1:
-        m, n = pt.reduced_recorders.swap_acceptance_pr
-        row.update({"Λ": global_barrier(pt), "log(Z₁/Z₀)": stepping_stone(pt),
+    red = pt.reduced_recorders
+    row = {"scans": n_scans_in_round(it)}
+    if red.round_trip is not None:
+        row["restarts"] = red.round_trip[0]
+    n_total = pt.replicas.N
+    if not isinstance(pt.inputs.target, TestSwapper) and n_total > 1:
+        m, n = red.swap_acceptance_pr
+        row["Λ"] = global_barrier(pt)
+        if isinstance(pt.shared.tempering, StabilizedPT) and pt.shared.tempering.variational_leg.communication_barriers is not None:
+            row["Λ_var"] = global_barrier_variational(pt)
+        row.update({"time(s)": last_round_max_time(pt), "log(Z₁/Z₀)": stepping_stone(pt),
                     "min(α)": float(np.min(m)), "mean(α)": float(np.mean(m))})
-    if pt.reduced_recorders.round_trip is not None:
-        row["restarts"], row["round trips"] = pt.reduced_recorders.round_trip
+        names = {b() for b in pt.inputs.record}
+        if "energy_ac1" in names and red.energy_ac1 is not None:
+            rho = np.abs(energy_ac1s(pt, True)); rho = rho[np.isfinite(rho)]
+            if rho.size:
+                row["max|ρ|"], row["mean|ρ|"] = float(rho.max()), float(rho.mean())
+        am, an = red.explorer_acceptance_pr if red.explorer_acceptance_pr is not None else (None, None)
+        if am is not None and np.any(np.asarray(an) > 0):
+            a = np.asarray(am)[np.asarray(an) > 0]
+            row["min(αₑ)"], row["mean(αₑ)"] = float(a.min()), float(a.mean())
+        if red.reversibility_rate is not None and np.any(np.asarray(red.reversibility_rate[1]) > 0):
+            rr = np.asarray(red.reversibility_rate[0])[np.asarray(red.reversibility_rate[1]) > 0]
+            row["min(RR)"], row["mean(RR)"] = float(rr.min()), float(rr.mean())
+    else:
+        row["time(s)"] = last_round_max_time(pt)
+    if red.round_trip is not None:
+        row["round trips"] = red.round_trip[1]
     pt.shared.reports.append(row)
     if pt.inputs.show_report:
         print("  ".join("%s=%s" % (k, ("%.4g" % v) if isinstance(v, float) else v) for k, v in row.items()))
