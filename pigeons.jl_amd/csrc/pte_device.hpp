@@ -161,7 +161,7 @@ __device__ inline double randexp_seq(SeqRng &r) { return randexp_from_raw(r, r.n
 // lanes draw speculatively at consecutive counters; the first lane that needs the slow path is
 // resolved sequentially (it may consume extra draws) and the lanes after it are re-drawn.
 __device__ inline double wave_randn_block(SeqRng &r, int lane, int n_valid /*uniform, <= 64*/,
-                                          const double *wi = ZIG_WI, const unsigned long long *ki = nullptr) {
+                                          const double *wi = ZIG_WI, const unsigned long long *ki = ZIG_KI) {
     double out = 0.0;
     int start = 0;
     while (start < n_valid) {
@@ -170,7 +170,7 @@ __device__ inline double wave_randn_block(SeqRng &r, int lane, int n_valid /*uni
         int idx = (int)(rabs & 0xFF);
         double x = (double)((u & 1) ? -rabs : rabs) * wi[idx];            // tables: global, or staged in LDS by the caller
         bool active = (lane >= start) && (lane < n_valid);
-        bool ok = (uint64_t)rabs < (ki ? ki[idx] : (unsigned long long)ZIG_KI[idx]);
+        bool ok = (uint64_t)rabs < ki[idx];
         uint64_t failmask = ballot64(active && !ok);
         int f = failmask ? (int)__builtin_ctzll(failmask) : n_valid;
         if (active && lane < f) out = x;

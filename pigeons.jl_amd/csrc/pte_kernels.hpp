@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64) void k_init(EngineDev e, uint64_t master_seed, 
 // the evaluation of its swap statistic.
 template <int NLU>
 __device__ __forceinline__ double iid_refresh(const EngineDev &e, int slot, double sd, int lane,
-                                              const double *wi = ZIG_WI, const unsigned long long *ki = nullptr) {
+                                              const double *wi = ZIG_WI, const unsigned long long *ki = ZIG_KI) {
     SeqRng r{e.rng[2 * slot], e.rng[2 * slot + 1]};
     double *xrow = e.x + (int64_t)slot * e.ld;
     const int B = (int)((e.d + 63) >> 6);
@@ -123,7 +123,7 @@ __device__ __forceinline__ double iid_refresh(const EngineDev &e, int slot, doub
         int nl = (int)min((int64_t)64, e.d - 64 * (int64_t)b);
         double v = wave_randn_block(r, lane, nl, wi, ki) / sd;
         if (lane < nl) xrow[64 * b + lane] = v; else v = 0.0;
-        double s = wave_tree_sum64(v * v);
+        double s = wave_sum_dpp(v * v);                     // same tree as wave_tree_sum64, DPP instead of LDS permutes
         if (lane == b) BS = s;
     }
     double S = upper_tree_root<NLU>(BS);
@@ -207,7 +207,7 @@ __device__ __forceinline__ void record_after_explore(const EngineDev &e, int64_t
 // the same at a chain of the MVN path, with explore!'s recorders around it
 template <int NLU>
 __device__ __forceinline__ void iid_refresh_recorded(const EngineDev &e, int64_t cl, int64_t c, int slot, double sd, int lane,
-                                                     const double *wi = ZIG_WI, const unsigned long long *ki = nullptr) {
+                                                     const double *wi = ZIG_WI, const unsigned long long *ki = ZIG_KI) {
     if (e.compose_phase == 2) return;                     // the first explorer's kernel already did
     const double lp0 = lp_before_explore(e, c, slot);
     const double S = iid_refresh<NLU>(e, slot, sd, lane, wi, ki);
