@@ -224,6 +224,26 @@ def test_errors_are_loud(P):
         e.set_schedule([0.0, 0.5, 0.4, 1.0])          # Schedule validity assert
     with pytest.raises(P.PteError):
         e.set_schedule([0.0, 1.0])
+    import pigeons_amd._lib as L
+    bad = [dict(n_chains=0), dict(n_chains=4, dim=0), dict(n_chains=4, dim=8, explorer=99), dict(n_chains=5, world_size=2),
+           dict(n_chains=4, n_chains_variational=4, world_size=2, rank=0),                         # two legs are single-engine
+           dict(n_chains=4, dim=8, explorer=L.EXPLORER_SLICE, explorer2=L.EXPLORER_TOY),            # Compose set
+           dict(n_chains=4, dim=8, target=L.TARGET_FUNNEL, explorer=L.EXPLORER_SLICE),             # funnel: Langevin kernels only
+           dict(n_chains=4, dim=2000, explorer=L.EXPLORER_AUTOMALA),                               # register-resident bound
+           dict(n_chains=4, dim=49, target=L.TARGET_ISING, explorer=L.EXPLORER_SLICE),
+           dict(n_chains=4, dim=8, record_flags=L.RECORD_TRACES_EXTENDED)]                         # extended needs traces
+    for kw in bad:
+        with pytest.raises(P.PteError):
+            P.Engine(**kw)
+    with pytest.raises(P.PteError):                       # a variational reference needs the interpolated path
+        e.set_variational_reference(np.zeros(8), np.ones(8), np.ones(4, dtype=np.int32))
+    f = P.Engine(n_chains=4, dim=6, target=L.TARGET_FUNNEL, explorer=L.EXPLORER_AUTOMALA, target_params=[1.0 / 9.0])
+    with pytest.raises(P.PteError):
+        f.set_variational_reference(np.zeros(6), np.array([1.0, 1.0, 0.0, 1.0, 1.0, 1.0]), np.ones(4, dtype=np.int32))   # std must be > 0
+    cfg = L.PteConfig(); L.load().pte_default_config(cfg); cfg.struct_size += 8
+    import ctypes as C
+    h = C.c_void_p()
+    assert L.load().pte_create(C.byref(cfg), C.byref(h)) != 0 and b"ABI mismatch" in L.load().pte_last_error(None)
 
 
 def test_full_size_properties_metric_config(P):
