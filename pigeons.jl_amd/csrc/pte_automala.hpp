@@ -60,20 +60,30 @@ struct AmTarget {
     double beta, omb, ref_nhp, ref_nprec, log3;   // funnel path
     // GaussianReference end of the path (variational leg): per-coordinate constants in registers when `vr`
     bool vr = false;
-    double vm[E], vc0[E], vi2[E], vgf[E];
+    static constexpr bool V_IN_REGS = (E < 16);      // d > 512: the replica's own vectors already fill the register file
+    double vm[V_IN_REGS ? E : 1], vc0[V_IN_REGS ? E : 1], vi2[V_IN_REGS ? E : 1], vgf[V_IN_REGS ? E : 1];
+    const double *pm = nullptr, *pc0 = nullptr, *pi2 = nullptr, *pgf = nullptr;
     __device__ __forceinline__ void load_variational(const EngineDev &e) {
+        pm = e.v_mean; pc0 = e.v_c0; pi2 = e.v_i2; pgf = e.v_gf;
+        if (V_IN_REGS) {
 #pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const bool ok = valid(j);
-            const int64_t i = 64 * (int64_t)j + lane;
-            vm[j] = ok ? e.v_mean[i] : 0.0; vc0[j] = ok ? e.v_c0[i] : 0.0; vi2[j] = ok ? e.v_i2[i] : 0.0; vgf[j] = ok ? e.v_gf[i] : 0.0;
+            for (int j = 0; j < E; ++j) {
+                const bool ok = valid(j);
+                const int64_t i = 64 * (int64_t)j + lane;
+                vm[j % (V_IN_REGS ? E : 1)] = ok ? e.v_mean[i] : 0.0; vc0[j % (V_IN_REGS ? E : 1)] = ok ? e.v_c0[i] : 0.0;
+                vi2[j % (V_IN_REGS ? E : 1)] = ok ? e.v_i2[i] : 0.0; vgf[j % (V_IN_REGS ? E : 1)] = ok ? e.v_gf[i] : 0.0;
+            }
         }
     }
+    __device__ __forceinline__ double VM(int j) const { return V_IN_REGS ? vm[j % (V_IN_REGS ? E : 1)] : (valid(j) ? pm[64 * j + lane] : 0.0); }
+    __device__ __forceinline__ double VC0(int j) const { return V_IN_REGS ? vc0[j % (V_IN_REGS ? E : 1)] : (valid(j) ? pc0[64 * j + lane] : 0.0); }
+    __device__ __forceinline__ double VI2(int j) const { return V_IN_REGS ? vi2[j % (V_IN_REGS ? E : 1)] : (valid(j) ? pi2[64 * j + lane] : 0.0); }
+    __device__ __forceinline__ double VGF(int j) const { return V_IN_REGS ? vgf[j % (V_IN_REGS ? E : 1)] : (valid(j) ? pgf[64 * j + lane] : 0.0); }
     // gaussian_logdensity (GaussianReference.jl:43-49) with the fixed tree in place of the sequential sum
     __device__ __forceinline__ double variational_lp(const double (&x)[E]) const {
         double t[E];
 #pragma unroll
-        for (int j = 0; j < E; ++j) { const double dx = x[j] - vm[j]; t[j] = valid(j) ? (vc0[j] - vi2[j] * (dx * dx)) : 0.0; }
+        for (int j = 0; j < E; ++j) { const double dx = x[j] - VM(j); t[j] = valid(j) ? (VC0(j) - VI2(j) * (dx * dx)) : 0.0; }
         return tree_sum_regs<E>(t);
     }
     __device__ __forceinline__ double ref_lp(const double (&x)[E], double S) const { return vr ? variational_lp(x) : ref_nhp * S; }
@@ -130,7 +140,7 @@ struct AmTarget {
         logdens += l2 * beta;
         if (vr) {                                    // BufferedAD{GaussianReference}: -1/s^2 (x - m)
 #pragma unroll
-            for (int j = 0; j < E; ++j) g[j] = (vgf[j] * (x[j] - vm[j])) * omb + g2[j] * beta;
+            for (int j = 0; j < E; ++j) g[j] = (VGF(j) * (x[j] - VM(j))) * omb + g2[j] * beta;
         } else {
 #pragma unroll
             for (int j = 0; j < E; ++j) g[j] = (ref_nprec * x[j]) * omb + g2[j] * beta;
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
                 x[j] = 0.0;
                 if (nl > 0) {
                     const double z = wave_randn_block(r0, lane, nl);
-                    x[j] = lane < nl ? z * e.v_std[64 * j + lane] + T.vm[j] : 0.0;
+                    x[j] = lane < nl ? z * e.v_std[64 * j + lane] + T.VM(j) : 0.0;
                     if (lane < nl) xrow[64 * j + lane] = x[j];
                 }
             }
