@@ -1000,3 +1000,24 @@ def test_gaussian_reference_survives_a_checkpoint(P, tmp_path):
     assert np.array_equal(straight.reduced_recorders.index_process, resumed.reduced_recorders.index_process)
     for a, b in zip(straight.replicas.states(), resumed.replicas.states()):
         assert np.array_equal(a, b)
+
+
+def test_two_leg_tempering_ising_and_compose(P):
+    """Two legs on the other device families: Ising (Bernoulli refresh at both ends) and Compose(SliceSampler, AutoMALA)."""
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio]
+    pt = P.PT(P.Inputs(target=P.IsingLogPotential(0.6, 32), n_chains=4, n_chains_variational=5, n_rounds=5, seed=3, record=rec, show_report=False))
+    ref = O.OraclePT(target=O.TARGET_ISING, explorer=O.EXPLORER_ISING, dim=32 * 32, p0=0.6, n_chains=4, n_chains_variational=5, seed=3, slice_n_passes=3)
+    pc = P.PT(P.Inputs(target=P.toy_mvn_target(7), n_chains=5, n_chains_variational=4, n_rounds=5, explorer=P.Compose(P.SliceSampler(), P.AutoMALA()),
+                       record=rec, show_report=False))
+    rc = O.OraclePT(dim=7, n_chains=5, n_chains_variational=4, explorer=O.EXPLORER_SLICE, explorer2=O.EXPLORER_AUTOMALA, am_preconditioner=2)
+    for dev, ora in ((pt, ref), (pc, rc)):
+        for _ in range(5):
+            assert P.next_round(dev)
+            red = P.run_one_round(dev); P.adapt(dev, red)
+            ora.run_round()
+            assert np.array_equal(red.index_process, ora.index_process()) and red.round_trip == ora.round_trip()
+            np.testing.assert_allclose(dev.shared.tempering.schedule.grids, ora.schedule(), rtol=RTOL)
+            np.testing.assert_allclose(P.stepping_stone_pair(dev), ora.stepping_stone_pair(), rtol=RTOL)
+        x, chain, rng = dev.replicas.states(); xr, cr, rr = ora.states()
+        assert np.array_equal(chain, cr) and np.array_equal(rng, rr)
+        np.testing.assert_allclose(x, xr, rtol=1e-9, atol=1e-15)
