@@ -344,22 +344,26 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                         const unsigned hi_h = delta == -4 ? r4hi_h : r8hi_h, lo_h = delta == -4 ? r4lo_h : r8lo_h;
                         const bool rej = need && (uhi > hi_h);
                         const bool amb = need && ((!rej && !(uhi < lo_h)) || !filter_ok);
-                        const int pk = (need ? 1 : 0) | (rej ? 0 : 2) | (amb ? 4 : 0);
-                        // ---- chase
-                        int cc = 0;
+                        // packed: bit 1 = accept, bit 2 = ambiguous, bits 3.. = the NEXT chase state 2 (c + need) + new spin
+                        const unsigned newbit = sg ^ (rej ? 0u : 1u);
+                        const int pk = (rej ? 0 : 2) | (amb ? 4 : 0) | ((2 * (lc + (need ? 1 : 0)) + (int)newbit) << 3);
+                        // ---- chase: state s2 = 2 c + b
+                        int s2 = (int)b;
 #pragma unroll
                         for (int s_ = 0; s_ < 7; ++s_) {
                             if (s_ >= LEN) break;
                             const int tt = T0 + s_;
-                            int q = __builtin_amdgcn_readlane(pk, s_ * (s_ + 1) + 2 * cc + (int)b);
+                            int q = __builtin_amdgcn_readlane(pk, s_ * (s_ + 1) + s2);
                             if (__builtin_expect(q & 4, 0)) {
                                 // guard band (or a chain where the filter is not valid): exact arithmetic of the reference
+                                const int cc = s2 >> 1;
+                                const unsigned bb_ = (unsigned)(s2 & 1);
                                 if (lane == 0) words[row + wj] = cur;
                                 __syncthreads();
                                 const long long spp = recompute();
                                 const unsigned sgs = (cur >> tt) & 1u;
                                 const unsigned rts = tt == 31 ? rt31 : ((cur >> (tt + 1)) & 1u);
-                                const int nbs = 2 * (int)(((up >> tt) & 1u) + ((dn >> tt) & 1u) + b + rts) - 4;
+                                const int nbs = 2 * (int)(((up >> tt) & 1u) + ((dn >> tt) & 1u) + bb_ + rts) - 4;
                                 const int dl = (1 - 2 * (int)sgs) * 2 * nbs;
                                 const unsigned uh = (unsigned)__builtin_amdgcn_readlane(__double2hiint(unit), p + cc);
                                 const unsigned ul = (unsigned)__builtin_amdgcn_readlane(__double2loint(unit), p + cc);
@@ -373,12 +377,14 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                                     if (ratio < 1) rj = (__longlong_as_double((long long)ub) > ratio) ? 1 : 0;
                                     else { rj = 0; nd = 0; }          // accept_ratio >= 1: the reference draws nothing
                                 }
-                                q = nd | (rj ? 0 : 2);
+                                const unsigned nbit = sgs ^ (rj ? 0u : 1u);
+                                q = (rj ? 0 : 2) | ((2 * (cc + nd) + (int)nbit) << 3);
                             }
                             cur ^= (unsigned)((q >> 1) & 1) << tt;
-                            b = (cur >> tt) & 1u;
-                            cc += q & 1;
+                            s2 = q >> 3;
                         }
+                        const int cc = s2 >> 1;
+                        b = (unsigned)(s2 & 1);
                         p += cc;
                     }
                     if (cur != cur0 && lane == 0) words[row + wj] = cur;
