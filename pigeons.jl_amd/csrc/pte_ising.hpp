@@ -257,10 +257,10 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
 // k_explore_ising_spec: the bit-packed sweep with the 64 lanes as hypotheses, the way k_explore_slice7/8
 // break the slice sampler's chain.  The outcome of site t depends on the sweep so far only through
 // (b, c): the NEW value b of its left neighbour and the number c of uniforms consumed since the chunk
-// started (which picks the uniform it would read).  For a chunk of 7 consecutive sites there are
-// sum_t 2 (t + 1) = 56 such hypotheses: lane t(t+1) + 2c + b evaluates site t under (c, b) in one vector
-// pass (neighbour count, delta, the filtered accept decision against the integer thresholds), and a
-// scalar chase of ~11 instructions per site walks through the true ones.  Guard-band decisions (and chains
+// started (which picks the uniform it would read).  A 16-site chunk is cut into four quads; quad k can start
+// in 2 (4k + 1) states, 56 hypotheses in all: each lane walks the four sites of its quad under its (c, b)
+// in one vector pass (neighbour counts, deltas, the filtered accept decisions against the integer thresholds),
+// and a scalar chase of four steps per chunk picks the true quads and carries the state on.  Guard-band decisions (and chains
 // whose filter is not valid) are taken by the exact arithmetic of the reference, with sum_pair_products
 // recomputed on demand; the final sum_pair_products is recomputed from the lattice by popcounts.
 // ---------------------------------------------------------------------------------------------
@@ -310,10 +310,11 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
         const unsigned long long r4lo = ((unsigned long long)r4lo_h << 32) | lo32(r4l), r4hi = ((unsigned long long)r4hi_h << 32) | lo32(r4h);
         const unsigned long long r8lo = ((unsigned long long)r8lo_h << 32) | lo32(r8l), r8hi = ((unsigned long long)r8hi_h << 32) | lo32(r8h);
         const bool filter_ok = bb > 1e-6;
-        // this lane's hypothesis (lt, lc, lb): site lt of the chunk, lc uniforms consumed before it, left neighbour now lb
-        int lt = 0;
-        while ((lt + 1) * (lt + 2) <= lane) lt += 1;
-        const int lidx = lane - lt * (lt + 1);
+        // this lane's hypothesis (lk, lc, lb): quad lk of a 16-site chunk (sites 4 lk .. 4 lk + 3), lc uniforms consumed
+        // since the chunk started, left neighbour of the quad's first site now lb; 2 (4 lk + 1) hypotheses per quad = 56 lanes
+        const int lk = (lane >= 2) + (lane >= 12) + (lane >= 30);
+        const int lbase = lk == 0 ? 0 : lk == 1 ? 2 : lk == 2 ? 12 : 30;
+        const int lidx = lane - lbase;
         const int lc = lidx >> 1;
         const unsigned lb = (unsigned)(lidx & 1);
         double unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma));
@@ -329,63 +330,77 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                     const unsigned rightbit = (wj == W - 1) ? (first_updated & 1u) : (lds_word(words, row + wj + 1) & 1u);
                     const unsigned cur0 = cur;
 #pragma unroll
-                    for (int T0 = 0; T0 < 32; T0 += 7) {
-                        const int LEN = (32 - T0) < 7 ? (32 - T0) : 7;
-                        if (p + LEN > 64) { seed += (uint64_t)p * gamma; unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma)); p = 0; }
-                        // ---- vector pass: every (site, consumed, left) hypothesis of the chunk
-                        const int t = (T0 + lt) & 31;
+                    for (int T0 = 0; T0 < 32; T0 += 16) {
+                        if (p + 16 > 64) { seed += (uint64_t)p * gamma; unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma)); p = 0; }
                         const unsigned rt31 = (W == 1) ? (cur & 1u) : rightbit;
-                        const unsigned sg = (cur >> t) & 1u;
-                        const unsigned rt = (T0 + lt == 31) ? rt31 : ((cur >> ((t + 1) & 31)) & 1u);
-                        const int nb = 2 * (int)(((up >> t) & 1u) + ((dn >> t) & 1u) + lb + rt) - 4;
-                        const int delta = (1 - 2 * (int)sg) * 2 * nb;
-                        const bool need = delta < 0;
-                        const unsigned uhi = (unsigned)__shfl(__double2hiint(unit), (p + lc) & 63, 64);
-                        const unsigned hi_h = delta == -4 ? r4hi_h : r8hi_h, lo_h = delta == -4 ? r4lo_h : r8lo_h;
-                        const bool rej = need && (uhi > hi_h);
-                        const bool amb = need && ((!rej && !(uhi < lo_h)) || !filter_ok);
-                        // packed: bit 1 = accept, bit 2 = ambiguous, bits 3.. = the NEXT chase state 2 (c + need) + new spin
-                        const unsigned newbit = sg ^ (rej ? 0u : 1u);
-                        const int pk = (rej ? 0 : 2) | (amb ? 4 : 0) | ((2 * (lc + (need ? 1 : 0)) + (int)newbit) << 3);
-                        // ---- chase: state s2 = 2 c + b
+                        // ---- vector pass: every (quad, consumed, left) hypothesis of the chunk walks its four sites
+                        int c_run = lc, accbits = 0;
+                        unsigned left = lb;
+                        bool amb = false;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int t = (T0 + 4 * lk + j) & 31;
+                            const unsigned sg = (cur >> t) & 1u;
+                            const unsigned rt = (t == 31) ? rt31 : ((cur >> ((t + 1) & 31)) & 1u);
+                            const int nb = 2 * (int)(((up >> t) & 1u) + ((dn >> t) & 1u) + left + rt) - 4;
+                            const int delta = (1 - 2 * (int)sg) * 2 * nb;
+                            const bool need = delta < 0;
+                            const unsigned uhi = (unsigned)__shfl(__double2hiint(unit), (p + c_run) & 63, 64);
+                            const unsigned hi_h = delta == -4 ? r4hi_h : r8hi_h, lo_h = delta == -4 ? r4lo_h : r8lo_h;
+                            const bool rej = need && (uhi > hi_h);
+                            amb = amb || (need && ((!rej && !(uhi < lo_h)) || !filter_ok));
+                            left = sg ^ (rej ? 0u : 1u);
+                            accbits |= (rej ? 0 : 1) << j;
+                            c_run += need ? 1 : 0;
+                        }
+                        // packed: bit 0 = ambiguous somewhere in the quad, bits 1-4 = accepts, bits 5.. = NEXT chase state 2 c + spin
+                        const int pk = (amb ? 1 : 0) | (accbits << 1) | ((2 * c_run + (int)left) << 5);
+                        // ---- chase over the four quads: state s2 = 2 c + b
                         int s2 = (int)b;
 #pragma unroll
-                        for (int s_ = 0; s_ < 7; ++s_) {
-                            if (s_ >= LEN) break;
-                            const int tt = T0 + s_;
-                            int q = __builtin_amdgcn_readlane(pk, s_ * (s_ + 1) + s2);
-                            if (__builtin_expect(q & 4, 0)) {
-                                // guard band (or a chain where the filter is not valid): exact arithmetic of the reference
-                                const int cc = s2 >> 1;
-                                const unsigned bb_ = (unsigned)(s2 & 1);
-                                if (lane == 0) words[row + wj] = cur;
-                                __syncthreads();
-                                const long long spp = recompute();
-                                const unsigned sgs = (cur >> tt) & 1u;
-                                const unsigned rts = tt == 31 ? rt31 : ((cur >> (tt + 1)) & 1u);
-                                const int nbs = 2 * (int)(((up >> tt) & 1u) + ((dn >> tt) & 1u) + bb_ + rts) - 4;
-                                const int dl = (1 - 2 * (int)sgs) * 2 * nbs;
-                                const unsigned uh = (unsigned)__builtin_amdgcn_readlane(__double2hiint(unit), p + cc);
-                                const unsigned ul = (unsigned)__builtin_amdgcn_readlane(__double2loint(unit), p + cc);
-                                const unsigned long long ub = ((unsigned long long)uh << 32) | ul;
-                                const unsigned long long lo = dl == -4 ? r4lo : r8lo, hi = dl == -4 ? r4hi : r8hi;
-                                int rj, nd = 1;
-                                if (filter_ok && ub > hi) rj = 1;
-                                else if (filter_ok && ub < lo) rj = 0;
-                                else {
-                                    const double ratio = exp(ising_lp(beta, bt, (double)(spp + dl)) - ising_lp(beta, bt, (double)spp));
-                                    if (ratio < 1) rj = (__longlong_as_double((long long)ub) > ratio) ? 1 : 0;
-                                    else { rj = 0; nd = 0; }          // accept_ratio >= 1: the reference draws nothing
+                        for (int kq = 0; kq < 4; ++kq) {
+                            const int q = __builtin_amdgcn_readlane(pk, (kq == 0 ? 0 : kq == 1 ? 2 : kq == 2 ? 12 : 30) + s2);
+                            if (__builtin_expect(q & 1, 0)) {
+                                // a guard-band decision (or a chain whose filter is not valid) inside this quad: its four sites by
+                                // the scalar procedure with the exact arithmetic of the reference where needed
+                                int cc = s2 >> 1;
+                                unsigned bb_ = (unsigned)(s2 & 1);
+                                for (int j = 0; j < 4; ++j) {
+                                    const int tt = T0 + 4 * kq + j;
+                                    const unsigned sgs = (cur >> tt) & 1u;
+                                    const unsigned rts = tt == 31 ? rt31 : ((cur >> (tt + 1)) & 1u);
+                                    const int nbs = 2 * (int)(((up >> tt) & 1u) + ((dn >> tt) & 1u) + bb_ + rts) - 4;
+                                    const int dl = (1 - 2 * (int)sgs) * 2 * nbs;
+                                    int rj = 0, nd = 0;
+                                    if (dl < 0) {
+                                        nd = 1;
+                                        const unsigned uh = (unsigned)__builtin_amdgcn_readlane(__double2hiint(unit), p + cc);
+                                        const unsigned ul = (unsigned)__builtin_amdgcn_readlane(__double2loint(unit), p + cc);
+                                        const unsigned long long ub = ((unsigned long long)uh << 32) | ul;
+                                        const unsigned long long lo = dl == -4 ? r4lo : r8lo, hi = dl == -4 ? r4hi : r8hi;
+                                        if (filter_ok && ub > hi) rj = 1;
+                                        else if (filter_ok && ub < lo) rj = 0;
+                                        else {
+                                            if (lane == 0) words[row + wj] = cur;
+                                            __syncthreads();
+                                            const long long spp = recompute();
+                                            const double ratio = exp(ising_lp(beta, bt, (double)(spp + dl)) - ising_lp(beta, bt, (double)spp));
+                                            if (ratio < 1) rj = (__longlong_as_double((long long)ub) > ratio) ? 1 : 0;
+                                            else { rj = 0; nd = 0; }          // accept_ratio >= 1: the reference draws nothing
+                                        }
+                                    }
+                                    cur ^= (unsigned)(rj ? 0 : 1) << tt;
+                                    bb_ = (cur >> tt) & 1u;
+                                    cc += nd;
                                 }
-                                const unsigned nbit = sgs ^ (rj ? 0u : 1u);
-                                q = (rj ? 0 : 2) | ((2 * (cc + nd) + (int)nbit) << 3);
+                                s2 = 2 * cc + (int)bb_;
+                            } else {
+                                cur ^= (unsigned)((q >> 1) & 15) << (T0 + 4 * kq);
+                                s2 = q >> 5;
                             }
-                            cur ^= (unsigned)((q >> 1) & 1) << tt;
-                            s2 = q >> 3;
                         }
-                        const int cc = s2 >> 1;
+                        p += s2 >> 1;
                         b = (unsigned)(s2 & 1);
-                        p += cc;
                     }
                     if (cur != cur0 && lane == 0) words[row + wj] = cur;
                     if (wj == 0) first_updated = cur;
