@@ -53,6 +53,7 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
     const int B = (int)((d + 63) >> 6);
     const double nhp = e.nhp[c];
     const double inv_nhp = 1.0 / nhp;
+    const double inv_abs_nhp = -inv_nhp * (1.0 + 1e-6);
     const double w = sp.w;
     const double w11 = 1.1 * sp.w;
     const int cap_iters = min(sp.max_iter, CAP_ITERS);
@@ -79,17 +80,27 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
     int p = 0;                                         // uniform: next unread draw of the window
     uint64_t gamma_inv = gamma;                        // gamma^-1 mod 2^64 (gamma is odd): Newton, 5 steps
     for (int k = 0; k < 5; ++k) gamma_inv *= 2ull - gamma * gamma_inv;
+    // Upper bound on sum x^2 for the filter margins.  An accepted coordinate grows sum x^2 by less than E_c / |nhp| (its
+    // new value satisfies v^2 < x_c^2 + E_c / |nhp| + margin), and every E_c taken on the fast path is one of the window's
+    // exponentials: so  S(now) <= S(at the last exact point) + (sum of ALL exponentials of the windows used since) / |nhp|.
+    // `wsum` = that sum for the current window; Sest is bumped by it at every refill and re-based at block boundaries.
+    double wsum = 0.0;
     auto fill_window = [&]() __attribute__((always_inline)) {
         __syncthreads();                               // one wave per block: orders the LDS accesses
+        double acc = 0.0;
 #pragma unroll
         for (int k = 0; k < WIN / 64; ++k) {
             const int i = 64 * k + lane;
             const uint64_t r = mix64(wseed + (uint64_t)(i + 1) * gamma);
             const uint64_t ri = r & MASK52;
             const int idx = (int)(ri & 0xFF);
+            const bool fast = ri < s_ke[idx];
+            const double ev = (double)ri * s_we[idx];
             s_u[i] = u52_to_unit(r);
-            s_e[i] = (ri < s_ke[idx]) ? (double)ri * s_we[idx] : __longlong_as_double(0x7ff8000000000000LL);
+            s_e[i] = fast ? ev : __longlong_as_double(0x7ff8000000000000LL);
+            acc += fast ? ev : 0.0;
         }
+        wsum = wave_sum_dpp(acc);
         p = 0;
         __syncthreads();
     };
@@ -107,11 +118,11 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
             const int64_t base = 64 * (int64_t)b;
             const int nl = (int)min((int64_t)64, d - base);
             double X = (lane < nl) ? xrow[base + lane] : 0.0;
-            double Sest = S;
+            double Sest = S * (1.0 + 1e-6) + wsum * inv_abs_nhp;       // upper bound on sum x^2 while this window lasts
             int l = 0;
             while (l < nl) {
                 PROF_T(t0);
-                if (p > REFILL_AT) { wseed += (uint64_t)p * gamma; fill_window(); }
+                if (p > REFILL_AT) { wseed += (uint64_t)p * gamma; fill_window(); Sest = Sest * (1.0 + 1e-6) + wsum * inv_abs_nhp; }
                 // ================= speculative round: lane = hypothesis (l + hg, p + hrel) ==========
                 // Decisions are sign tests of d(v) = v^2 - Q; every tested |d| is folded into dmin and the
                 // hypothesis is valid only if dmin clears the margin at the end (so the loops carry no
@@ -269,18 +280,15 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                     valid = valid && (!chk || (ok && !unfinished));
                 }
                 valid = valid && (dmin > 2e-12 * Bq);
-                const int packed = (valid ? VALID : 0) | (2 + kd + n) | ((kd + n) << 8);
-                const double dS = fabs(xf * xf - xold * xold);
+                const int packed = (valid ? VALID : 0) | (2 + kd + n);
 #ifdef PTE_PROFILE_SECTIONS
-                asm volatile("" :: "v"(packed), "v"(dS));
+                asm volatile("" :: "v"(packed));
 #endif
                 PROF_T(t3); PROF_ADD(2, t3 - t2); PROF_ADD(3, 1);
                 // ================= chase the true path through the hypotheses =======================
                 int gdone = 0;
                 {
-                    const double X0 = X, Sest0 = Sest;
-                    int o = 0, st = 0;
-                    uint64_t tmask = 0;
+                    int o = 0;
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         if (l + g >= nl) break;
@@ -289,20 +297,11 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                         const int ln = BASE[g] + k;
                         const int pk = __builtin_amdgcn_readlane(packed, ln);
                         if (!(pk & VALID)) break;
-                        tmask |= 1ull << ln;
-                        Sest = Sest + readlane_f64(dS, ln);
                         X = writelane_f64(X, readlane_f64(xf, ln), l + g);
                         o += pk & 0xFF;
-                        st += (pk >> 8) & 0xFFF;
                         gdone += 1;
                     }
-                    // every applied hypothesis' margin (computed from the round's Sest) must still cover S
-                    if (__builtin_expect((ballot64(!(Sest <= 99.0 * Bq)) & tmask) != 0ull, 0)) {
-                        const int pk = __builtin_amdgcn_readlane(packed, 0);        // keep the certain one only
-                        X = writelane_f64(X0, readlane_f64(xf, 0), l);
-                        Sest = Sest0 + readlane_f64(dS, 0);
-                        o = pk & 0xFF; st = (pk >> 8) & 0xFFF; gdone = 1;
-                    }
+                    const int st = o - 2 * gdone;             // explorer_n_steps: every coordinate draws E and u0, the rest are steps
                     steps_sum += st; steps_n += 2 * gdone; acc_n += gdone; acc_sum += gdone;
                     p += o;
                     l += gdone;
