@@ -36,6 +36,7 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
     __shared__ unsigned long long s_ke[256];
     __shared__ double s_u[WIN];
     __shared__ double s_e[WIN];              // randexp fast-path value; NaN <=> slow path needed
+    __shared__ double s_x[64];               // the current 64-coordinate block: start-of-pass values, overwritten as coordinates retire
     const int lane = lane_id();
     for (int i = lane; i < 256; i += 64) { s_we[i] = ZIG_WE[i]; s_ke[i] = ZIG_KE[i]; }
     __syncthreads();
@@ -63,6 +64,14 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
     const int hg = (lane >= BASE[1]) + (lane >= BASE[2]) + (lane >= BASE[3]) + (lane >= BASE[4]);
     const int hrel = (hg == 0) ? 0 : (hg == 1) ? (LO[1] + lane - BASE[1]) : (hg == 2) ? (LO[2] + lane - BASE[2])
                    : (hg == 3) ? (LO[3] + lane - BASE[3]) : (LO[4] + lane - BASE[4]);
+
+    // the hypothesis that follows this one on the true path starts `cnt` draws later, one coordinate further:
+    // lane  succ_base + (cnt + succ_off)  if that falls into the next level's window (never for the last level)
+    const int succ_lo = (hg == 0) ? LO[1] : (hg == 1) ? LO[2] : (hg == 2) ? LO[3] : (hg == 3) ? LO[4] : 0;
+    const int succ_wd = (hg == 0) ? WD[1] : (hg == 1) ? WD[2] : (hg == 2) ? WD[3] : (hg == 3) ? WD[4] : 0;
+    const int succ_base = (hg == 0) ? BASE[1] : (hg == 1) ? BASE[2] : (hg == 2) ? BASE[3] : (hg == 3) ? BASE[4] : 0;
+    const int succ_off = hrel - succ_lo;
+    const uint64_t seed_in = e.rng[2 * slot];
 
     double BS = 0.0;                                   // lane b: exact fixed-tree sum of block b
     for (int b = 0; b < B; ++b) {
@@ -106,8 +115,10 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
     };
     fill_window();
 
-    long long steps_sum = 0;
-    int steps_n = 0, acc_sum = 0, acc_n = 0;
+    // recorder sums of the coordinates done by the exact sequential procedure; those of the speculative rounds are
+    // derived at the end from the draws consumed (every coordinate draws E and u0, every further draw is one step)
+    long long steps_sum = 0, fb_draws = 0;
+    int steps_n = 0, acc_sum = 0, acc_n = 0, n_fb = 0;
     int err = 0, err_coord = -1;
 #ifdef PTE_PROFILE_SECTIONS
     long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -117,7 +128,8 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
         for (int b = 0; b < B && !err; ++b) {
             const int64_t base = 64 * (int64_t)b;
             const int nl = (int)min((int64_t)64, d - base);
-            double X = (lane < nl) ? xrow[base + lane] : 0.0;
+            s_x[lane] = (lane < nl) ? xrow[base + lane] : 0.0;
+            __builtin_amdgcn_wave_barrier();
             double Sest = S * (1.0 + 1e-6) + wsum * inv_abs_nhp;       // upper bound on sum x^2 while this window lasts
             int l = 0;
             while (l < nl) {
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                 // validity state).  NaNs never pass: they fail the final interval-width test.
                 // ---- head: slice level and initial interval (SliceSampler.jl:97-113)
                 const bool active = (l + hg) < nl;
-                const double xold = __shfl(X, (l + hg) & 63, 64);
+                const double xold = s_x[(l + hg) & 63];       // not yet updated in this pass
                 const int idx0 = p + hrel;
                 const double E = s_e[idx0];
                 const double u0 = s_u[idx0 + 1];
@@ -280,39 +292,47 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                     valid = valid && (!chk || (ok && !unfinished));
                 }
                 valid = valid && (dmin > 2e-12 * Bq);
-                const int packed = (valid ? VALID : 0) | (2 + kd + n);
+                // ================= chase the true path through the hypotheses =======================
+                // Branch free: every lane names its successor, the chase is one v_readlane per level.  An invalid
+                // hypothesis packs 0, so a broken path falls back to lane 0, which never carries the level >= 1 flag.
+                const int cnt = 2 + kd + n;
+                const int kn = cnt + succ_off;
+                const bool inw = (unsigned)kn < (unsigned)succ_wd;
+                const uint64_t vmask = ballot64(valid);
+                const int packed = (valid && lane != 0) ? (int)(0x80000000u | (unsigned)cnt | (inw ? (unsigned)(kn + succ_base) << 8 : 0u)) : 0;
 #ifdef PTE_PROFILE_SECTIONS
                 asm volatile("" :: "v"(packed));
 #endif
                 PROF_T(t3); PROF_ADD(2, t3 - t2); PROF_ADD(3, 1);
-                // ================= chase the true path through the hypotheses =======================
-                int gdone = 0;
+                int gdone = (int)(vmask & 1ull);
                 {
-                    int o = 0;
+                    const int cnt0 = __builtin_amdgcn_readlane(cnt, 0);
+                    const int k1 = cnt0 - LO[1];
+                    int o = gdone ? cnt0 : 0;
+                    int cur = (gdone && (unsigned)k1 < (unsigned)WD[1]) ? BASE[1] + k1 : 0;
+                    uint64_t tmask = 1ull;
 #pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        if (l + g >= nl) break;
-                        const int k = o - LO[g];
-                        if ((unsigned)k >= (unsigned)WD[g]) break;
-                        const int ln = BASE[g] + k;
-                        const int pk = __builtin_amdgcn_readlane(packed, ln);
-                        if (!(pk & VALID)) break;
-                        X = writelane_f64(X, readlane_f64(xf, ln), l + g);
+                    for (int g = 1; g < G; ++g) {
+                        const int pk = __builtin_amdgcn_readlane(packed, cur);
+                        tmask |= 1ull << cur;
                         o += pk & 0xFF;
-                        gdone += 1;
+                        gdone += (int)((unsigned)pk >> 31);
+                        cur = (pk >> 8) & 63;
                     }
-                    const int st = o - 2 * gdone;             // explorer_n_steps: every coordinate draws E and u0, the rest are steps
-                    steps_sum += st; steps_n += 2 * gdone; acc_n += gdone; acc_sum += gdone;
+                    tmask &= vmask;                           // (a path ends AT an invalid lane: its bit was set above)
+                    if (__builtin_amdgcn_inverse_ballot_w64(tmask)) s_x[(l + hg) & 63] = xf;
+                    __builtin_amdgcn_wave_barrier();
                     p += o;
                     l += gdone;
                 }
 #ifdef PTE_PROFILE_SECTIONS
-                asm volatile("" :: "v"(X), "s"(p), "s"(l));
+                asm volatile("" :: "s"(p), "s"(l));
 #endif
                 PROF_T(t4); PROF_ADD(5, t4 - t3); PROF_ADD(4, gdone);
                 if (__builtin_expect(gdone == 0, 0)) {
                     // ================= exact sequential procedure for coordinate l ===================
                     SeqRng rs{wseed + (uint64_t)p * gamma, gamma};
+                    const double X = s_x[lane];
                     const double xo = readlane_f64(X, l);
                     const double E = randexp_seq(rs);
                     const double u0 = rs.rand();
@@ -377,13 +397,17 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                     }
                     if (!fin) { err = ERR_SLICE_MAX_ITER; err_coord = (int)(base + l); break; }
                     Sest = Sest + fabs(xn * xn - xo * xo);
-                    if (lane == l) X = xn;
+                    if (lane == l) s_x[l] = xn;
+                    __builtin_amdgcn_wave_barrier();
                     l += 1;
-                    p += (int)((rs.seed - (wseed + (uint64_t)p * gamma)) * gamma_inv);   // draws consumed; window stays
+                    const int used = (int)((rs.seed - (wseed + (uint64_t)p * gamma)) * gamma_inv);   // draws consumed; window stays
+                    p += used;
+                    fb_draws += used; n_fb += 1;
                     PROF_T(t5); PROF_ADD(7, t5 - t4); PROF_ADD(6, 1);
                 }
             }
             if (err) break;
+            const double X = s_x[lane];
             if (lane < nl) xrow[base + lane] = X;
             {   // re-establish the exact fixed-tree values at the block boundary
                 const double s = wave_sum_dpp(X * X);
@@ -395,8 +419,12 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
     }
     if (err) { if (lane == 0) set_error(e, err, (int)c, err_coord); return; }
     if (lane == 0) {
+        const uint64_t seed_out = wseed + (uint64_t)p * gamma;
+        const long long n_spec = (long long)sp.n_passes * d - n_fb;                               // coordinates retired by speculative rounds
+        const long long spec_draws = (long long)((seed_out - seed_in) * gamma_inv) - fb_draws;
+        steps_sum += spec_draws - 2 * n_spec; steps_n += (int)(2 * n_spec); acc_sum += (int)n_spec; acc_n += (int)n_spec;
         e.suff[slot] = S;
-        e.rng[2 * slot] = wseed + (uint64_t)p * gamma;
+        e.rng[2 * slot] = seed_out;
         e.expl_steps_sum[cl] += (double)steps_sum; e.expl_steps_n[cl] += steps_n;
         e.expl_acc_sum[cl] += (double)acc_sum;     e.expl_acc_n[cl] += acc_n;
 #ifdef PTE_PROFILE_SECTIONS

@@ -20,7 +20,7 @@ pt.replicas.reduce()
 m, v, n = pt.replicas.online()
 cnt = (v * (n - 1)).reshape(-1)[:8 * N].reshape(N, 8) / scans
 names = ["head_dbl", "shrink", "accept", "rounds", "coords_spec", "chase", "fallbacks", "fallback_cyc"]
-for ch in (1, 32, 64, 127):
+for ch in (1, 8, 16, 32, 48, 64, 80, 96, 112, 127):
     c = cnt[ch]
     tot = c[0] + c[1] + c[2] + c[5] + c[7]
     print("chain %3d: total %.2fM | " % (ch, tot / 1e6) + "  ".join("%s %.0f" % (nm, x) for nm, x in zip(names, c)))
