@@ -212,18 +212,54 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                 double Lbar = LL, Rbar = RR, xf = xold, W = 0.0;
                 int n = 0;
                 bool fin = false;
+                if constexpr (S8_BS == 8) {
+                    // Hand-scheduled: a lane whose proposal lands inside the slice drops out of EXEC (v_cmpx), which freezes
+                    // its result, step count and bracket -- no per-step selects, no mask arithmetic, no branches.  Fixed
+                    // registers because the 64-bit selects address register halves.  (>= 2 instructions between a VALU
+                    // write of VCC and its use as a lane mask; EXEC restored before the block ends.)
+                    double t_ = 0.0;
+                    uint64_t fin_mask, exec_save;
+#define PTE_S8_STEP(U) \
+                    "v_add_f64 v[216:217], v[202:203], -v[200:201]\n" \
+                    "v_mul_f64 v[206:207], " U ", v[216:217]\n" \
+                    "v_add_f64 v[204:205], v[200:201], v[206:207]\n" \
+                    "v_cmp_lt_f64 vcc, v[204:205], v[212:213]\n" \
+                    "v_mul_f64 v[206:207], v[204:205], v[204:205]\n" \
+                    "v_add_u32 v210, 1, v210\n" \
+                    "v_add_f64 v[206:207], v[206:207], -v[214:215]\n" \
+                    "v_cndmask_b32 v200, v200, v204, vcc\n" \
+                    "v_cndmask_b32 v201, v201, v205, vcc\n" \
+                    "v_cndmask_b32 v202, v204, v202, vcc\n" \
+                    "v_cndmask_b32 v203, v205, v203, vcc\n" \
+                    "v_min_f64 v[208:209], v[208:209], |v[206:207]|\n" \
+                    "v_cmpx_ngt_f64 vcc, 0, v[206:207]\n"
+                    asm volatile("s_mov_b64 %[sv], exec\n"
+                                 PTE_S8_STEP("%[u0]") PTE_S8_STEP("%[u1]") PTE_S8_STEP("%[u2]") PTE_S8_STEP("%[u3]")
+                                 PTE_S8_STEP("%[u4]") PTE_S8_STEP("%[u5]") PTE_S8_STEP("%[u6]") PTE_S8_STEP("%[u7]")
+                                 "s_andn2_b64 %[fin], %[sv], exec\n"
+                                 "s_mov_b64 exec, %[sv]\n"
+                                 "s_nop 3\n"
+                                 : "+{v[200:201]}"(Lbar), "+{v[202:203]}"(Rbar), "+{v[204:205]}"(xf), "+{v[206:207]}"(t_),
+                                   "+{v[208:209]}"(dmin), "+{v210}"(n), "+{v[216:217]}"(W), [fin] "=&s"(fin_mask), [sv] "=&s"(exec_save)
+                                 : "{v[212:213]}"(xold), "{v[214:215]}"(Q), [u0] "v"(u[0]), [u1] "v"(u[1]), [u2] "v"(u[2]), [u3] "v"(u[3]),
+                                   [u4] "v"(u[4]), [u5] "v"(u[5]), [u6] "v"(u[6]), [u7] "v"(u[7])
+                                 : "vcc");
+#undef PTE_S8_STEP
+                    fin = __builtin_amdgcn_inverse_ballot_w64(fin_mask);
+                } else {
 #pragma unroll
-                for (int k = 0; k < S8_BS; ++k) {
-                    W = Rbar - Lbar;
-                    const double v = Lbar + u[k] * W;
-                    const double dv = v * v - Q;
-                    dmin = fmin(dmin, fabs(dv));              // (after `fin` too: only ever makes the filter more conservative)
-                    xf = fin ? xf : v;
-                    n += fin ? 0 : 1;
-                    const bool below = v < xold;
-                    Lbar = below ? v : Lbar;                 // (after `fin` these only shrink further: harmless)
-                    Rbar = below ? Rbar : v;
-                    fin = fin || (dv < 0.0);
+                    for (int k = 0; k < S8_BS; ++k) {
+                        W = Rbar - Lbar;
+                        const double v = Lbar + u[k] * W;
+                        const double dv = v * v - Q;
+                        dmin = fmin(dmin, fabs(dv));              // (after `fin` too: only ever makes the filter more conservative)
+                        xf = fin ? xf : v;
+                        n += fin ? 0 : 1;
+                        const bool below = v < xold;
+                        Lbar = below ? v : Lbar;                 // (after `fin` these only shrink further: harmless)
+                        Rbar = below ? Rbar : v;
+                        fin = fin || (dv < 0.0);
+                    }
                 }
                 if (__builtin_expect(ballot64(lane == 0 && !fin && n < cap_iters) != 0ull, 0)) {
                     // the certain hypothesis continues from its state after S8_BS rejected proposals
