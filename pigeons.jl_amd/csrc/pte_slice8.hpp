@@ -117,11 +117,11 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
 
     // recorder sums of the coordinates done by the exact sequential procedure; those of the speculative rounds are
     // derived at the end from the draws consumed (every coordinate draws E and u0, every further draw is one step)
-    long long steps_sum = 0, fb_draws = 0;
+    long long steps_sum = 0, fb_draws = 0, ex_total = 0;     // ex_total: extra draws of slow-path exponentials taken inside rounds
     int steps_n = 0, acc_sum = 0, acc_n = 0, n_fb = 0;
     int err = 0, err_coord = -1;
 #ifdef PTE_PROFILE_SECTIONS
-    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
     for (int pass = 0; pass < sp.n_passes && !err; ++pass) {
@@ -142,8 +142,23 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                 // ---- head: slice level and initial interval (SliceSampler.jl:97-113)
                 const bool active = (l + hg) < nl;
                 const double xold = s_x[(l + hg) & 63];       // not yet updated in this pass
-                const int idx0 = p + hrel;
-                const double E = s_e[idx0];
+                int idx0 = p + hrel;
+                double E = s_e[idx0];
+                int ex0 = 0;
+                if (__builtin_expect((ballot64(E != E) & 1ull) != 0ull, 0)) {
+                    // the certain hypothesis needs the ziggurat's slow path for its exponential (2.3 % of the coordinates):
+                    // evaluate it exactly at its stream position; its other draws follow `ex0` positions later
+                    SeqRng rs{wseed + (uint64_t)p * gamma, gamma};
+                    const double Ex = randexp_seq(rs);
+                    const int used = (int)((rs.seed - (wseed + (uint64_t)p * gamma)) * gamma_inv);
+                    if (used <= 17) {
+                        ex0 = used - 1;
+                        if (lane == 0) { E = Ex; idx0 += ex0; }
+                        Sest += Ex * inv_abs_nhp;            // not among the window's fast-path exponentials summed into Sest
+                        ex_total += ex0;
+                    }
+                }
+                const int ex = (lane == 0) ? ex0 : 0;
                 const double u0 = s_u[idx0 + 1];
                 double Vn = s_u[idx0 + 2];                   // next unread draw of this hypothesis
                 const double Q = xold * xold - E * inv_nhp;
@@ -327,11 +342,24 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                     }
                     valid = valid && (!chk || (ok && !unfinished));
                 }
+#ifdef PTE_PROFILE_SECTIONS
+                {   // why the certain hypothesis (lane 0) fails, when it does
+                    const bool mg = dmin > 2e-12 * Bq;
+                    const uint64_t v0 = ballot64(valid && mg) & 1ull;
+                    if (!v0) {
+                        PROF_ADD(8, (int)(ballot64(E != E) & 1ull));
+                        PROF_ADD(9, (int)(ballot64(!fin) & 1ull));
+                        PROF_ADD(10, (int)(ballot64(!(E != E) && fin && !valid) & 1ull));   // acceptance check said no / unfinished / other
+                        PROF_ADD(11, (int)(ballot64(valid && !mg) & 1ull));
+                        PROF_ADD(12, (int)(ballot64(!(fmin(dL, dR) < 0.0) ? false : true) & 1ull));
+                    }
+                }
+#endif
                 valid = valid && (dmin > 2e-12 * Bq);
                 // ================= chase the true path through the hypotheses =======================
                 // Branch free: every lane names its successor, the chase is one v_readlane per level.  An invalid
                 // hypothesis packs 0, so a broken path falls back to lane 0, which never carries the level >= 1 flag.
-                const int cnt = 2 + kd + n;
+                const int cnt = 2 + kd + n + ex;
                 const int kn = cnt + succ_off;
                 const bool inw = (unsigned)kn < (unsigned)succ_wd;
                 const uint64_t vmask = ballot64(valid);
@@ -367,6 +395,7 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                 PROF_T(t4); PROF_ADD(5, t4 - t3); PROF_ADD(4, gdone);
                 if (__builtin_expect(gdone == 0, 0)) {
                     // ================= exact sequential procedure for coordinate l ===================
+                    ex_total -= ex0;                              // (its exponential is drawn again below)
                     SeqRng rs{wseed + (uint64_t)p * gamma, gamma};
                     const double X = s_x[lane];
                     const double xo = readlane_f64(X, l);
@@ -458,13 +487,13 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
         const uint64_t seed_out = wseed + (uint64_t)p * gamma;
         const long long n_spec = (long long)sp.n_passes * d - n_fb;                               // coordinates retired by speculative rounds
         const long long spec_draws = (long long)((seed_out - seed_in) * gamma_inv) - fb_draws;
-        steps_sum += spec_draws - 2 * n_spec; steps_n += (int)(2 * n_spec); acc_sum += (int)n_spec; acc_n += (int)n_spec;
+        steps_sum += spec_draws - ex_total - 2 * n_spec; steps_n += (int)(2 * n_spec); acc_sum += (int)n_spec; acc_n += (int)n_spec;
         e.suff[slot] = S;
         e.rng[2 * slot] = seed_out;
         e.expl_steps_sum[cl] += (double)steps_sum; e.expl_steps_n[cl] += steps_n;
         e.expl_acc_sum[cl] += (double)acc_sum;     e.expl_acc_n[cl] += acc_n;
 #ifdef PTE_PROFILE_SECTIONS
-        for (int i = 0; i < 8; ++i) e.on_m2[8 * cl + i] += (double)prof[i];   // debug builds only (needs d >= 8K)
+        for (int i = 0; i < 16; ++i) e.on_m2[16 * cl + i] += (double)prof[i];   // debug builds only (needs d >= 16K)
 #endif
     }
     record_after_explore(e, cl, c, slot, lane, lp_before, S, 0.0);

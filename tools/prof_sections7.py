@@ -11,18 +11,21 @@ from pigeons_amd import _lib
 _lib.LIB_PATH = lib
 import numpy as np
 import pigeons_amd as P
-N, d = 128, 1024
+N, d = (64 if os.environ.get('S_IMPL') == '8' else 128), 1024
 pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=10, explorer=P.SliceSampler(), show_report=False,
                    record=[P.online, P.log_sum_ratio]))
 scans = 8
 pt.replicas.run_scans(1, scans)
 pt.replicas.reduce()
 m, v, n = pt.replicas.online()
-cnt = (v * (n - 1)).reshape(-1)[:8 * N].reshape(N, 8) / scans
+W_ = 16 if os.environ.get('S_IMPL') == '8' else 8
+cnt = (v * (n - 1)).reshape(-1)[:W_ * N].reshape(N, W_) / scans
 names = ["head_dbl", "shrink", "accept", "rounds", "coords_spec", "chase", "fallbacks", "fallback_cyc"]
-for ch in (1, 8, 16, 32, 48, 64, 80, 96, 112, 127):
+for ch in ((1, 16, 32, 48, 63) if N == 64 else (1, 32, 64, 127)):
     c = cnt[ch]
     tot = c[0] + c[1] + c[2] + c[5] + c[7]
     print("chain %3d: total %.2fM | " % (ch, tot / 1e6) + "  ".join("%s %.0f" % (nm, x) for nm, x in zip(names, c)))
     print("   per round: head+doubling %.0f  shrink %.0f  accept %.0f  chase %.0f cyc; coords/round %.2f; fallbacks %.0f at %.0f cyc each"
           % (c[0] / c[3], c[1] / c[3], c[2] / c[3], c[5] / c[3], c[4] / c[3], c[6], c[7] / max(c[6], 1)))
+    if W_ == 16:
+        print("   lane-0 failures by cause: E slow path %.1f, no proposal inside within the caps %.1f, acceptance check / other %.1f, sliver %.1f, (ends inside after doubling %.1f)" % tuple(c[8:13]))
