@@ -160,7 +160,9 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                 }
                 const int ex = (lane == 0) ? ex0 : 0;
                 const double u0 = s_u[idx0 + 1];
-                double Vn = s_u[idx0 + 2];                   // next unread draw of this hypothesis
+                double Vd[S8_BD];                             // the draws of the budgeted doubling steps, loaded with the head's
+#pragma unroll
+                for (int it = 0; it < S8_BD; ++it) Vd[it] = s_u[idx0 + 2 + it];
                 const double Q = xold * xold - E * inv_nhp;
                 const double Bq = Sest + fabs(Q);
                 double dmin = INFINITY;
@@ -177,9 +179,8 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
 #pragma unroll
                 for (int it = 0; it < S8_BD; ++it) {
                     const bool need = (fmin(dL, dR) < 0.0) && it < sp.p;
-                    const double V = Vn;
+                    const double V = Vd[it];                  // (a step is needed only if every earlier one was: draw #it)
                     kd += need ? 1 : 0;
-                    Vn = s_u[idx0 + 2 + kd];                 // the draw after this step (first shrinkage draw at the end)
                     const bool left = V <= 0.5;
                     const double wd = RR - LL;
                     const double cand = left ? (LL - wd) : (RR + wd);
@@ -195,9 +196,8 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                 if (__builtin_expect(ballot64(lane == 0 && (fmin(dL, dR) < 0.0) && kd < kcap) != 0ull, 0)) {
                     bool need = (lane == 0);
                     while (need) {
-                        const double V = Vn;
+                        const double V = s_u[idx0 + 2 + kd];
                         kd += 1;
-                        Vn = s_u[idx0 + 2 + kd];
                         const bool left = V <= 0.5;
                         const double wd = RR - LL;
                         const double cand = left ? (LL - wd) : (RR + wd);
@@ -214,16 +214,15 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                 const bool doubled = (RR - LL) > w11;
                 const double thr2 = 1e-6 * fmax(fabs(LL), fabs(RR));
 #ifdef PTE_PROFILE_SECTIONS
-                asm volatile("" :: "v"(LL), "v"(RR), "v"(kd), "v"(thr2), "v"(Vn));
+                asm volatile("" :: "v"(LL), "v"(RR), "v"(kd), "v"(thr2));
 #endif
                 PROF_T(t1); PROF_ADD(0, t1 - t0);
                 // ---- shrinkage (:141-190) up to the first proposal inside the slice: S8_BS predicated steps,
                 //      their draws loaded up front (consecutive stream positions of this hypothesis)
                 const double *us = &s_u[idx0 + 2 + kd];
                 double u[S8_BS];
-                u[0] = Vn;
 #pragma unroll
-                for (int k = 1; k < S8_BS; ++k) u[k] = us[k];
+                for (int k = 0; k < S8_BS; ++k) u[k] = us[k];
                 double Lbar = LL, Rbar = RR, xf = xold, W = 0.0;
                 int n = 0;
                 bool fin = false;
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                     // its result, step count and bracket -- no per-step selects, no mask arithmetic, no branches.  Fixed
                     // registers because the 64-bit selects address register halves.  (>= 2 instructions between a VALU
                     // write of VCC and its use as a lane mask; EXEC restored before the block ends.)
-                    double t_ = 0.0;
+                    double t_;
                     uint64_t fin_mask, exec_save;
 #define PTE_S8_STEP(U) \
                     "v_add_f64 v[216:217], v[202:203], -v[200:201]\n" \
@@ -254,8 +253,8 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                                  "s_andn2_b64 %[fin], %[sv], exec\n"
                                  "s_mov_b64 exec, %[sv]\n"
                                  "s_nop 3\n"
-                                 : "+{v[200:201]}"(Lbar), "+{v[202:203]}"(Rbar), "+{v[204:205]}"(xf), "+{v[206:207]}"(t_),
-                                   "+{v[208:209]}"(dmin), "+{v210}"(n), "+{v[216:217]}"(W), [fin] "=&s"(fin_mask), [sv] "=&s"(exec_save)
+                                 : "+{v[200:201]}"(Lbar), "+{v[202:203]}"(Rbar), "=&{v[204:205]}"(xf), "=&{v[206:207]}"(t_),
+                                   "+{v[208:209]}"(dmin), "+{v210}"(n), "=&{v[216:217]}"(W), [fin] "=&s"(fin_mask), [sv] "=&s"(exec_save)
                                  : "{v[212:213]}"(xold), "{v[214:215]}"(Q), [u0] "v"(u[0]), [u1] "v"(u[1]), [u2] "v"(u[2]), [u3] "v"(u[3]),
                                    [u4] "v"(u[4]), [u5] "v"(u[5]), [u6] "v"(u[6]), [u7] "v"(u[7])
                                  : "vcc");
@@ -343,16 +342,21 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                     valid = valid && (!chk || (ok && !unfinished));
                 }
 #ifdef PTE_PROFILE_SECTIONS
-                {   // why the certain hypothesis (lane 0) fails, when it does
+                {   // why the true path ends where it ends (slots 8..15: all 5 levels done, then the causes)
                     const bool mg = dmin > 2e-12 * Bq;
-                    const uint64_t v0 = ballot64(valid && mg) & 1ull;
-                    if (!v0) {
-                        PROF_ADD(8, (int)(ballot64(E != E) & 1ull));
-                        PROF_ADD(9, (int)(ballot64(!fin) & 1ull));
-                        PROF_ADD(10, (int)(ballot64(!(E != E) && fin && !valid) & 1ull));   // acceptance check said no / unfinished / other
-                        PROF_ADD(11, (int)(ballot64(valid && !mg) & 1ull));
-                        PROF_ADD(12, (int)(ballot64(!(fmin(dL, dR) < 0.0) ? false : true) & 1ull));
+                    const int rc = !active ? 7 : (E != E) ? 1 : !dbl_ok ? 2 : !fin ? 3 : !valid ? 4 : !mg ? 5 : 0;
+                    const int cnt_ = 2 + kd + n + ex;
+                    int o_ = 0, g_ = 0, why = 0;
+                    for (g_ = 0; g_ < G; ++g_) {
+                        if (l + g_ >= nl) { why = 7; break; }
+                        const int k_ = o_ - LO[g_];
+                        if ((unsigned)k_ >= (unsigned)WD[g_]) { why = 6; break; }
+                        const int ln_ = BASE[g_] + k_;
+                        const int r_ = __builtin_amdgcn_readlane(rc, ln_);
+                        if (r_) { why = r_; break; }
+                        o_ += __builtin_amdgcn_readlane(cnt_, ln_);
                     }
+                    PROF_ADD(8 + why, 1);
                 }
 #endif
                 valid = valid && (dmin > 2e-12 * Bq);

@@ -28,4 +28,4 @@ for ch in ((1, 16, 32, 48, 63) if N == 64 else (1, 32, 64, 127)):
     print("   per round: head+doubling %.0f  shrink %.0f  accept %.0f  chase %.0f cyc; coords/round %.2f; fallbacks %.0f at %.0f cyc each"
           % (c[0] / c[3], c[1] / c[3], c[2] / c[3], c[5] / c[3], c[4] / c[3], c[6], c[7] / max(c[6], 1)))
     if W_ == 16:
-        print("   lane-0 failures by cause: E slow path %.1f, no proposal inside within the caps %.1f, acceptance check / other %.1f, sliver %.1f, (ends inside after doubling %.1f)" % tuple(c[8:13]))
+        print("   rounds ending: all 5 levels %.0f | slow-path E %.0f, doubling over budget / ends inside %.0f, no proposal inside within the budget %.0f, acceptance check %.0f, sliver %.0f, successor outside its window %.0f, end of block %.0f" % tuple(c[8:16]))
