@@ -234,28 +234,28 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                     double t_;
                     uint64_t fin_mask, exec_save;
 #define PTE_S8_STEP(U) \
-                    "v_add_f64 v[216:217], v[202:203], -v[200:201]\n" \
-                    "v_mul_f64 v[206:207], " U ", v[216:217]\n" \
-                    "v_add_f64 v[204:205], v[200:201], v[206:207]\n" \
-                    "v_cmp_lt_f64 vcc, v[204:205], v[212:213]\n" \
-                    "v_mul_f64 v[206:207], v[204:205], v[204:205]\n" \
-                    "v_add_u32 v210, 1, v210\n" \
-                    "v_add_f64 v[206:207], v[206:207], -v[214:215]\n" \
-                    "v_cndmask_b32 v200, v200, v204, vcc\n" \
-                    "v_cndmask_b32 v201, v201, v205, vcc\n" \
-                    "v_cndmask_b32 v202, v204, v202, vcc\n" \
-                    "v_cndmask_b32 v203, v205, v203, vcc\n" \
-                    "v_min_f64 v[208:209], v[208:209], |v[206:207]|\n" \
-                    "v_cmpx_ngt_f64 vcc, 0, v[206:207]\n"
+                    "v_add_f64 v[112:113], v[98:99], -v[96:97]\n" \
+                    "v_mul_f64 v[102:103], " U ", v[112:113]\n" \
+                    "v_add_f64 v[100:101], v[96:97], v[102:103]\n" \
+                    "v_cmp_lt_f64 vcc, v[100:101], v[108:109]\n" \
+                    "v_mul_f64 v[102:103], v[100:101], v[100:101]\n" \
+                    "v_add_u32 v106, 1, v106\n" \
+                    "v_add_f64 v[102:103], v[102:103], -v[110:111]\n" \
+                    "v_cndmask_b32 v96, v96, v100, vcc\n" \
+                    "v_cndmask_b32 v97, v97, v101, vcc\n" \
+                    "v_cndmask_b32 v98, v100, v98, vcc\n" \
+                    "v_cndmask_b32 v99, v101, v99, vcc\n" \
+                    "v_min_f64 v[104:105], v[104:105], |v[102:103]|\n" \
+                    "v_cmpx_ngt_f64 vcc, 0, v[102:103]\n"
                     asm volatile("s_mov_b64 %[sv], exec\n"
                                  PTE_S8_STEP("%[u0]") PTE_S8_STEP("%[u1]") PTE_S8_STEP("%[u2]") PTE_S8_STEP("%[u3]")
                                  PTE_S8_STEP("%[u4]") PTE_S8_STEP("%[u5]") PTE_S8_STEP("%[u6]") PTE_S8_STEP("%[u7]")
                                  "s_andn2_b64 %[fin], %[sv], exec\n"
                                  "s_mov_b64 exec, %[sv]\n"
                                  "s_nop 3\n"
-                                 : "+{v[200:201]}"(Lbar), "+{v[202:203]}"(Rbar), "=&{v[204:205]}"(xf), "=&{v[206:207]}"(t_),
-                                   "+{v[208:209]}"(dmin), "+{v210}"(n), "=&{v[216:217]}"(W), [fin] "=&s"(fin_mask), [sv] "=&s"(exec_save)
-                                 : "{v[212:213]}"(xold), "{v[214:215]}"(Q), [u0] "v"(u[0]), [u1] "v"(u[1]), [u2] "v"(u[2]), [u3] "v"(u[3]),
+                                 : "+{v[96:97]}"(Lbar), "+{v[98:99]}"(Rbar), "=&{v[100:101]}"(xf), "=&{v[102:103]}"(t_),
+                                   "+{v[104:105]}"(dmin), "+{v106}"(n), "=&{v[112:113]}"(W), [fin] "=&s"(fin_mask), [sv] "=&s"(exec_save)
+                                 : "{v[108:109]}"(xold), "{v[110:111]}"(Q), [u0] "v"(u[0]), [u1] "v"(u[1]), [u2] "v"(u[2]), [u3] "v"(u[3]),
                                    [u4] "v"(u[4]), [u5] "v"(u[5]), [u6] "v"(u[6]), [u7] "v"(u[7])
                                  : "vcc");
 #undef PTE_S8_STEP
