@@ -266,6 +266,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingParams ip) {
     extern __shared__ unsigned words[];
+    __shared__ unsigned s_uh[72];            // high words of the 64 buffered uniforms (+ padding read only by dead hypotheses)
     const int lane = lane_id();
     const int64_t cl = blockIdx.x;
     if (cl >= e.K) return;
@@ -318,6 +319,9 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
         const int lc = lidx >> 1;
         const unsigned lb = (unsigned)(lidx & 1);
         double unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma));
+        if (lane < 8) s_uh[64 + lane] = 0u;
+        s_uh[lane] = (unsigned)__double2hiint(unit);
+        __builtin_amdgcn_wave_barrier();
         int p = 0;
         for (int k = 0; k < ip.n_steps; ++k) {
             for (int i = 0; i < L; ++i) {
@@ -331,10 +335,18 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                     const unsigned cur0 = cur;
 #pragma unroll
                     for (int T0 = 0; T0 < 32; T0 += 16) {
-                        if (p + 16 > 64) { seed += (uint64_t)p * gamma; unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma)); p = 0; }
+                        if (p + 16 > 64) {
+                            seed += (uint64_t)p * gamma; unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma)); p = 0;
+                            __builtin_amdgcn_wave_barrier();
+                            s_uh[lane] = (unsigned)__double2hiint(unit);
+                            __builtin_amdgcn_wave_barrier();
+                        }
                         const unsigned rt31 = (W == 1) ? (cur & 1u) : rightbit;
                         // ---- vector pass: every (quad, consumed, left) hypothesis of the chunk walks its four sites
-                        int c_run = lc, accbits = 0;
+                        // (its uniforms are the next <= 4 of the buffer from position p + lc: loaded at once, picked by the count so far)
+                        const unsigned *uhp = &s_uh[p + lc];
+                        const unsigned uh0 = uhp[0], uh1 = uhp[1], uh2 = uhp[2], uh3 = uhp[3];
+                        int dc = 0, accbits = 0;
                         unsigned left = lb;
                         bool amb = false;
 #pragma unroll
@@ -345,58 +357,71 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                             const int nb = 2 * (int)(((up >> t) & 1u) + ((dn >> t) & 1u) + left + rt) - 4;
                             const int delta = (1 - 2 * (int)sg) * 2 * nb;
                             const bool need = delta < 0;
-                            const unsigned uhi = (unsigned)__shfl(__double2hiint(unit), (p + c_run) & 63, 64);
+                            const unsigned uhi = (j == 0 || dc == 0) ? uh0 : (j == 1 || dc == 1) ? uh1 : (j == 2 || dc == 2) ? uh2 : uh3;
                             const unsigned hi_h = delta == -4 ? r4hi_h : r8hi_h, lo_h = delta == -4 ? r4lo_h : r8lo_h;
                             const bool rej = need && (uhi > hi_h);
                             amb = amb || (need && ((!rej && !(uhi < lo_h)) || !filter_ok));
                             left = sg ^ (rej ? 0u : 1u);
                             accbits |= (rej ? 0 : 1) << j;
-                            c_run += need ? 1 : 0;
+                            dc += need ? 1 : 0;
                         }
+                        const int c_run = lc + dc;
                         // packed: bit 0 = ambiguous somewhere in the quad, bits 1-4 = accepts, bits 5.. = NEXT chase state 2 c + spin
                         const int pk = (amb ? 1 : 0) | (accbits << 1) | ((2 * c_run + (int)left) << 5);
                         // ---- chase over the four quads: state s2 = 2 c + b
                         int s2 = (int)b;
+                        // all four quads at once when none of them met a guard-band decision (the common case): no branches
+                        const int q0 = __builtin_amdgcn_readlane(pk, s2);
+                        const int q1 = __builtin_amdgcn_readlane(pk, 2 + (q0 >> 5));
+                        const int q2 = __builtin_amdgcn_readlane(pk, 12 + (q1 >> 5));
+                        const int q3 = __builtin_amdgcn_readlane(pk, 30 + (q2 >> 5));
+                        if (__builtin_expect(((q0 | q1 | q2 | q3) & 1) == 0, 1)) {
+                            const unsigned flips = (unsigned)((q0 >> 1) & 15) | ((unsigned)((q1 >> 1) & 15) << 4)
+                                                 | ((unsigned)((q2 >> 1) & 15) << 8) | ((unsigned)((q3 >> 1) & 15) << 12);
+                            cur ^= flips << T0;
+                            s2 = q3 >> 5;
+                        } else {
 #pragma unroll
-                        for (int kq = 0; kq < 4; ++kq) {
-                            const int q = __builtin_amdgcn_readlane(pk, (kq == 0 ? 0 : kq == 1 ? 2 : kq == 2 ? 12 : 30) + s2);
-                            if (__builtin_expect(q & 1, 0)) {
-                                // a guard-band decision (or a chain whose filter is not valid) inside this quad: its four sites by
-                                // the scalar procedure with the exact arithmetic of the reference where needed
-                                int cc = s2 >> 1;
-                                unsigned bb_ = (unsigned)(s2 & 1);
-                                for (int j = 0; j < 4; ++j) {
-                                    const int tt = T0 + 4 * kq + j;
-                                    const unsigned sgs = (cur >> tt) & 1u;
-                                    const unsigned rts = tt == 31 ? rt31 : ((cur >> (tt + 1)) & 1u);
-                                    const int nbs = 2 * (int)(((up >> tt) & 1u) + ((dn >> tt) & 1u) + bb_ + rts) - 4;
-                                    const int dl = (1 - 2 * (int)sgs) * 2 * nbs;
-                                    int rj = 0, nd = 0;
-                                    if (dl < 0) {
-                                        nd = 1;
-                                        const unsigned uh = (unsigned)__builtin_amdgcn_readlane(__double2hiint(unit), p + cc);
-                                        const unsigned ul = (unsigned)__builtin_amdgcn_readlane(__double2loint(unit), p + cc);
-                                        const unsigned long long ub = ((unsigned long long)uh << 32) | ul;
-                                        const unsigned long long lo = dl == -4 ? r4lo : r8lo, hi = dl == -4 ? r4hi : r8hi;
-                                        if (filter_ok && ub > hi) rj = 1;
-                                        else if (filter_ok && ub < lo) rj = 0;
-                                        else {
-                                            if (lane == 0) words[row + wj] = cur;
-                                            __syncthreads();
-                                            const long long spp = recompute();
-                                            const double ratio = exp(ising_lp(beta, bt, (double)(spp + dl)) - ising_lp(beta, bt, (double)spp));
-                                            if (ratio < 1) rj = (__longlong_as_double((long long)ub) > ratio) ? 1 : 0;
-                                            else { rj = 0; nd = 0; }          // accept_ratio >= 1: the reference draws nothing
+                            for (int kq = 0; kq < 4; ++kq) {
+                                const int q = __builtin_amdgcn_readlane(pk, (kq == 0 ? 0 : kq == 1 ? 2 : kq == 2 ? 12 : 30) + s2);
+                                if (__builtin_expect(q & 1, 0)) {
+                                    // a guard-band decision (or a chain whose filter is not valid) inside this quad: its four sites by
+                                    // the scalar procedure with the exact arithmetic of the reference where needed
+                                    int cc = s2 >> 1;
+                                    unsigned bb_ = (unsigned)(s2 & 1);
+                                    for (int j = 0; j < 4; ++j) {
+                                        const int tt = T0 + 4 * kq + j;
+                                        const unsigned sgs = (cur >> tt) & 1u;
+                                        const unsigned rts = tt == 31 ? rt31 : ((cur >> (tt + 1)) & 1u);
+                                        const int nbs = 2 * (int)(((up >> tt) & 1u) + ((dn >> tt) & 1u) + bb_ + rts) - 4;
+                                        const int dl = (1 - 2 * (int)sgs) * 2 * nbs;
+                                        int rj = 0, nd = 0;
+                                        if (dl < 0) {
+                                            nd = 1;
+                                            const unsigned uh = (unsigned)__builtin_amdgcn_readlane(__double2hiint(unit), p + cc);
+                                            const unsigned ul = (unsigned)__builtin_amdgcn_readlane(__double2loint(unit), p + cc);
+                                            const unsigned long long ub = ((unsigned long long)uh << 32) | ul;
+                                            const unsigned long long lo = dl == -4 ? r4lo : r8lo, hi = dl == -4 ? r4hi : r8hi;
+                                            if (filter_ok && ub > hi) rj = 1;
+                                            else if (filter_ok && ub < lo) rj = 0;
+                                            else {
+                                                if (lane == 0) words[row + wj] = cur;
+                                                __syncthreads();
+                                                const long long spp = recompute();
+                                                const double ratio = exp(ising_lp(beta, bt, (double)(spp + dl)) - ising_lp(beta, bt, (double)spp));
+                                                if (ratio < 1) rj = (__longlong_as_double((long long)ub) > ratio) ? 1 : 0;
+                                                else { rj = 0; nd = 0; }          // accept_ratio >= 1: the reference draws nothing
+                                            }
                                         }
+                                        cur ^= (unsigned)(rj ? 0 : 1) << tt;
+                                        bb_ = (cur >> tt) & 1u;
+                                        cc += nd;
                                     }
-                                    cur ^= (unsigned)(rj ? 0 : 1) << tt;
-                                    bb_ = (cur >> tt) & 1u;
-                                    cc += nd;
+                                    s2 = 2 * cc + (int)bb_;
+                                } else {
+                                    cur ^= (unsigned)((q >> 1) & 15) << (T0 + 4 * kq);
+                                    s2 = q >> 5;
                                 }
-                                s2 = 2 * cc + (int)bb_;
-                            } else {
-                                cur ^= (unsigned)((q >> 1) & 15) << (T0 + 4 * kq);
-                                s2 = q >> 5;
                             }
                         }
                         p += s2 >> 1;

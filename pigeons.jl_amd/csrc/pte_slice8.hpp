@@ -13,12 +13,15 @@
 // which coordinates l+1 .. l+4 can start (their windows cover ~3 sigma of the consumed-draw
 // distribution).  Every lane runs the complete scalar procedure of the reference
 // (SliceSampler.jl:97-237: doubling, shrinkage, acceptance check of the doubling scheme) on its own
-// hypothesis, reading pre-converted draws from a 256-draw LDS window of the stream.  The chase then
-// walks g = 0,1,.. through the lanes that turned out to be true and applies their results.  A
-// hypothesis that meets anything inexact (ambiguous filter outcome, ziggurat slow path, window
-// overflow, too many iterations) is marked invalid; if the chase hits it the coordinate is done by
-// the exact sequential procedure (fixed-tree recompute available), which is also how errors are
-// raised.  So a round retires ~4.5 coordinates for the latency of the slowest of 64 scalar updates.
+// hypothesis, reading pre-converted draws from a 256-draw LDS window of the stream.  Every lane also
+// names the lane that follows it on the true path (its draw count fixes where the next coordinate
+// starts), so the chase is one v_readlane per level, without branches; the true lanes then store
+// their results into the LDS copy of the block.  A hypothesis that meets anything inexact (ambiguous
+// filter outcome, ziggurat slow path, window overflow, a budget) is marked invalid and ends the
+// chase: its coordinate is lane 0 of the next round, where the certain hypothesis alone may run past
+// the budgets and resolves a slow-path exponential exactly; what is still inexact then goes to the
+// exact sequential procedure (fixed-tree recompute available), which is also how errors are raised.
+// A round retires ~3.5 coordinates for ~450 instructions of one wave.
 #pragma once
 #include "pte_slice7.hpp"
 
