@@ -39,7 +39,8 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
     __shared__ unsigned long long s_ke[256];
     __shared__ double s_u[WIN];
     __shared__ double s_e[WIN];              // randexp fast-path value; NaN <=> slow path needed
-    __shared__ double s_x[64];               // the current 64-coordinate block: start-of-pass values, overwritten as coordinates retire
+    constexpr int BLK = 256, CPB = BLK / 64;  // coordinates per block (rounds do not reach across a block end) = CPB 64-leaf chunks of the tree
+    __shared__ double s_x[BLK];              // the current block: start-of-pass values, overwritten as coordinates retire
     const int lane = lane_id();
     for (int i = lane; i < 256; i += 64) { s_we[i] = ZIG_WE[i]; s_ke[i] = ZIG_KE[i]; }
     __syncthreads();
@@ -128,10 +129,11 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
 #endif
 
     for (int pass = 0; pass < sp.n_passes && !err; ++pass) {
-        for (int b = 0; b < B && !err; ++b) {
-            const int64_t base = 64 * (int64_t)b;
-            const int nl = (int)min((int64_t)64, d - base);
-            s_x[lane] = (lane < nl) ? xrow[base + lane] : 0.0;
+        for (int b = 0; BLK * (int64_t)b < d && !err; ++b) {
+            const int64_t base = BLK * (int64_t)b;
+            const int nl = (int)min((int64_t)BLK, d - base);
+#pragma unroll
+            for (int k = 0; k < CPB; ++k) s_x[64 * k + lane] = (64 * k + lane < nl) ? xrow[base + 64 * k + lane] : 0.0;
             __builtin_amdgcn_wave_barrier();
             double Sest = S * (1.0 + 1e-6) + wsum * inv_abs_nhp;       // upper bound on sum x^2 while this window lasts
             int l = 0;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                 // validity state).  NaNs never pass: they fail the final interval-width test.
                 // ---- head: slice level and initial interval (SliceSampler.jl:97-113)
                 const bool active = (l + hg) < nl;
-                const double xold = s_x[(l + hg) & 63];       // not yet updated in this pass
+                const double xold = s_x[(l + hg) & (BLK - 1)];   // not yet updated in this pass
                 int idx0 = p + hrel;
                 double E = s_e[idx0];
                 int ex0 = 0;
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                         cur = (pk >> 8) & 63;
                     }
                     tmask &= vmask;                           // (a path ends AT an invalid lane: its bit was set above)
-                    if (__builtin_amdgcn_inverse_ballot_w64(tmask)) s_x[(l + hg) & 63] = xf;
+                    if (__builtin_amdgcn_inverse_ballot_w64(tmask)) s_x[(l + hg) & (BLK - 1)] = xf;
                     __builtin_amdgcn_wave_barrier();
                     p += o;
                     l += gdone;
@@ -404,18 +406,26 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                     // ================= exact sequential procedure for coordinate l ===================
                     ex_total -= ex0;                              // (its exponential is drawn again below)
                     SeqRng rs{wseed + (uint64_t)p * gamma, gamma};
-                    const double X = s_x[lane];
-                    const double xo = readlane_f64(X, l);
+                    // (the block's chunk sums have not been refreshed since the block started: do it now, for the exact tree)
+                    const int ck = l >> 6, li = l & 63, bc = CPB * b + ck;
+#pragma unroll
+                    for (int k = 0; k < CPB; ++k) {
+                        const double xk = s_x[64 * k + lane];
+                        const double sk = wave_sum_dpp(xk * xk);
+                        if (lane == CPB * b + k) BS = sk;
+                    }
+                    const double X = s_x[64 * ck + lane];
+                    const double xo = readlane_f64(X, li);
                     const double E = randexp_seq(rs);
                     const double u0 = rs.rand();
                     const double Q = xo * xo - E * inv_nhp;
                     const double mg = 1e-12 * (Sest + fabs(Q));
                     const double Qlo = Q - mg, Qhi = Q + mg;
                     auto inside_exact = [&](double v) __attribute__((always_inline)) -> bool {
-                        const double Xv = (lane == l) ? v : X;
+                        const double Xv = (lane == li) ? v : X;
                         const double sv = wave_sum_dpp(Xv * Xv), s0 = wave_sum_dpp(X * X);
-                        const double Sv = upper_tree_root<NLU>((lane == b) ? sv : BS);
-                        const double S0 = upper_tree_root<NLU>((lane == b) ? s0 : BS);
+                        const double Sv = upper_tree_root<NLU>((lane == bc) ? sv : BS);
+                        const double S0 = upper_tree_root<NLU>((lane == bc) ? s0 : BS);
                         const double zz = nhp * S0 - E;
                         return zz < nhp * Sv;
                     };
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                     }
                     if (!fin) { err = ERR_SLICE_MAX_ITER; err_coord = (int)(base + l); break; }
                     Sest = Sest + fabs(xn * xn - xo * xo);
-                    if (lane == l) s_x[l] = xn;
+                    if (lane == li) s_x[l] = xn;
                     __builtin_amdgcn_wave_barrier();
                     l += 1;
                     const int used = (int)((rs.seed - (wseed + (uint64_t)p * gamma)) * gamma_inv);   // draws consumed; window stays
@@ -479,11 +489,14 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                 }
             }
             if (err) break;
-            const double X = s_x[lane];
-            if (lane < nl) xrow[base + lane] = X;
-            {   // re-establish the exact fixed-tree values at the block boundary
-                const double s = wave_sum_dpp(X * X);
-                if (lane == b) BS = s;
+            {   // write the block back and re-establish the exact fixed-tree values at the block boundary
+#pragma unroll
+                for (int k = 0; k < CPB; ++k) {
+                    const double X = s_x[64 * k + lane];
+                    if (64 * k + lane < nl) xrow[base + 64 * k + lane] = X;
+                    const double s = wave_sum_dpp(X * X);
+                    if (lane == CPB * b + k) BS = s;
+                }
                 S = upper_tree_root<NLU>(BS);
                 if (__builtin_expect(!isfinite(nhp * S), 0)) { err = ERR_SLICE_INVALID_LP; err_coord = (int)base; }
             }
