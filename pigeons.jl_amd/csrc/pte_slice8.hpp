@@ -306,25 +306,32 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                 // ---- acceptance check of the doubling scheme (:192-237) for the proposal found; a
                 //      proposal that fails it sends the hypothesis to the exact path
                 const bool chk = valid && doubled;
-                if (ballot64(chk) != 0ull) {
+                {
+                    // Only the doubled hypotheses work here (EXEC-masked region, <= 2 halvings for a budgeted hypothesis);
+                    // the flags leave the region as per-lane integers.
                     double Lhat = LL, Rhat = RR, oL = dL, oR = dR;
-                    bool D = false, ok = true;
-#pragma unroll
-                    for (int it = 0; it < S8_BA; ++it) {
-                        const bool cont = chk && ok && (Rhat - Lhat > w11);
-                        const double Mid = (Lhat + Rhat) * 0.5;
-                        const bool right = xf < Mid;
-                        const double dm = Mid * Mid - Q;
-                        dmin = cont ? fmin(dmin, fabs(dm)) : dmin;
-                        D = D || (cont && ((xold < Mid) != right));
-                        const bool cr = cont && right, cl_ = cont && !right;
-                        Rhat = cr ? Mid : Rhat;
-                        Lhat = cl_ ? Mid : Lhat;
-                        oR = cr ? dm : oR;
-                        oL = cl_ ? dm : oL;
-                        ok = ok && !(cont && D && !(oL < 0.0) && !(oR < 0.0));
+                    int Di = 0, oki = 1, unf = 0;
+                    if (chk) {
+                        auto halve = [&]() __attribute__((always_inline)) {
+                            const double Mid = (Lhat + Rhat) * 0.5;
+                            const bool right = xf < Mid;
+                            const double dm = test(Mid);
+                            Di |= ((xold < Mid) != right) ? 1 : 0;
+                            Rhat = right ? Mid : Rhat;
+                            Lhat = right ? Lhat : Mid;
+                            oR = right ? dm : oR;
+                            oL = right ? oL : dm;
+                            oki = (Di && !(oL < 0.0) && !(oR < 0.0)) ? 0 : 1;
+                        };
+                        halve();
+                        if (oki && (Rhat - Lhat > w11)) {
+                            halve();
+                            unf = (oki && (Rhat - Lhat > w11)) ? 1 : 0;
+                        }
                     }
-                    bool unfinished = chk && ok && (Rhat - Lhat > w11);
+                    asm volatile("" : "+v"(Di), "+v"(oki), "+v"(unf));
+                    bool D = Di != 0, ok = oki != 0;
+                    bool unfinished = unf != 0;
                     if (__builtin_expect(ballot64(lane == 0 && unfinished) != 0ull, 0)) {
                         bool go = (lane == 0);
                         while (go) {
@@ -339,9 +346,9 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                             ok = !(D && !(oL < 0.0) && !(oR < 0.0));
                             go = ok && (Rhat - Lhat > w11);
                         }
-                        int oki = ok ? 1 : 0;
-                        asm volatile("" : "+v"(oki));
-                        ok = oki != 0;
+                        int oki2 = ok ? 1 : 0;
+                        asm volatile("" : "+v"(oki2));
+                        ok = oki2 != 0;
                         unfinished = unfinished && lane != 0;
                     }
                     valid = valid && (!chk || (ok && !unfinished));
