@@ -132,6 +132,9 @@ def test_config1_quickstart_slice(P):
     (2, 33, 5, 5),        # only reference + target
     (1, 8, 4, 1),         # single chain: no reference, no swaps
     (9, 300, 3, 4),
+    (5, 256, 3, 6),       # exactly one 256-coordinate block of the default kernel
+    (4, 257, 3, 8),       # ... and one coordinate more
+    (3, 4096, 2, 2),      # BASELINE configs[3] dimension: 16 blocks, the deepest reduction tree
 ])
 def test_slice_sampler_parity(P, N, d, rounds, seed):
     pt, ref = _mk(P, N, d, rounds, "slice", seed=seed)
