@@ -216,6 +216,15 @@ class OraclePT:
     def round(self):
         return int(self.L.po_round(self.h))
 
+    def set_states(self, x=None, chain=None, rng=None):
+        xa = None if x is None else np.ascontiguousarray(x, dtype=np.float64)
+        ca = None if chain is None else np.ascontiguousarray(chain, dtype=np.int64)
+        ra = None if rng is None else np.ascontiguousarray(rng, dtype=np.uint64)
+        self.L.po_set_states.restype = None
+        self.L.po_set_states.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.L.po_set_states(self.h, None if xa is None else xa.ctypes.data, None if ca is None else ca.ctypes.data,
+                             None if ra is None else ra.ctypes.data)
+
     def states(self):
         x = np.zeros((self.N, max(self.d, 1)))
         chain = np.zeros(self.N, dtype=np.int64)
@@ -412,15 +421,6 @@ class OracleShard(OraclePT):
         rep = np.zeros((4096, self.K), dtype=np.int64); ch = np.zeros((4096, self.K), dtype=np.int64)
         n = int(self.L.po_shard_index_process(self.h, _ip(rep), _ip(ch)))
         return rep[:n].copy(), ch[:n].copy()
-
-    def set_states(self, x=None, chain=None, rng=None):
-        xa = None if x is None else np.ascontiguousarray(x, dtype=np.float64)
-        ca = None if chain is None else np.ascontiguousarray(chain, dtype=np.int64)
-        ra = None if rng is None else np.ascontiguousarray(rng, dtype=np.uint64)
-        self.L.po_set_states.restype = None
-        self.L.po_set_states.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        self.L.po_set_states(self.h, None if xa is None else xa.ctypes.data, None if ca is None else ca.ctypes.data,
-                             None if ra is None else ra.ctypes.data)
 
     def replica_ids(self):
         out = np.zeros(self.K, dtype=np.int64)

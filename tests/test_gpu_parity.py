@@ -855,6 +855,22 @@ def test_slice_parameters_off_the_defaults(P, monkeypatch, impl):
             _check_round(P, pt, ref)
 
 
+def test_slice_special_states(P):
+    """States a user can hand in through pte_set_state: all zeros (sum x^2 = 0, the margin of the filtered predicate has
+    nothing to scale with), negative zeros, squares that underflow, large magnitudes -- same chain of decisions as the oracle."""
+    N, d, rounds = 5, 70, 4
+    pt, ref = _mk(P, N, d, rounds, "slice", seed=3)
+    x = np.zeros((N, d))
+    x[1] = -0.0
+    x[2] = 1e-170 * np.arange(1, d + 1)
+    x[3] = 1e3 * np.cos(np.arange(d))
+    x[4, ::2] = 5e-324                              # denormals between zeros
+    pt.replicas.set_states(x=x)
+    ref.set_states(x=x)
+    for _ in range(rounds):
+        _check_round(P, pt, ref)
+
+
 def test_slice_max_iter_error_is_raised_by_every_kernel(P, monkeypatch):
     """slice_shrink!'s "Maximum number of iterations reached" (SliceSampler.jl:179-185) with max_iter below the speculation depth."""
     for impl in ["1", "8"]:
