@@ -89,8 +89,11 @@ __device__ __forceinline__ double upper_tree_root_dyn(double bs, int nlu) {
 // ---- DPP wave reduction with the association of the fixed tree; result uniform -----------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add_step(double v) {
-    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
-    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    // Full-mask permutations have a source for every lane: bound_ctrl tells the compiler that no lane keeps the `old`
+    // operand, which saves initialising it.  The row-broadcast steps leave whole rows untouched: those must read +0.0.
+    constexpr bool full = (ROW_MASK == 0xF);
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, full);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, full);
     return v + __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_sum_dpp(double v) {
