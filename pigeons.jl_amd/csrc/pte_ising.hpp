@@ -417,7 +417,9 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                                         bb_ = (cur >> tt) & 1u;
                                         cc += nd;
                                     }
-                                    s2 = 2 * cc + (int)bb_;
+                                    // (every lane computed the same values; tell the compiler, so that the chunk loop stays scalar)
+                                    s2 = __builtin_amdgcn_readfirstlane(2 * cc + (int)bb_);
+                                    cur = (unsigned)__builtin_amdgcn_readfirstlane((int)cur);
                                 } else {
                                     cur ^= (unsigned)((q >> 1) & 15) << (T0 + 4 * kq);
                                     s2 = q >> 5;
