@@ -30,7 +30,7 @@ namespace pte {
 // Straight-line variant of k_explore_slice7: the budgeted part of every stage is fully unrolled and
 // predicated (no exec-mask loops, no taken branches: a lone wave pays ~35 cycles of refetch per taken
 // branch); only the certain hypothesis (lane 0) can continue beyond the budgets, in rarely entered loops.
-constexpr int S8_BD = 2, S8_BA = 2;      // doubling / acceptance-check budgets; the shrinkage budget S8_BS is a template parameter
+constexpr int S8_BD = 2;                 // doubling budget of a speculative hypothesis (=> its acceptance check has <= 2 halvings); the shrinkage budget S8_BS is a template parameter
 
 template <int NLU, int S8_BS>
 __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams sp) {
