@@ -19,8 +19,9 @@ def run(impl, N, d, seed, rounds, w, p):
 bad = 0; n = 0
 shapes = [(64, 300), (33, 64), (16, 1000), (128, 129), (8, 4096), (50, 7)]
 params = [(10.0, 20), (1.0, 20), (0.2, 4), (100.0, 20)]
-for (N, d), (w, p), seed in itertools.product(shapes, params, range(1, 7)):
-    rounds = 4 if d >= 1000 else 5
+seed0 = int(os.environ.get("STRESS_SEED0", "1")); nseeds = int(os.environ.get("STRESS_NSEEDS", "6")); extra = int(os.environ.get("STRESS_EXTRA_ROUNDS", "0"))
+for (N, d), (w, p), seed in itertools.product(shapes, params, range(seed0, seed0 + nseeds)):
+    rounds = (4 if d >= 1000 else 5) + extra
     a, sa = run("1", N, d, seed, rounds, w, p)
     b, sb = run(os.environ.get("STRESS_IMPL", "8"), N, d, seed, rounds, w, p)
     ok = all(np.array_equal(x, y) for ra, rb in zip(a, b) for x, y in zip(ra, rb)) and all(np.array_equal(x, y) for x, y in zip(sa, sb))
