@@ -67,9 +67,11 @@ struct pte_engine {
     Snapshot snap;
     std::string err;
     // timing
-    bool timing = false;
+    int timing = 0;                  // 0 off, 1 every kernel, 2 explore kernels only
+    bool ev_open = false;
     struct Ev { hipEvent_t a, b; int kernel; };
     std::vector<Ev> events;
+    std::vector<hipEvent_t> ev_pool;
     double t_ms[2] = {0, 0};
     int64_t t_n[2] = {0, 0};
 };
@@ -194,16 +196,23 @@ int check_device_error(pte_engine *h) {
     }
 }
 
+// h->timing: 0 off, 1 every kernel, 2 the explore kernels only (an event pair costs ~10 us of stream time per launch)
 void time_begin(pte_engine *h, int kernel) {
-    if (!h->timing) return;
+    h->ev_open = false;
+    if (!h->timing || (h->timing == 2 && kernel != 0)) return;
     pte_engine::Ev ev; ev.kernel = kernel;
-    hipEventCreate(&ev.a); hipEventCreate(&ev.b);
+    if (h->ev_pool.size() >= 2) {
+        ev.a = h->ev_pool.back(); h->ev_pool.pop_back();
+        ev.b = h->ev_pool.back(); h->ev_pool.pop_back();
+    } else { hipEventCreate(&ev.a); hipEventCreate(&ev.b); }
     hipEventRecord(ev.a, h->stream);
     h->events.push_back(ev);
+    h->ev_open = true;
 }
 void time_end(pte_engine *h) {
-    if (!h->timing) return;
+    if (!h->ev_open) return;
     hipEventRecord(h->events.back().b, h->stream);
+    h->ev_open = false;
 }
 void time_collect(pte_engine *h) {
     for (auto &ev : h->events) {
@@ -211,7 +220,7 @@ void time_collect(pte_engine *h) {
         hipEventSynchronize(ev.b);
         hipEventElapsedTime(&ms, ev.a, ev.b);
         h->t_ms[ev.kernel] += ms; h->t_n[ev.kernel] += 1;
-        hipEventDestroy(ev.a); hipEventDestroy(ev.b);
+        h->ev_pool.push_back(ev.a); h->ev_pool.push_back(ev.b);
     }
     h->events.clear();
 }
@@ -551,6 +560,7 @@ int pte_destroy(pte_engine *h) {
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     time_collect(h);
+    for (hipEvent_t ev : h->ev_pool) hipEventDestroy(ev);
     for (void *p : h->allocs) hipFree(p);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -1045,7 +1055,7 @@ int pte_timing_reset(pte_engine *h, int enable) {
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
     time_collect(h);
-    h->timing = enable != 0;
+    h->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     h->t_ms[0] = h->t_ms[1] = 0.0; h->t_n[0] = h->t_n[1] = 0;
     return 0;
 }

@@ -240,7 +240,8 @@ class Engine:
 
     # --- measurement
     def timing_reset(self, enable=True):
-        self._chk(self.L.pte_timing_reset(self.h, 1 if enable else 0))
+        """enable: False / True (every kernel) / 2 (explore kernels only)."""
+        self._chk(self.L.pte_timing_reset(self.h, 2 if enable == 2 and enable is not True else (1 if enable else 0)))
 
     def timing(self, kernel):
         ms = np.zeros(1); n = np.zeros(1, dtype=np.int64)
