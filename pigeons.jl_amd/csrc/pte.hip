@@ -262,8 +262,8 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
             if (const char *t = std::getenv("PTE_S7_BUDGETS")) std::sscanf(t, "%d,%d,%d", &tn.bud_d, &tn.bud_s, &tn.bud_a);
             DISPATCH_NLU(h->nlu, k_explore_slice7, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, tn);
         } else if (h->slice_impl == 8) {
-            // 8 shrinkage steps for every hypothesis: measured optimum (6: 1.86, 7: 1.77, 8: 1.71, 10: 1.72 ms/scan)
-            DISPATCH_NLU_M(h->nlu, k_explore_slice8, 8, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
+            // shrinkage steps for every hypothesis: PTE_S8_BS = 9, re-measured after every change of the round's cost (tools/bench_variant.py)
+            DISPATCH_NLU_M(h->nlu, k_explore_slice8, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_impl == 5 && h->slice_m == 3) {
             DISPATCH_NLU_M(h->nlu, k_explore_slice5, 3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_impl == 5 && h->slice_m == 6) {

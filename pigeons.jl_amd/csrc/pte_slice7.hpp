@@ -9,11 +9,11 @@
 // BEFORE o_c is known.
 //
 // One round handles G = 5 consecutive coordinates with the 64 lanes as hypotheses (g, o):
-// lane 0 is coordinate l at the known position; 12 / 14 / 17 / 20 lanes cover the positions at
+// lane 0 is coordinate l at the known position; 14 / 16 / 17 / 16 lanes cover the positions at
 // which coordinates l+1 .. l+4 can start (their windows cover ~3 sigma of the consumed-draw
 // distribution).  Every lane runs the complete scalar procedure of the reference
 // (SliceSampler.jl:97-237: doubling, shrinkage, acceptance check of the doubling scheme) on its own
-// hypothesis, reading pre-converted draws from a 256-draw LDS window of the stream.  The chase then
+// hypothesis, reading pre-converted draws from a 512-draw LDS window of the stream.  The chase then
 // walks g = 0,1,.. through the lanes that turned out to be true and applies their results.  A
 // hypothesis that meets anything inexact (ambiguous filter outcome, ziggurat slow path, window
 // overflow, too many iterations) is marked invalid; if the chase hits it the coordinate is done by
@@ -26,12 +26,23 @@ namespace pte {
 
 namespace s7 {
 constexpr int G = 5;
-constexpr int WIN = 256;                 // draws in the LDS window
-constexpr int REFILL_AT = WIN - 100;     // hypotheses start <= p + 33; leave >= 60 draws to each
+#ifndef PTE_S7_WIN
+#define PTE_S7_WIN 512
+#endif
+constexpr int WIN = PTE_S7_WIN;          // draws in the LDS window (a multiple of 64)
+#ifndef PTE_S7_MARGIN
+#define PTE_S7_MARGIN 80
+#endif
+constexpr int REFILL_AT = WIN - PTE_S7_MARGIN;   // hypotheses start <= p + 29 and read <= 46 draws (lane 0: <= 62): 76 would do
 constexpr int CAP_ITERS = 24;            // speculative shrinkage cap (beyond: exact path)
-__device__ constexpr int LO[G] = {0, 3, 6, 10, 14};
-__device__ constexpr int WD[G] = {1, 12, 14, 17, 20};
-__device__ constexpr int BASE[G] = {0, 1, 13, 27, 44};
+#ifndef PTE_S7_TABLES                     // (a tuning build can substitute its own window layout: LO, WD, BASE initialisers)
+#define PTE_S7_TABLES {0, 3, 6, 10, 14}, {1, 14, 16, 17, 16}, {0, 1, 15, 31, 48}
+#endif
+struct S7Tables { int lo[G], wd[G], base[G]; };
+constexpr S7Tables S7T = {PTE_S7_TABLES};
+__device__ constexpr int LO[G] = {S7T.lo[0], S7T.lo[1], S7T.lo[2], S7T.lo[3], S7T.lo[4]};
+__device__ constexpr int WD[G] = {S7T.wd[0], S7T.wd[1], S7T.wd[2], S7T.wd[3], S7T.wd[4]};
+__device__ constexpr int BASE[G] = {S7T.base[0], S7T.base[1], S7T.base[2], S7T.base[3], S7T.base[4]};
 constexpr int VALID = 1 << 30;
 }  // namespace s7
 

@@ -9,11 +9,11 @@
 // BEFORE o_c is known.
 //
 // One round handles G = 5 consecutive coordinates with the 64 lanes as hypotheses (g, o):
-// lane 0 is coordinate l at the known position; 12 / 14 / 17 / 20 lanes cover the positions at
+// lane 0 is coordinate l at the known position; 14 / 16 / 17 / 16 lanes cover the positions at
 // which coordinates l+1 .. l+4 can start (their windows cover ~3 sigma of the consumed-draw
 // distribution).  Every lane runs the complete scalar procedure of the reference
 // (SliceSampler.jl:97-237: doubling, shrinkage, acceptance check of the doubling scheme) on its own
-// hypothesis, reading pre-converted draws from a 256-draw LDS window of the stream.  Every lane also
+// hypothesis, reading pre-converted draws from a 512-draw LDS window of the stream.  Every lane also
 // names the lane that follows it on the true path (its draw count fixes where the next coordinate
 // starts), so the chase is one v_readlane per level, without branches; the true lanes then store
 // their results into the LDS copy of the block.  A hypothesis that meets anything inexact (ambiguous
@@ -30,7 +30,13 @@ namespace pte {
 // Straight-line variant of k_explore_slice7: the budgeted part of every stage is fully unrolled and
 // predicated (no exec-mask loops, no taken branches: a lone wave pays ~35 cycles of refetch per taken
 // branch); only the certain hypothesis (lane 0) can continue beyond the budgets, in rarely entered loops.
-constexpr int S8_BD = 2;                 // doubling budget of a speculative hypothesis (=> its acceptance check has <= 2 halvings); the shrinkage budget S8_BS is a template parameter
+#ifndef PTE_S8_BD
+#define PTE_S8_BD 2
+#endif
+#ifndef PTE_S8_BS                        // shrinkage budget instantiated by pte.hip (6..10; tuning builds override it)
+#define PTE_S8_BS 9
+#endif
+constexpr int S8_BD = PTE_S8_BD;                 // doubling budget of a speculative hypothesis (=> its acceptance check has <= 2 halvings); the shrinkage budget S8_BS is a template parameter
 
 template <int NLU, int S8_BS>
 __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams sp) {
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                 double Lbar = LL, Rbar = RR, xf = xold, W = 0.0;
                 int n = 0;
                 bool fin = false;
-                if constexpr (S8_BS == 8) {
+                if constexpr (S8_BS == PTE_S8_BS && S8_BS >= 6 && S8_BS <= 10) {
                     // Hand-scheduled: a lane whose proposal lands inside the slice drops out of EXEC (v_cmpx), which freezes
                     // its result, step count and bracket -- no per-step selects, no mask arithmetic, no branches.  Fixed
                     // registers because the 64-bit selects address register halves.  (>= 2 instructions between a VALU
@@ -254,14 +260,27 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
                     "v_cmpx_ngt_f64 vcc, 0, v[102:103]\n"
                     asm volatile("s_mov_b64 %[sv], exec\n"
                                  PTE_S8_STEP("%[u0]") PTE_S8_STEP("%[u1]") PTE_S8_STEP("%[u2]") PTE_S8_STEP("%[u3]")
-                                 PTE_S8_STEP("%[u4]") PTE_S8_STEP("%[u5]") PTE_S8_STEP("%[u6]") PTE_S8_STEP("%[u7]")
+                                 PTE_S8_STEP("%[u4]") PTE_S8_STEP("%[u5]")
+#if PTE_S8_BS >= 7
+                                 PTE_S8_STEP("%[u6]")
+#endif
+#if PTE_S8_BS >= 8
+                                 PTE_S8_STEP("%[u7]")
+#endif
+#if PTE_S8_BS >= 9
+                                 PTE_S8_STEP("%[u8]")
+#endif
+#if PTE_S8_BS >= 10
+                                 PTE_S8_STEP("%[u9]")
+#endif
                                  "s_andn2_b64 %[fin], %[sv], exec\n"
                                  "s_mov_b64 exec, %[sv]\n"
                                  "s_nop 3\n"
                                  : "+{v[96:97]}"(Lbar), "+{v[98:99]}"(Rbar), "=&{v[100:101]}"(xf), "=&{v[102:103]}"(t_),
                                    "+{v[104:105]}"(dmin), "+{v106}"(n), "=&{v[112:113]}"(W), [fin] "=&s"(fin_mask), [sv] "=&s"(exec_save)
                                  : "{v[108:109]}"(xold), "{v[110:111]}"(Q), [u0] "v"(u[0]), [u1] "v"(u[1]), [u2] "v"(u[2]), [u3] "v"(u[3]),
-                                   [u4] "v"(u[4]), [u5] "v"(u[5]), [u6] "v"(u[6]), [u7] "v"(u[7])
+                                   [u4] "v"(u[4]), [u5] "v"(u[5]), [u6] "v"(u[S8_BS > 6 ? 6 : 0]), [u7] "v"(u[S8_BS > 7 ? 7 : 0]),
+                                   [u8] "v"(u[S8_BS > 8 ? 8 : 0]), [u9] "v"(u[S8_BS > 9 ? 9 : 0])
                                  : "vcc");
 #undef PTE_S8_STEP
                     fin = __builtin_amdgcn_inverse_ballot_w64(fin_mask);

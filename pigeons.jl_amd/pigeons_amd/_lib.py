@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)                       # .../pigeons.jl_amd
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libpte.so")
+LIB_PATH = os.environ.get("PTE_LIB") or os.path.join(PKG_ROOT, "lib", "libpte.so")   # PTE_LIB: a tuning build (tools/)
 
 TARGET_MVN_SCALED_PRECISION, TARGET_TEST_SWAPPER, TARGET_FUNNEL, TARGET_ISING = 0, 1, 2, 3
 EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA, EXPLORER_ISING_METROPOLIS, EXPLORER_MALA = 0, 1, 2, 3, 4, 5
