@@ -45,7 +45,10 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
     __shared__ unsigned long long s_ke[256];
     __shared__ double s_u[WIN];
     __shared__ double s_e[WIN];              // randexp fast-path value; NaN <=> slow path needed
-    constexpr int BLK = 256, CPB = BLK / 64;  // coordinates per block (rounds do not reach across a block end) = CPB 64-leaf chunks of the tree
+#ifndef PTE_S8_BLK
+#define PTE_S8_BLK 256
+#endif
+    constexpr int BLK = PTE_S8_BLK, CPB = BLK / 64;  // coordinates per block (rounds do not reach across a block end) = CPB 64-leaf chunks of the tree
     __shared__ double s_x[BLK];              // the current block: start-of-pass values, overwritten as coordinates retire
     const int lane = lane_id();
     for (int i = lane; i < 256; i += 64) { s_we[i] = ZIG_WE[i]; s_ke[i] = ZIG_KE[i]; }
