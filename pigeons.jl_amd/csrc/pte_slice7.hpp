@@ -25,7 +25,10 @@
 namespace pte {
 
 namespace s7 {
-constexpr int G = 5;
+#ifndef PTE_S7_G
+#define PTE_S7_G 5
+#endif
+constexpr int G = PTE_S7_G;              // coordinates (levels) per round
 #ifndef PTE_S7_WIN
 #define PTE_S7_WIN 512
 #endif
@@ -40,9 +43,15 @@ constexpr int CAP_ITERS = 24;            // speculative shrinkage cap (beyond: e
 #endif
 struct S7Tables { int lo[G], wd[G], base[G]; };
 constexpr S7Tables S7T = {PTE_S7_TABLES};
-__device__ constexpr int LO[G] = {S7T.lo[0], S7T.lo[1], S7T.lo[2], S7T.lo[3], S7T.lo[4]};
-__device__ constexpr int WD[G] = {S7T.wd[0], S7T.wd[1], S7T.wd[2], S7T.wd[3], S7T.wd[4]};
-__device__ constexpr int BASE[G] = {S7T.base[0], S7T.base[1], S7T.base[2], S7T.base[3], S7T.base[4]};
+struct S7Row { int v[G]; };
+constexpr S7Row s7_row(const int (&a)[G]) { S7Row r{}; for (int i = 0; i < G; ++i) r.v[i] = a[i]; return r; }
+__device__ constexpr S7Row LO_ = s7_row(S7T.lo), WD_ = s7_row(S7T.wd), BASE_ = s7_row(S7T.base);
+#define LO LO_.v
+#define WD WD_.v
+#define BASE BASE_.v
+// level and offset (relative to the round's start) of the hypothesis of a lane
+__device__ __forceinline__ int s7_level(int lane) { int g = 0; for (int k = 1; k < G; ++k) g += (lane >= BASE[k]) ? 1 : 0; return g; }
+__device__ __forceinline__ int s7_pick(const int (&a)[G], int g, int dflt) { int r = dflt; for (int k = 0; k < G; ++k) r = (g == k) ? a[k] : r; return r; }
 constexpr int VALID = 1 << 30;
 }  // namespace s7
 
@@ -82,9 +91,8 @@ __global__ __launch_bounds__(64) void k_explore_slice7(EngineDev e, SliceParams 
     const int kcap = min(sp.p, 20);                    // window headroom: 2 + 20 + 24 draws per hypothesis
 
     // hypothesis (g, rel) of this lane
-    const int hg = (lane >= BASE[1]) + (lane >= BASE[2]) + (lane >= BASE[3]) + (lane >= BASE[4]);
-    const int hrel = (hg == 0) ? 0 : (hg == 1) ? (LO[1] + lane - BASE[1]) : (hg == 2) ? (LO[2] + lane - BASE[2])
-                   : (hg == 3) ? (LO[3] + lane - BASE[3]) : (LO[4] + lane - BASE[4]);
+    const int hg = s7_level(lane);
+    const int hrel = s7_pick(LO, hg, 0) + lane - s7_pick(BASE, hg, 0);
 
     double BS = 0.0;                                   // lane b: exact fixed-tree sum of block b
     for (int b = 0; b < B; ++b) {

@@ -74,15 +74,12 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
     const int kcap = min(sp.p, 20);                    // window headroom: 2 + 20 + 24 draws per hypothesis
 
     // hypothesis (g, rel) of this lane
-    const int hg = (lane >= BASE[1]) + (lane >= BASE[2]) + (lane >= BASE[3]) + (lane >= BASE[4]);
-    const int hrel = (hg == 0) ? 0 : (hg == 1) ? (LO[1] + lane - BASE[1]) : (hg == 2) ? (LO[2] + lane - BASE[2])
-                   : (hg == 3) ? (LO[3] + lane - BASE[3]) : (LO[4] + lane - BASE[4]);
+    const int hg = s7_level(lane);
+    const int hrel = s7_pick(LO, hg, 0) + lane - s7_pick(BASE, hg, 0);
 
     // the hypothesis that follows this one on the true path starts `cnt` draws later, one coordinate further:
     // lane  succ_base + (cnt + succ_off)  if that falls into the next level's window (never for the last level)
-    const int succ_lo = (hg == 0) ? LO[1] : (hg == 1) ? LO[2] : (hg == 2) ? LO[3] : (hg == 3) ? LO[4] : 0;
-    const int succ_wd = (hg == 0) ? WD[1] : (hg == 1) ? WD[2] : (hg == 2) ? WD[3] : (hg == 3) ? WD[4] : 0;
-    const int succ_base = (hg == 0) ? BASE[1] : (hg == 1) ? BASE[2] : (hg == 2) ? BASE[3] : (hg == 3) ? BASE[4] : 0;
+    const int succ_lo = s7_pick(LO, hg + 1, 0), succ_wd = s7_pick(WD, hg + 1, 0), succ_base = s7_pick(BASE, hg + 1, 0);
     const int succ_off = hrel - succ_lo;
     const uint64_t seed_in = e.rng[2 * slot];
 
