@@ -263,7 +263,9 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
             DISPATCH_NLU(h->nlu, k_explore_slice7, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, tn);
         } else if (h->slice_impl == 8) {
             // shrinkage steps for every hypothesis: PTE_S8_BS = 9, re-measured after every change of the round's cost (tools/bench_variant.py)
-            DISPATCH_NLU_M(h->nlu, k_explore_slice8, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
+            // 14 KB of LDS per replica (512-draw window) allow 11 replicas per CU; beyond 256 x 11 the 10 KB variant keeps 16
+            if (N <= 256 * 11) { DISPATCH_NLU_M(h->nlu, k_explore_slice8, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp); }
+            else { DISPATCH_NLU_M(h->nlu, k_explore_slice8_lds10k, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp); }
         } else if (h->slice_impl == 5 && h->slice_m == 3) {
             DISPATCH_NLU_M(h->nlu, k_explore_slice5, 3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_impl == 5 && h->slice_m == 6) {

@@ -38,9 +38,16 @@ namespace pte {
 #endif
 constexpr int S8_BD = PTE_S8_BD;                 // doubling budget of a speculative hypothesis (=> its acceptance check has <= 2 halvings); the shrinkage budget S8_BS is a template parameter
 
-template <int NLU, int S8_BS>
-__global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams sp) {
+#ifndef PTE_S8_WAVES                     // resident waves per SIMD the register allocation must allow (4 <=> 128 VGPRs)
+#define PTE_S8_WAVES 4
+#endif
+// The body is shared by two kernels that differ in the size of the LDS draw window: 512 draws convert fewer draws twice
+// (1.2 % faster), 256 draws keep the block at 10 KB of LDS, i.e. 16 resident replicas per CU (4 per SIMD) when a GPU holds
+// more than ~2800 replicas.
+template <int NLU, int S8_BS, int WINDOW>
+__device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
     using namespace s7;
+    constexpr int WIN = WINDOW, REFILL_AT = WINDOW - PTE_S7_MARGIN;
     __shared__ double s_we[256];
     __shared__ unsigned long long s_ke[256];
     __shared__ double s_u[WIN];
@@ -543,6 +550,15 @@ __global__ __launch_bounds__(64) void k_explore_slice8(EngineDev e, SliceParams 
 #endif
     }
     record_after_explore(e, cl, c, slot, lane, lp_before, S, 0.0);
+}
+
+template <int NLU, int S8_BS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES, PTE_S8_WAVES))) void k_explore_slice8(EngineDev e, SliceParams sp) {
+    slice8_body<NLU, S8_BS, PTE_S7_WIN>(e, sp);
+}
+template <int NLU, int S8_BS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES, PTE_S8_WAVES))) void k_explore_slice8_lds10k(EngineDev e, SliceParams sp) {
+    slice8_body<NLU, S8_BS, 256>(e, sp);
 }
 
 }  // namespace pte

@@ -855,6 +855,27 @@ def test_slice_parameters_off_the_defaults(P, monkeypatch, impl):
             _check_round(P, pt, ref)
 
 
+def test_slice_kernel_many_replicas_equals_sequential_kernel(P, monkeypatch):
+    """More than 256 x 11 replicas on one GPU run the default SliceSampler kernel with the 256-draw window (10 KB of LDS, 16
+    resident replicas per CU); same bits as the plain sequential kernel (which the oracle pins at small sizes)."""
+    def run(impl):
+        monkeypatch.setenv("PTE_SLICE_IMPL", impl)
+        pt = P.PT(P.Inputs(target=P.toy_mvn_target(70), n_chains=3000, n_rounds=3, seed=11, explorer=P.SliceSampler(),
+                           record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False))
+        out = []
+        for _ in range(3):
+            P.next_round(pt); red = P.run_one_round(pt); P.adapt(pt, red)
+            out.append((red.index_process.copy(), red.swap_acceptance_pr[0].copy(), red.explorer_n_steps[0].copy()))
+        return out, pt.replicas.states()
+    a, sa = run("1")
+    b, sb = run("8")
+    for ra, rb in zip(a, b):
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y)
+    for x, y in zip(sa, sb):
+        assert np.array_equal(x, y)
+
+
 def test_slice_special_states(P):
     """States a user can hand in through pte_set_state: all zeros (sum x^2 = 0, the margin of the filtered predicate has
     nothing to scale with), negative zeros, squares that underflow, large magnitudes -- same chain of decisions as the oracle."""
