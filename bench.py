@@ -1,16 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- replica-steps/sec of the explore-then-swap scan loop on MI355X.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line (rank 0).
 A "step" is one scan = explore! over all chains + one DEO communicate! (reference
 src/pt/pigeons.jl:49-52), the unit the reference's own stopwatch brackets.  Workload at N=1 is the
 configuration BASELINE.json's metric is quoted on: toy_mvn_target(1024), n_chains=1024,
 SliceSampler(w=10, p=20, n_passes=3), seed=1, synthetic (states drawn from split RNG streams).
 Replica states are resident in HBM before the timed region starts.
+
+N > 1: one process per GPU.  Started as plain `python bench.py --gpus N` this process only LAUNCHES: it touches no
+GPU, spawns N fresh children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), relays rank 0's JSON
+line and exits non-zero if any child fails.  Started under `python -m torch.distributed.run --nproc-per-node N` the
+environment is already there and the process is a rank.  The path shards by CHAIN: rank g owns chains
+[g*K, (g+1)*K); only the boundary pair of neighbouring ranks is exchanged, by RCCL send/recv that libpte itself
+enqueues on the engine's stream (pte_comm_init / pte_run_scans) -- there is no data-path collective and no
+torch.distributed call inside the timed loop; torch.distributed (backend nccl = RCCL) carries the 128-byte
+communicator id, the barriers around the timed region and the MAX over ranks.
+  --scaling weak   (default) 1024 chains per GPU, d = 1024: the metric's shape on every GPU, ladder of N*1024 chains
+  --scaling strong BASELINE configs[3]: toy_mvn_target(4096), n_chains = 8192 in total, 8192/N per GPU
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,55 +32,143 @@ for p in (ROOT, os.path.join(ROOT, "pigeons.jl_amd"), os.path.join(ROOT, "tests"
     if p not in sys.path:
         sys.path.insert(0, p)
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0    # ... and the measured float4-copy rate the guide quotes (SURVEY.md 8(d) prices against both)
 
 
-def cpu_baseline(d, cores, sample_chains=1024, sample_scans=2):
-    """Restated CPU baseline (NOT Pigeons.jl): the oracle's full-recompute SliceSampler, OpenMP
-    static schedule over replicas (mirrors @threads, reference src/pt/pigeons.jl:82-85), on a
-    bounded sample of the same workload."""
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--dim", type=int, default=None)
+    ap.add_argument("--chains", type=int, default=None, help="chains per GPU (weak) / in total (strong)")
+    ap.add_argument("--explorer", default="slice", choices=["slice", "toy"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--round-trip-rounds", type=int, default=11,
+                    help="untimed leg after the timed region: rounds 1..R of the reference's round loop with schedule "
+                         "adaptation; the round-trip rate is read off the last round (2^R scans).  0 = skip")
+    return ap.parse_args()
+
+
+def launch(args):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks.  Nothing here may touch the GPU (a process that
+    has initialised HIP must not fork / exec ranks), so neither torch nor libpte is imported in this process."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(args.gpus),
+                LOCAL_WORLD_SIZE=str(args.gpus))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    base.setdefault("OMP_NUM_THREADS", "1")
+    import tempfile
+    procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
+    for r in range(args.gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    # wait for all; a rank that dies would leave its peers blocked in a collective, so the first failure ends the others
+    rcs = [None] * len(procs)
+    while any(rc is None for rc in rcs):
+        for i, p in enumerate(procs):
+            if rcs[i] is None:
+                rcs[i] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            time.sleep(2.0)
+            for i, p in enumerate(procs):
+                if rcs[i] is None and p.poll() is None:
+                    p.kill()                                 # exactly the PIDs started above
+            rcs = [p.wait() for p in procs]
+            break
+        time.sleep(0.05)
+    out0.seek(0)
+    text = out0.read()
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    if any(rcs) or not lines:
+        sys.stderr.write("bench.py: ranks exited with %s\n%s\n" % (rcs, text))
+        return 1
+    print(lines[-1])
+    return 0
+
+
+def physical_cores():
+    """(physical cores, logical CPUs) available to this process."""
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        allowed = os.sched_getaffinity(0)
+        cores = set()
+        cpu, phys, core = None, 0, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("processor"):
+                cpu = int(ln.split(":")[1])
+            elif ln.startswith("physical id"):
+                phys = int(ln.split(":")[1])
+            elif ln.startswith("core id"):
+                core = int(ln.split(":")[1])
+            elif not ln.strip() and cpu is not None:
+                if cpu in allowed:
+                    cores.add((phys, core if core is not None else cpu))
+                cpu, phys, core = None, 0, None
+        return (len(cores) or logical), logical
+    except Exception:
+        return logical, logical
+
+
+def cpu_baseline(d, target_seconds=12.0):
+    """Restated CPU baseline (NOT Pigeons.jl): the oracle's SliceSampler with the full O(d) log density per evaluation as in
+    SliceSampler.jl, OpenMP static schedule over replicas (mirrors @threads, reference src/pt/pigeons.jl:82-85), one thread
+    pinned to every physical core (OMP_PLACES=cores, set in main() before any OpenMP runtime starts), compiled for this
+    machine (-O3 -march=native, -ffp-contract=off) -- on a bounded sample of the same workload."""
     import oracle as O
-    pt = O.OraclePT(n_chains=sample_chains, dim=d, explorer=O.EXPLORER_SLICE, n_threads=cores,
-                    record_index_process=0)
+    phys, logical = physical_cores()
+    try:
+        path, flags = O.build_native(), "-O3 -march=native"
+    except Exception as exc:                          # no compiler on the box: the portable build, and say so
+        path, flags = None, "-O2 (native build failed: %r)" % (exc,)
+    chains = max(phys * 4, 64)                          # 4 replicas per core: static schedule balanced
+    pt = O.OraclePT(lib_path=path, n_chains=chains, dim=d, explorer=O.EXPLORER_SLICE, n_threads=phys, record_index_process=0)
     pt.begin_round()
-    pt.run_scans(1)                       # untimed: spins up the OpenMP team, first-touch of the replica buffers
     t0 = time.perf_counter()
-    pt.run_scans(sample_scans)
+    pt.run_scans(1)                                     # untimed for the rate: spins up the team, first touch; sizes the sample
+    probe = time.perf_counter() - t0
+    scans = max(1, min(64, int(target_seconds / max(probe, 1e-3))))
+    t0 = time.perf_counter()
+    pt.run_scans(scans)
     dt = time.perf_counter() - t0
     return {
-        "value": sample_chains * sample_scans / dt, "unit": "replica-steps/s", "cores": cores, "kind": "port",
-        "sample": "toy_mvn_target(%d), %d chains x %d scans, SliceSampler, oracle (full O(d) log-density "
-                  "per evaluation as in SliceSampler.jl), OpenMP over replicas; restated CPU baseline, "
-                  "not Pigeons.jl" % (d, sample_chains, sample_scans),
+        "value": chains * scans / dt, "unit": "replica-steps/s", "cores": phys, "kind": "port",
+        "physical_cores": phys, "logical_cpus": logical, "threads": phys, "pinning": "OMP_PLACES=cores OMP_PROC_BIND=close",
+        "compiler_flags": flags + " -ffp-contract=off -fopenmp",
+        "per_core": chains * scans / dt / phys,
+        "sample": "toy_mvn_target(%d), %d chains x %d scans, SliceSampler(w=10,p=20,n_passes=3), oracle (full O(d) log density "
+                  "per evaluation as in SliceSampler.jl), OpenMP static over replicas; restated CPU baseline, not Pigeons.jl"
+                  % (d, chains, scans),
         "seconds": dt,
     }
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--dim", type=int, default=1024)
-    ap.add_argument("--chains", type=int, default=1024, help="chains per GPU (weak scaling)")
-    ap.add_argument("--explorer", default="slice", choices=["slice", "toy"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        sys.exit(launch(args))
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # the CPU baseline leg pins one OpenMP thread per physical core; libgomp reads this when it is first mapped
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        os.environ.setdefault("OMP_PLACES", "cores")
+        os.environ.setdefault("OMP_PROC_BIND", "close")
 
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("PTE_BENCH_BACKEND", "nccl")          # nccl == RCCL on ROCm
-        if os.environ.get("PTE_BENCH_SINGLE_DEVICE") == "1":           # smoke-testing N ranks on a 1-GPU box (gloo only)
-            local_rank = 0
+        backend = os.environ.get("PTE_BENCH_BACKEND", "nccl")          # nccl == RCCL on ROCm (control plane only)
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -76,16 +177,25 @@ def main():
 
     import numpy as np
     import pigeons_amd as P
+    from pigeons_amd.pt import reduce_recorders, adapt, next_round, run_one_round
 
-    d, K, W = args.dim, args.steps, args.warmup
-    n_chains = args.chains                      # chains per GPU; the ladder has n_chains * world chains
+    K, W = args.steps, args.warmup
+    if args.scaling == "strong":                # BASELINE configs[3]: d = 4096, 8192 chains in total
+        d = args.dim or 4096
+        total_chains = args.chains or 8192
+        if total_chains % world:
+            raise SystemExit("bench.py: %d chains do not divide over %d GPUs" % (total_chains, world))
+        n_chains = total_chains // world
+    else:                                       # the metric's shape on every GPU
+        d = args.dim or 1024
+        n_chains = args.chains or 1024
+        total_chains = n_chains * world
     explorer = P.SliceSampler() if args.explorer == "slice" else P.ToyExplorer()
-    # The path shards by chain: rank g owns chains [g*n_chains, (g+1)*n_chains); only the
-    # boundary pair of neighbouring ranks is exchanged (RCCL send/recv), no data-path collective.
-    inputs = P.Inputs(target=P.toy_mvn_target(d), n_chains=n_chains * world, n_rounds=30, explorer=explorer, seed=1,
+    rt_rounds = max(args.round_trip_rounds, 0)
+    inputs = P.Inputs(target=P.toy_mvn_target(d), n_chains=total_chains, n_rounds=max(rt_rounds, 1), explorer=explorer, seed=1,
                       record=[P.round_trip, P.log_sum_ratio], show_report=False, device=local_rank)
     if world > 1:
-        pt = P.PT(inputs, rank=rank, world=world, dist_device=torch.device("cuda", local_rank))
+        pt = P.PT(inputs, rank=rank, world=world)            # RcclShard: communicator id over torch.distributed, then libpte only
         runner = pt.shards
     else:
         pt = P.PT(inputs)
@@ -97,9 +207,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    from pigeons_amd.pt import reduce_recorders, adapt
-    # warmup: W scans, then one reduce + schedule adaptation (as at a round boundary)
-    eng.timing_reset(True)              # the swap kernel's duration is taken during the warmup scans ...
+    # warmup: W scans (first RCCL transfers open their connections here), then one reduce + schedule adaptation
+    eng.timing_reset(True)              # the swap kernels' duration is taken during the warmup scans ...
     runner.run_scans(1, W)
     sw_ms, sw_n = eng.timing(1)
     adapt(pt, reduce_recorders(pt))
@@ -109,28 +218,50 @@ def main():
     t0 = time.perf_counter()
     runner.run_scans(1, K)              # exactly K explore+swap scans, synchronous at return
     sync()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
+    dt, per_rank_ms = dt_local, [dt_local / K * 1e3]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
+        ts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)
+        per_rank_ms = [float(x.item()) / K * 1e3 for x in ts]
+        dt = max(float(x.item()) for x in ts)
     ex_ms, ex_n = eng.timing(0)
+    samples = np.sort(eng.timing_samples(0))
     eng.timing_reset(False)
-
-    # round-trip rate over the timed scans (RoundTripRecorder semantics: FSM reset at the reduce above)
     red = reduce_recorders(pt)
-    restarts, trips = red.round_trip
     ss_sum, ss_n = red.explorer_n_steps
+    boundary = [int(getattr(runner, "n_boundary_swaps", 0))]
+    ranks_seen = int(getattr(runner, "n_ranks_seen", 1))
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, boundary[0])
+        boundary = [int(b) for b in gathered]
 
-    total_chains = n_chains * world
+    # round-trip half of the metric (src/recorders/RoundTripRecorder.jl:23): untimed, the reference's own
+    # round loop -- rounds 1..R with schedule adaptation after each -- the rate is n_round_trips(last round) / 2^R
+    rt = None
+    if rt_rounds > 0 and args.explorer == "slice":
+        t1 = time.perf_counter()
+        pt.shared.iterators.round = 0
+        last = None
+        while next_round(pt):
+            last = run_one_round(pt)
+            adapt(pt, last)
+        restarts, trips = last.round_trip
+        n_scans = 2 ** rt_rounds
+        rt = {"rounds": rt_rounds, "scans_in_last_round": n_scans, "n_round_trips": int(trips), "n_tempered_restarts": int(restarts),
+              "round_trip_rate": trips / n_scans, "global_barrier": float(P.global_barrier(pt)),
+              "seconds": time.perf_counter() - t1,
+              "note": "untimed leg after the timed region; last round of an R-round run with schedule adaptation, as the reference reports it"}
+
     value = total_chains * K / dt
     # algorithmic HBM bytes of the dominant kernel per launch:
-    #   explore (slice / iid): state read + write + rng r/w = 16 d + 32 B per replica
+    #   explore (slice / iid): state read + write + rng r/w = 16 d + 32 B per replica; composite explore+swap: 24 d + 128
     bytes_per_replica = 16 * d + 32 if args.explorer == "slice" else 8 * d + 32
     alg_bytes = bytes_per_replica * n_chains
     ex_avg_ms = ex_ms / max(ex_n, 1)
-    impl = os.environ.get("PTE_SLICE_IMPL", "8")
-    kernel_name = {"slice": "k_explore_slice" + ("" if impl == "1" else impl), "toy": "k_explore_toy"}[args.explorer]
+    kernel_name = eng.kernel_name()                # reported by the library (pte_kernel_name), not guessed
     traffic = None
     issue = None
     try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this kernel at this workload
@@ -141,33 +272,44 @@ def main():
     except Exception:
         traffic = None
     achieved = alg_bytes / (ex_avg_ms * 1e-3) / 1e9 if ex_avg_ms > 0 else 0.0
+    lp_evals = float(np.sum(ss_sum) / max(K * (total_chains - 1), 1)) + 2.0 * 3 * d if args.explorer == "slice" else 0.0
+    composite_bytes = (24 * d + 128) * value            # B/s over the whole job
     out = {
         "metric": "replica-steps/sec (explore+swap), toy_mvn d=%d, n_chains=%d; round-trip rate" % (d, total_chains),
         "value": value, "unit": "replica-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "toy_mvn_target(%d), n_chains=%d per GPU x %d GPU, %s, seed=1, DEO swaps every scan"
                                % (d, n_chains, world, "SliceSampler(w=10,p=20,n_passes=3)" if args.explorer == "slice" else "ToyExplorer"),
-                   "sharding": ("chains sharded over %d GPUs, boundary replicas exchanged by RCCL send/recv" % world) if world > 1 else "single GPU",
-                   "boundary_swaps_rank0": getattr(runner, "n_boundary_swaps", 0)},
-        "round_trip_rate": trips / K, "n_round_trips": trips, "n_tempered_restarts": restarts,
-        "lp_evals_per_replica_step": float(np.sum(ss_sum) / max(K * (total_chains - 1), 1)) + 2.0 * 3 * d if args.explorer == "slice" else 0.0,
+                   "sharding": ("chains sharded over %d GPUs, boundary replicas exchanged by RCCL send/recv inside libpte (pte_comm_*)" % world) if world > 1 else "single GPU",
+                   "n_ranks_seen": ranks_seen, "boundary_swaps_per_rank": boundary, "ms_per_step_per_rank": per_rank_ms},
+        "round_trip_rate": rt["round_trip_rate"] if rt else None, "n_round_trips": rt["n_round_trips"] if rt else None,
+        "n_tempered_restarts": rt["n_tempered_restarts"] if rt else None, "round_trip": rt,
+        "lp_evals_per_replica_step": lp_evals,
         "roofline": {"bound": "hbm", "kernel": kernel_name,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "avg_launch_ms": ex_avg_ms, "launches": ex_n,
+                     "launch_ms_min_median_max": [float(samples[0]), float(samples[len(samples) // 2]), float(samples[-1])] if len(samples) else None,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "swap_kernel_avg_launch_ms": sw_ms / max(sw_n, 1),
+                     "composite_explore_plus_swap": {
+                         "bytes_per_replica_step": 24 * d + 128, "achieved_GBps": composite_bytes / 1e9,
+                         "frac_of_6.29TBps": composite_bytes / 1e9 / HBM_ACHIEVABLE_GBS / world,
+                         "frac_of_8TBps": composite_bytes / 1e9 / HBM_PEAK_GBS / world},
+                     "fp64_reference_equivalent_flops": 2.0 * d * lp_evals * value,
                      "instruction_issue": issue,
                      "note": "SliceSampler is bound by the instruction issue of ONE wave per replica walking a sequential "
                              "decision chain (3*d coordinate updates, ~6.5 draws each), not by HBM; see DESIGN.md sec. 5"},
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.explorer == "slice":
-            out["cpu_baseline"] = cpu_baseline(d, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(d)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

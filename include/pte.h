@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PTE_ABI_VERSION 1
+#define PTE_ABI_VERSION 2
 
 /* Device log-potential families (closed set; arbitrary Julia closures cannot run
  * on the GPU -- unsupported combinations make pte_create fail, and the caller
@@ -61,6 +61,14 @@ enum {                                   /* Inputs.record (src/pt/Inputs.jl:57-6
     PTE_RECORD_TRACES        = 1u << 3,  /* traces: [state; log density] of the target chain per scan (src/recorders/recorder.jl:27,39-43; src/pt/pigeons.jl:116-125) */
     PTE_RECORD_TRACES_EXTENDED = 1u << 5, /* with PTE_RECORD_TRACES: inputs.extended_traces, every chain is traced (src/pt/pigeons.jl:116) */
     PTE_RECORD_ENERGY_AC1    = 1u << 4   /* energy_ac1: per-chain covariance of the log density before / after explore! (recorder.jl:113; pigeons.jl:134-143) */
+};
+
+enum {                                   /* pte_config.debug_kernel: which kernel generation explores (0 = the default)   */
+    PTE_KERNEL_DEFAULT          = 0,
+    PTE_KERNEL_SLICE_SEQUENTIAL = 1,     /* SliceSampler: the plain sequential kernel (exact fallback of the default one)  */
+    /* 2, 5, 7 (and 8 = the default named explicitly): earlier SliceSampler generations, test build libpte_test.so only    */
+    PTE_KERNEL_ISING_BITS       = 101,   /* IsingMetropolis: scalar bit-packed sweep, test build only                      */
+    PTE_KERNEL_ISING_BYTES      = 102    /* IsingMetropolis: scalar byte-lattice sweep (the kernel of base_length % 32 != 0) */
 };
 
 /* Mirrors the fields of `Inputs` (src/pt/Inputs.jl:9-102) and of the explorer
@@ -100,6 +108,10 @@ typedef struct pte_config {
      * ends, the two targets in the middle.  pte_set_schedule takes the N per-chain betas in that order
      * (concatenate_log_potentials, StabilizedPT.jl:67-69).  0 = one leg (NonReversiblePT).  Single engine only. */
     int64_t  n_chains_variational;
+    /* Debug / bisecting: PTE_KERNEL_*.  The kernel is chosen by this field only -- the library never reads the
+     * environment -- and pte_create fails on a value this build does not contain.  pte_kernel_name reports the choice. */
+    int32_t  debug_kernel;
+    int32_t  reserved0;
 } pte_config;
 
 typedef struct pte_engine pte_engine;
@@ -124,7 +136,8 @@ int pte_set_explorer_adaptation(pte_engine *h, double step_size, const double *t
 int pte_explore(pte_engine *h, int64_t scan);
 /* One communicate!: DEO graph parity = iseven(scan) (src/swap/DEO.jl:12). */
 int pte_swap(pte_engine *h, int64_t scan);
-/* The fused scan loop: for s = first_scan .. first_scan+n_scans-1: explore!(s); communicate!(s). */
+/* The fused scan loop: for s = first_scan .. first_scan+n_scans-1: explore!(s); communicate!(s).
+ * On a chain-sharded engine (world_size > 1) this needs pte_comm_init and is collective over the ranks. */
 int pte_run_scans(pte_engine *h, int64_t first_scan, int64_t n_scans);
 
 /* reduce_recorders!: snapshot the round's accumulators to the host and reset them on the
@@ -168,8 +181,8 @@ int pte_set_state(pte_engine *h, const double *state, const int64_t *chain, cons
  * partner replica's rank and moves chain labels.  Here the shard boundary is between CHAINS, so only
  * the G-1 boundary pairs cross GPUs: their SwapStats are exchanged between the two phases below and,
  * iff the swap is accepted, the two replicas' payloads {state, sum x^2, rng, replica id, round-trip
- * state} trade places.  The host moves the bytes (RCCL send/recv over xGMI between ranks; a plain
- * copy between engines of one process).  side: 0 = pair (c0-1, c0), 1 = pair (c0+K-1, c0+K).
+ * state} trade places.  With these two-phase calls the HOST moves the bytes (any transport; the CPU tests use
+ * gloo, loopback tests plain copies); the transport the library itself provides is pte_comm_* below.  side: 0 = pair (c0-1, c0), 1 = pair (c0+K-1, c0+K).
  * With world_size == 1 these calls are valid too (no boundary is ever active) and equal pte_swap. */
 int pte_shard_info(const pte_engine *h, int64_t *first_chain, int64_t *n_local_chains, int64_t *n_local_pairs);
 /* phase 1: swap_stat of every local chain (one rand per replica), index_process / round_trip records.
@@ -197,6 +210,39 @@ int pte_shard_set_buffers(pte_engine *h, void *send_lo, void *recv_lo, void *sen
 int pte_shard_scan_begin(pte_engine *h, int64_t scan, int32_t *active_out);
 int pte_shard_scan_finish(pte_engine *h, int64_t scan);
 int pte_shard_sync(pte_engine *h, int64_t *boundary_swaps_out);
+/* ---- transport behind the ABI -------------------------------------------------------------------
+ * The reference keeps its communication inside the package (MPI: src/mpi_utils/Entangler.jl:118-180
+ * `transmit!`, :188-251 `all_reduce_deterministically`; distributed swap! src/swap/swap.jl:79-102).  Here the
+ * boundary exchange of a chain-sharded engine is RCCL point-to-point (ncclSend / ncclRecv in one group per scan,
+ * over xGMI inside a node) enqueued on the engine's own HIP stream between the pack and the decide kernels:
+ * no host synchronisation inside the scan loop, no collective on the data path.
+ *   one process per GPU : rank 0 calls pte_comm_unique_id, the host hands the 128 bytes to every rank by any
+ *                         means it has (MPI.bcast, a socket, a file), every rank calls pte_comm_init; from then
+ *                         on pte_run_scans works on the sharded engine exactly as on a single one.
+ *   one process, G GPUs : pte_group_run_scans drives G engines (rank g = engines[g]) from one host thread; the
+ *                         messages move by stream-ordered device-to-device copies (peer copies over xGMI).
+ * Message buffers are engine-owned unless the caller installed its own with pte_shard_set_buffers.
+ * RCCL is mapped at run time (dlopen; $PTE_RCCL_LIB overrides the search), libpte.so does not link it. */
+#define PTE_COMM_ID_BYTES 128
+int pte_comm_unique_id(uint8_t *id_out /*PTE_COMM_ID_BYTES*/);
+int pte_comm_init(pte_engine *h, const uint8_t *id /*PTE_COMM_ID_BYTES*/);   /* ncclCommInitRank(cfg.world_size, id, cfg.rank); collective */
+int pte_comm_destroy(pte_engine *h);
+/* kind: 0 none, 1 RCCL; n_ranks_seen: sum over the communicator of 1 (measured, not configured);
+ * boundary_swaps[2]: boundary swaps applied on the device since pte_create, per side. NULLs are skipped. */
+int pte_comm_info(pte_engine *h, int32_t *kind, int32_t *n_ranks_seen, int64_t *boundary_swaps);
+/* Small host-side collectives over the same communicator, so that a host without MPI can bracket a round:
+ * barrier; element-wise MAX / SUM of n doubles (op: 0 max, 1 sum); all-gather of `bytes` bytes per rank into
+ * recv[world * bytes] in rank order (the per-round recorder slices -- recorders are keyed by chain / pair, so
+ * concatenation in rank order is deterministic).  With world_size == 1 they are local no-ops / copies. */
+int pte_comm_barrier(pte_engine *h);
+int pte_comm_allreduce(pte_engine *h, double *inout, int64_t n, int32_t op);
+int pte_comm_allgather(pte_engine *h, const void *send, int64_t bytes, void *recv);
+/* G engines of ONE process, engines[g] = rank g of a world of G (same N, d, explorer): the fused scan loop. */
+int pte_group_run_scans(pte_engine *const *engines, int32_t n_engines, int64_t first_scan, int64_t n_scans);
+
+/* Name of the kernel that explores on this engine (e.g. "k_explore_slice8"), for profiles and bench.py. */
+const char *pte_kernel_name(const pte_engine *h);
+
 /* index process of the local slots: replica[scan][K], chain[scan][K] (global ids). */
 int pte_get_index_process_shard(const pte_engine *h, int64_t *replica, int64_t *chain, int64_t *n_scans);
 int pte_get_replica_ids(const pte_engine *h, int64_t *out /*K*/);
@@ -206,6 +252,8 @@ int pte_get_replica_ids(const pte_engine *h, int64_t *out /*K*/);
  * enable: 0 off, 1 every kernel, 2 the explore kernels only (an event pair costs ~10 us of stream time per launch). */
 int pte_timing_reset(pte_engine *h, int enable);
 int pte_timing_get(const pte_engine *h, int kernel, double *total_ms, int64_t *launches);
+/* the individual launch durations behind pte_timing_get (min / median / max of the timed region); out_ms may be NULL */
+int pte_timing_get_samples(const pte_engine *h, int kernel, double *out_ms, int64_t capacity, int64_t *n_out);
 
 /* RNG building blocks exposed for parity tests of the device samplers: fill `n` draws from the
  * stream (seed, gamma) on the device, in the reference's sequential order.

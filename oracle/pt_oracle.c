@@ -108,21 +108,34 @@ static int64_t next_pow2(int64_t n) { int64_t p = 1; while (p < n) p <<= 1; retu
  * x_i^2 in natural order, zero-padded to the next power of two
  * (node[i] = node[2i] + node[2i+1]).  x + 0.0 is exact, so padding is inert. */
 double po_sqr_norm(const double *x, int64_t d) {
+    /* The balanced tree evaluated without a scratch array: 8-leaf subtrees in registers, their sums merged through
+     * a binary-counter stack (level l holds a completed subtree of 8 * 2^l leaves).  Zero padding never has to be
+     * materialised: a subtree of zeros adds 0.0, which is exact, so a partial right edge just moves up the tree.
+     * Same association as node[i] = node[2i] + node[2i+1] -- tests/test_oracle_kat.py::test_sqr_norm_tree pins the bits. */
     if (d <= 0) return 0.0;
-    int64_t P = next_pow2(d);
-    double stackbuf[1024];
-    double *a = (P / 2 <= 1024) ? stackbuf : (double *)malloc(sizeof(double) * (size_t)(P / 2));
-    if (P == 1) return x[0] * x[0];
-    for (int64_t i = 0; i < P / 2; i++) {
-        double l = (2 * i < d) ? x[2 * i] * x[2 * i] : 0.0;
-        double r = (2 * i + 1 < d) ? x[2 * i + 1] * x[2 * i + 1] : 0.0;
-        a[i] = l + r;
+    double stack[64];
+    int level[64];
+    int top = 0;
+    int64_t i = 0;
+    for (; i + 8 <= d; i += 8) {
+        const double *v = x + i;
+        double s = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) +
+                   ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+        int l = 0;
+        while (top > 0 && level[top - 1] == l) { s = stack[--top] + s; l++; }
+        stack[top] = s; level[top] = l; top++;
     }
-    for (int64_t len = P / 2; len > 1; len /= 2)
-        for (int64_t i = 0; i < len / 2; i++) a[i] = a[2 * i] + a[2 * i + 1];
-    double s = a[0];
-    if (a != stackbuf) free(a);
-    return s;
+    if (i < d) {                                   /* ragged last block: missing leaves are 0.0 */
+        double q[8];
+        for (int k = 0; k < 8; k++) q[k] = (i + k < d) ? x[i + k] * x[i + k] : 0.0;
+        double s = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+        int l = 0;
+        while (top > 0 && level[top - 1] == l) { s = stack[--top] + s; l++; }
+        stack[top] = s; level[top] = l; top++;
+    }
+    double acc = stack[--top];                     /* the right edge climbs (adding exact zeros) until it meets its left sibling */
+    while (top > 0) acc = stack[--top] + acc;
+    return acc;
 }
 
 /* LogExpFunctions.logaddexp (0.3.x): max + log1pexp(-|x-y|); used by

@@ -13,12 +13,16 @@
 
 #include "../../include/pte.h"
 #include "pte_kernels.hpp"
+// The headers of the earlier SliceSampler generations hold helpers the default kernel shares (draw buffer, filtered
+// predicates, exact sequential fallback, window tables); their kernels are templates and are only instantiated --
+// i.e. only exist in the library -- in the test build (-DPTE_TEST_KERNELS, libpte_test.so), see launch_explorer_kind.
 #include "pte_slice2.hpp"
 #include "pte_slice5.hpp"
 #include "pte_slice7.hpp"
 #include "pte_slice8.hpp"
 #include "pte_automala.hpp"
 #include "pte_ising.hpp"
+#include "pte_comm.hpp"
 
 using namespace pte;
 
@@ -45,7 +49,15 @@ struct pte_engine {
     EngineDev dev{};
     hipStream_t stream = nullptr;
     int nlu = 0;
-    int slice_impl = 8, slice_m = 4;   // PTE_SLICE_IMPL = 1 plain sequential | 2 lane-batched tree path | 5 tree-free batches | 7 offset speculation, loops | 8 the same, straight-line (default)
+    int slice_impl = 8, slice_m = 4;   // from pte_config.debug_kernel: 8 offset speculation, straight-line (default) | 1 plain sequential; test build: 2, 5, 7
+    int ising_impl = 0;                // 0 lane-speculative bit-packed sweep (default) | test build: 1 scalar bit-packed, 2 byte lattice
+    // transport behind the ABI (pte_comm_*)
+    int comm_kind = 0;                 // 0 none, 1 RCCL communicator over the ranks
+    ncclComm_t nccl = nullptr;
+    int n_ranks_seen = 0;
+    double *own_msg = nullptr;         // engine-owned message buffers [4][d+8] when the caller set none
+    double *d_coll = nullptr;          // [16] device staging of the small host collectives
+    hipEvent_t ev_pack = nullptr, ev_copied = nullptr;   // in-process group transport (pte_group_run_scans)
     int64_t N = 0, d = 0;          // global chains, state dimension
     int64_t K = 0, c0 = 0;         // local chains [c0, c0+K)
     int world = 1, rank = 0;
@@ -74,6 +86,7 @@ struct pte_engine {
     std::vector<hipEvent_t> ev_pool;
     double t_ms[2] = {0, 0};
     int64_t t_n[2] = {0, 0};
+    std::vector<float> t_samples[2];  // per-launch durations since the last reset (spread of the timed region)
 };
 
 namespace {
@@ -220,6 +233,7 @@ void time_collect(pte_engine *h) {
         hipEventSynchronize(ev.b);
         hipEventElapsedTime(&ms, ev.a, ev.b);
         h->t_ms[ev.kernel] += ms; h->t_n[ev.kernel] += 1;
+        if (h->t_samples[ev.kernel].size() < (size_t)1 << 20) h->t_samples[ev.kernel].push_back(ms);
         h->ev_pool.push_back(ev.a); h->ev_pool.push_back(ev.b);
     }
     h->events.clear();
@@ -255,30 +269,25 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
     case PTE_EXPLORER_SLICE: {
         SliceParams sp{h->cfg.slice_w, h->cfg.slice_p, h->cfg.slice_n_passes, h->cfg.slice_max_iter};
         time_begin(h, 0);
-        if (h->slice_impl == 1) {
+        if (h->slice_impl == 1) {          // PTE_KERNEL_SLICE_SEQUENTIAL: the plain sequential kernel (exact fallback, bisecting)
             DISPATCH_NLU(h->nlu, k_explore_slice, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
-        } else if (h->slice_impl == 7) {
-            S7Tune tn{2, 8, 2};
-            if (const char *t = std::getenv("PTE_S7_BUDGETS")) std::sscanf(t, "%d,%d,%d", &tn.bud_d, &tn.bud_s, &tn.bud_a);
-            DISPATCH_NLU(h->nlu, k_explore_slice7, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, tn);
         } else if (h->slice_impl == 8) {
             // shrinkage steps for every hypothesis: PTE_S8_BS = 9, re-measured after every change of the round's cost (tools/bench_variant.py)
             // 14 KB of LDS per replica (512-draw window) allow 11 replicas per CU; beyond 256 x 11 the 10 KB variant keeps 16
             if (N <= 256 * 11) { DISPATCH_NLU_M(h->nlu, k_explore_slice8, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp); }
             else { DISPATCH_NLU_M(h->nlu, k_explore_slice8_lds10k, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp); }
-        } else if (h->slice_impl == 5 && h->slice_m == 3) {
-            DISPATCH_NLU_M(h->nlu, k_explore_slice5, 3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
-        } else if (h->slice_impl == 5 && h->slice_m == 6) {
-            DISPATCH_NLU_M(h->nlu, k_explore_slice5, 6, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
+        }
+#ifdef PTE_TEST_KERNELS
+        else if (h->slice_impl == 7) {
+            S7Tune tn{2, 8, 2};
+            DISPATCH_NLU(h->nlu, k_explore_slice7, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, tn);
         } else if (h->slice_impl == 5) {
             DISPATCH_NLU_M(h->nlu, k_explore_slice5, 4, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
-        } else if (h->slice_m == 3) {
-            DISPATCH_NLU_M(h->nlu, k_explore_slice2, 3, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
-        } else if (h->slice_m == 6) {
-            DISPATCH_NLU_M(h->nlu, k_explore_slice2, 6, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
-        } else {
+        } else if (h->slice_impl == 2) {
             DISPATCH_NLU_M(h->nlu, k_explore_slice2, 4, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         }
+#endif
+        else return fail(h, "SliceSampler kernel %d is not in this build", h->slice_impl);   // pte_create validates; unreachable
         time_end(h);
         break;
     }
@@ -306,13 +315,13 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
     case PTE_EXPLORER_ISING_METROPOLIS: {
         IsingParams ip{(int)std::llround(std::sqrt((double)h->d)), h->cfg.slice_n_passes, h->cfg.target_params[0]};
         time_begin(h, 0);
-        const char *impl = std::getenv("PTE_ISING_IMPL");      // "bytes" | "bits" | default: lane-speculative bit-packed sweep
-        if (ip.L % 32 == 0 && !std::getenv("PTE_ISING_BYTES") && !(impl && !std::strcmp(impl, "bytes"))) {
-            if (impl && !std::strcmp(impl, "bits"))
-                hipLaunchKernelGGL(k_explore_ising_bits, dim3((unsigned)N), dim3(64), (size_t)(h->d / 8), h->stream, h->dev, ip);
-            else
-                hipLaunchKernelGGL(k_explore_ising_spec, dim3((unsigned)N), dim3(64), (size_t)(h->d / 8), h->stream, h->dev, ip);
-        }
+        // L % 32 == 0: lane-speculative bit-packed sweep; other lattice sizes: the scalar byte-lattice kernel
+        if (ip.L % 32 == 0 && h->ising_impl == 0)
+            hipLaunchKernelGGL(k_explore_ising_spec, dim3((unsigned)N), dim3(64), (size_t)(h->d / 8), h->stream, h->dev, ip);
+#ifdef PTE_TEST_KERNELS
+        else if (ip.L % 32 == 0 && h->ising_impl == 1)
+            hipLaunchKernelGGL(k_explore_ising_bits, dim3((unsigned)N), dim3(64), (size_t)(h->d / 8), h->stream, h->dev, ip);
+#endif
         else
             hipLaunchKernelGGL(k_explore_ising, dim3((unsigned)N), dim3(64), (size_t)h->d, h->stream, h->dev, ip);
         time_end(h);
@@ -350,6 +359,8 @@ void boundary_active(const pte_engine *h, int even, int32_t active[2]) {
     active[0] = (h->c0 > 0 && partner(h->c0) == h->c0 - 1) ? 1 : 0;
     active[1] = (h->c0 + h->K < h->N && partner(h->c0 + h->K - 1) == h->c0 + h->K) ? 1 : 0;
 }
+
+int run_scans_sharded(pte_engine *h, int64_t first_scan, int64_t n_scans);
 
 }  // namespace
 
@@ -416,6 +427,17 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
         return fail(nullptr, "pte_create: explorer %d is not implemented on the device", cfg->explorer);
     if ((cfg->record_flags & PTE_RECORD_TRACES_EXTENDED) && !(cfg->record_flags & PTE_RECORD_TRACES))
         return fail(nullptr, "pte_create: PTE_RECORD_TRACES_EXTENDED needs PTE_RECORD_TRACES");
+    {   // debug_kernel: 0 = the default kernel of the explorer; anything else must exist in THIS build (no silent fall-through)
+        const int dk = cfg->debug_kernel;
+        const bool slice = cfg->explorer == PTE_EXPLORER_SLICE || cfg->explorer2 == PTE_EXPLORER_SLICE;
+        bool ok = dk == 0 || (slice && dk == PTE_KERNEL_SLICE_SEQUENTIAL) || (ising && dk == PTE_KERNEL_ISING_BYTES);
+#ifdef PTE_TEST_KERNELS
+        ok = ok || (slice && (dk == 2 || dk == 5 || dk == 7 || dk == 8)) || (ising && dk == PTE_KERNEL_ISING_BITS);
+#endif
+        if (!ok) return fail(nullptr, "pte_create: debug_kernel %d is not available for this explorer in this build of libpte "
+                                      "(0 = default, %d = sequential SliceSampler kernel; the other generations live in the test build libpte_test.so)",
+                             dk, PTE_KERNEL_SLICE_SEQUENTIAL);
+    }
     if ((cfg->record_flags & PTE_RECORD_TRACES) &&
         (double)cfg->max_scans_per_round * (double)((cfg->record_flags & PTE_RECORD_TRACES_EXTENDED) ? cfg->n_chains / cfg->world_size : 1) * (double)(cfg->dim + 1) * 8.0 > 64e9)
         return fail(nullptr, "pte_create: the traces buffer (max_scans_per_round x chains x (dim+1) doubles) would exceed 64 GB");
@@ -436,8 +458,9 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     if (hipStreamCreate(&h->stream) != hipSuccess) { h->err = "hipStreamCreate failed"; return bail(1); }
     const int64_t B = (d + 63) / 64;
     h->nlu = next_pow2_log(B > 0 ? B : 1);
-    if (const char *s = std::getenv("PTE_SLICE_IMPL")) h->slice_impl = std::atoi(s);
-    if (const char *s = std::getenv("PTE_SLICE_M")) h->slice_m = std::atoi(s);
+    // pte_config.debug_kernel (validated above): which kernel generation explores; never read from the environment
+    if (cfg->explorer == PTE_EXPLORER_SLICE || cfg->explorer2 == PTE_EXPLORER_SLICE) h->slice_impl = cfg->debug_kernel == 0 ? 8 : cfg->debug_kernel;
+    if (cfg->explorer == PTE_EXPLORER_ISING_METROPOLIS) h->ising_impl = cfg->debug_kernel == PTE_KERNEL_ISING_BITS ? 1 : (cfg->debug_kernel == PTE_KERNEL_ISING_BYTES ? 2 : 0);
     EngineDev &e = h->dev;
     e.N = N; e.K = K; e.c0 = h->c0; e.d = d; e.ld = (d + 1) & ~(int64_t)1;
     e.record_flags = cfg->record_flags; e.target = cfg->target; e.test_swapper_pr = cfg->target_params[0];
@@ -562,6 +585,9 @@ int pte_destroy(pte_engine *h) {
     hipSetDevice(h->cfg.device);
     if (h->stream) hipStreamSynchronize(h->stream);
     time_collect(h);
+    pte_comm_destroy(h);
+    if (h->ev_pack) hipEventDestroy(h->ev_pack);
+    if (h->ev_copied) hipEventDestroy(h->ev_copied);
     for (hipEvent_t ev : h->ev_pool) hipEventDestroy(ev);
     for (void *p : h->allocs) hipFree(p);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -629,6 +655,7 @@ int pte_swap(pte_engine *h, int64_t scan) {
 int pte_run_scans(pte_engine *h, int64_t first_scan, int64_t n_scans) {
     if (!h) return 1;
     HIP_OK(h, hipSetDevice(h->cfg.device));
+    if (h->world != 1) return run_scans_sharded(h, first_scan, n_scans);
     for (int64_t s = first_scan; s < first_scan + n_scans; ++s) {
         if (launch_explore(h, s)) return 1;
         if (launch_swap(h, s)) return 1;
@@ -944,6 +971,232 @@ int pte_shard_sync(pte_engine *h, int64_t *boundary_swaps_out) {
     return rc;
 }
 
+// ---- transport behind the ABI: RCCL point-to-point on the engine's stream / in-process groups ------------
+namespace {
+
+#define NCCL_OK(h, api, call)                                                                     \
+    do { ncclResult_t r_ = (call);                                                                \
+         if (r_ != ncclSuccess) return fail(h, "%s failed: %s", #call, (api)->GetErrorString(r_)); } while (0)
+
+// engine-owned message buffers {send_lo, recv_lo, send_hi, recv_hi}, d + 8 words each, unless the caller installed its own
+int ensure_msg_buffers(pte_engine *h) {
+    if (h->msg_send[0] && h->msg_recv[0] && h->msg_send[1] && h->msg_recv[1]) return 0;
+    const size_t w = (size_t)(h->d + 8);
+    if (!h->own_msg && dev_alloc(h, &h->own_msg, 4 * w)) return 1;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    h->msg_send[0] = h->own_msg;         h->msg_recv[0] = h->own_msg + w;
+    h->msg_send[1] = h->own_msg + 2 * w; h->msg_recv[1] = h->own_msg + 3 * w;
+    return 0;
+}
+
+// One DEO scan of a chain-sharded engine, everything enqueued on the engine's stream:
+//   explore -> k_swap_stats -> k_boundary_pack -> { ncclSend, ncclRecv per active side, one group }
+//   -> k_boundary_stats_in -> k_swap_decide -> k_boundary_apply
+int run_scans_sharded(pte_engine *h, int64_t first_scan, int64_t n_scans) {
+    if (h->comm_kind != 1)
+        return fail(h, "pte_run_scans on a chain-sharded engine (world_size %d) needs pte_comm_init "
+                       "(or drive the engines of one process with pte_group_run_scans, or the two-phase pte_swap_begin / pte_swap_finish)", h->world);
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) return fail(h, "%s", err.c_str());
+    if (ensure_msg_buffers(h)) return 1;
+    const size_t words = (size_t)(h->d + 8);
+    for (int64_t s = first_scan; s < first_scan + n_scans; ++s) {
+        int32_t active[2];
+        if (pte_shard_scan_begin(h, s, active)) return 1;
+        if (active[0] || active[1]) {
+            NCCL_OK(h, api, api->GroupStart());
+            for (int sd = 0; sd < 2; ++sd) {
+                if (!active[sd]) continue;
+                const int peer = sd == 0 ? h->rank - 1 : h->rank + 1;
+                NCCL_OK(h, api, api->Send(h->msg_send[sd], words, ncclDouble, peer, h->nccl, h->stream));
+                NCCL_OK(h, api, api->Recv(h->msg_recv[sd], words, ncclDouble, peer, h->nccl, h->stream));
+            }
+            NCCL_OK(h, api, api->GroupEnd());
+        }
+        if (pte_shard_scan_finish(h, s)) return 1;
+    }
+    return pte_shard_sync(h, nullptr);
+}
+
+}  // namespace
+
+int pte_comm_unique_id(uint8_t *id_out) {
+    if (!id_out) return fail(nullptr, "pte_comm_unique_id: null argument");
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) return fail(nullptr, "%s", err.c_str());
+    static_assert(sizeof(ncclUniqueId) == PTE_COMM_ID_BYTES, "PTE_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
+    ncclUniqueId id;
+    ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, "ncclGetUniqueId failed: %s", api->GetErrorString(r));
+    std::memcpy(id_out, &id, sizeof id);
+    return 0;
+}
+
+int pte_comm_init(pte_engine *h, const uint8_t *id_bytes) {
+    if (!h || !id_bytes) return 1;
+    if (h->comm_kind != 0) return fail(h, "pte_comm_init: the engine already has a communicator");
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) return fail(h, "%s", err.c_str());
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof id);
+    NCCL_OK(h, api, api->CommInitRank(&h->nccl, h->world, id, h->rank));
+    h->comm_kind = 1;
+    if (!h->d_coll && dev_alloc(h, &h->d_coll, 16)) return 1;
+    if (ensure_msg_buffers(h)) return 1;
+    // n_ranks_seen: measured (an all-reduce of 1 over the communicator), not the configured world size
+    double one = 1.0;
+    if (pte_comm_allreduce(h, &one, 1, 1)) return 1;
+    h->n_ranks_seen = (int)std::llround(one);
+    if (h->n_ranks_seen != h->world) return fail(h, "pte_comm_init: the communicator spans %d ranks, expected world_size %d", h->n_ranks_seen, h->world);
+    return 0;
+}
+
+int pte_comm_destroy(pte_engine *h) {
+    if (!h) return 1;
+    if (h->comm_kind == 1 && h->nccl) {
+        std::string err;
+        if (RcclApi *api = rccl_api(err)) { hipSetDevice(h->cfg.device); hipStreamSynchronize(h->stream); api->CommDestroy(h->nccl); }
+    }
+    h->nccl = nullptr; h->comm_kind = 0;
+    return 0;
+}
+
+int pte_comm_info(pte_engine *h, int32_t *kind, int32_t *n_ranks_seen, int64_t *boundary_swaps) {
+    if (!h) return 1;
+    if (kind) *kind = h->comm_kind;
+    if (n_ranks_seen) *n_ranks_seen = h->comm_kind == 1 ? h->n_ranks_seen : 1;
+    if (boundary_swaps) {
+        HIP_OK(h, hipSetDevice(h->cfg.device));
+        HIP_OK(h, hipMemcpyAsync(boundary_swaps, h->d_napplied, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(h, hipStreamSynchronize(h->stream));
+    }
+    return 0;
+}
+
+int pte_comm_allreduce(pte_engine *h, double *inout, int64_t n, int32_t op) {
+    if (!h || !inout || n < 0 || (op != 0 && op != 1)) return 1;
+    if (h->world == 1 || n == 0) return 0;
+    if (h->comm_kind != 1) return fail(h, "pte_comm_allreduce: call pte_comm_init first");
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) return fail(h, "%s", err.c_str());
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    double *buf = h->d_coll;
+    const bool big = n > 16;
+    if (big) HIP_OK(h, hipMalloc((void **)&buf, sizeof(double) * n));
+    hipError_t e1 = hipMemcpyAsync(buf, inout, sizeof(double) * n, hipMemcpyHostToDevice, h->stream);
+    ncclResult_t r = e1 == hipSuccess ? api->AllReduce(buf, buf, (size_t)n, ncclDouble, op == 0 ? ncclMax : ncclSum, h->nccl, h->stream) : ncclSuccess;
+    if (e1 == hipSuccess && r == ncclSuccess) e1 = hipMemcpyAsync(inout, buf, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    if (big) hipFree(buf);
+    if (r != ncclSuccess) return fail(h, "ncclAllReduce failed: %s", api->GetErrorString(r));
+    HIP_OK(h, e1); HIP_OK(h, e2);
+    return 0;
+}
+
+int pte_comm_barrier(pte_engine *h) {
+    if (!h) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    double z = 0.0;
+    return pte_comm_allreduce(h, &z, 1, 1);
+}
+
+int pte_comm_allgather(pte_engine *h, const void *send, int64_t bytes, void *recv) {
+    if (!h || !send || !recv || bytes < 0) return 1;
+    if (h->world == 1) { std::memmove(recv, send, (size_t)bytes); return 0; }
+    if (h->comm_kind != 1) return fail(h, "pte_comm_allgather: call pte_comm_init first");
+    if (bytes == 0) return 0;
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) return fail(h, "%s", err.c_str());
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    unsigned char *buf = nullptr;
+    HIP_OK(h, hipMalloc((void **)&buf, (size_t)bytes * (size_t)(h->world + 1)));
+    unsigned char *sb = buf + (size_t)bytes * (size_t)h->world;
+    hipError_t e1 = hipMemcpyAsync(sb, send, (size_t)bytes, hipMemcpyHostToDevice, h->stream);
+    ncclResult_t r = e1 == hipSuccess ? api->AllGather(sb, buf, (size_t)bytes, ncclUint8, h->nccl, h->stream) : ncclSuccess;
+    if (e1 == hipSuccess && r == ncclSuccess) e1 = hipMemcpyAsync(recv, buf, (size_t)bytes * (size_t)h->world, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    hipFree(buf);
+    if (r != ncclSuccess) return fail(h, "ncclAllGather failed: %s", api->GetErrorString(r));
+    HIP_OK(h, e1); HIP_OK(h, e2);
+    return 0;
+}
+
+// G engines of one process (engines[g] = rank g): the same kernels, the messages move by stream-ordered
+// device-to-device copies.  Cross-stream order per scan:
+//   pack(g)   waits for copied(g-1), copied(g+1) of the previous scan   (they read g's send buffers)
+//   copies(g) wait for pack(g-1) / pack(g+1) of this scan               (they read the neighbours' send buffers)
+int pte_group_run_scans(pte_engine *const *hs, int32_t G, int64_t first_scan, int64_t n_scans) {
+    if (!hs || G < 1 || !hs[0]) return fail(nullptr, "pte_group_run_scans: null argument");
+    pte_engine *h0 = hs[0];
+    for (int g = 0; g < G; ++g) {
+        pte_engine *h = hs[g];
+        if (!h) return fail(h0, "pte_group_run_scans: engine %d is null", g);
+        if (h->world != G || h->rank != g || h->N != h0->N || h->d != h0->d)
+            return fail(h0, "pte_group_run_scans: engines[%d] must be rank %d of a world of %d over the same chains (got rank %d of %d)", g, g, G, h->rank, h->world);
+        if (h->comm_kind != 0) return fail(h0, "pte_group_run_scans: engine %d has an RCCL communicator; use pte_run_scans", g);
+        HIP_OK(h, hipSetDevice(h->cfg.device));
+        if (ensure_msg_buffers(h)) { h0->err = h->err; return 1; }
+        if (!h->ev_pack) HIP_OK(h, hipEventCreateWithFlags(&h->ev_pack, hipEventDisableTiming));
+        if (!h->ev_copied) HIP_OK(h, hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming));
+    }
+    const size_t bytes = sizeof(double) * (size_t)(h0->d + 8);
+    std::vector<int32_t> act((size_t)(2 * G));
+    for (int64_t s = first_scan; s < first_scan + n_scans; ++s) {
+        for (int g = 0; g < G; ++g) {
+            pte_engine *h = hs[g];
+            HIP_OK(h, hipSetDevice(h->cfg.device));
+            if (g > 0) HIP_OK(h, hipStreamWaitEvent(h->stream, hs[g - 1]->ev_copied, 0));
+            if (g + 1 < G) HIP_OK(h, hipStreamWaitEvent(h->stream, hs[g + 1]->ev_copied, 0));
+            if (pte_shard_scan_begin(h, s, &act[2 * g])) { if (h != h0) h0->err = h->err; return 1; }
+            HIP_OK(h, hipEventRecord(h->ev_pack, h->stream));
+        }
+        for (int g = 0; g < G; ++g) {
+            pte_engine *h = hs[g];
+            HIP_OK(h, hipSetDevice(h->cfg.device));
+            if (act[2 * g]) {                     // my recv_lo <- lower neighbour's send_hi
+                HIP_OK(h, hipStreamWaitEvent(h->stream, hs[g - 1]->ev_pack, 0));
+                HIP_OK(h, hipMemcpyAsync(h->msg_recv[0], hs[g - 1]->msg_send[1], bytes, hipMemcpyDefault, h->stream));
+            }
+            if (act[2 * g + 1]) {                 // my recv_hi <- upper neighbour's send_lo
+                HIP_OK(h, hipStreamWaitEvent(h->stream, hs[g + 1]->ev_pack, 0));
+                HIP_OK(h, hipMemcpyAsync(h->msg_recv[1], hs[g + 1]->msg_send[0], bytes, hipMemcpyDefault, h->stream));
+            }
+            HIP_OK(h, hipEventRecord(h->ev_copied, h->stream));
+            if (pte_shard_scan_finish(h, s)) { if (h != h0) h0->err = h->err; return 1; }
+        }
+    }
+    int rc = 0;
+    for (int g = 0; g < G; ++g)
+        if (pte_shard_sync(hs[g], nullptr)) { if (hs[g] != h0) h0->err = hs[g]->err; rc = 1; }
+    return rc;
+}
+
+const char *pte_kernel_name(const pte_engine *h) {
+    if (!h) return "";
+    switch (h->cfg.explorer) {
+    case PTE_EXPLORER_TOY: return "k_explore_toy";
+    case PTE_EXPLORER_SLICE:
+        switch (h->slice_impl) {
+        case 1: return "k_explore_slice"; case 2: return "k_explore_slice2"; case 5: return "k_explore_slice5";
+        case 7: return "k_explore_slice7";
+        default: return h->K <= 256 * 11 ? "k_explore_slice8" : "k_explore_slice8_lds10k";
+        }
+    case PTE_EXPLORER_AUTOMALA: case PTE_EXPLORER_MALA: return "k_explore_automala";
+    case PTE_EXPLORER_ISING_METROPOLIS: {
+        const int64_t L = (int64_t)std::llround(std::sqrt((double)h->d));
+        return (L % 32 == 0 && h->ising_impl == 0) ? "k_explore_ising_spec" : (L % 32 == 0 && h->ising_impl == 1) ? "k_explore_ising_bits" : "k_explore_ising";
+    }
+    default: return "";
+    }
+}
+
 namespace {
 int refresh_funnel_stats(pte_engine *h) {
     const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
@@ -1059,6 +1312,18 @@ int pte_timing_reset(pte_engine *h, int enable) {
     time_collect(h);
     h->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     h->t_ms[0] = h->t_ms[1] = 0.0; h->t_n[0] = h->t_n[1] = 0;
+    h->t_samples[0].clear(); h->t_samples[1].clear();
+    return 0;
+}
+int pte_timing_get_samples(const pte_engine *hc, int kernel, double *out_ms, int64_t capacity, int64_t *n_out) {
+    pte_engine *h = const_cast<pte_engine *>(hc);
+    if (!h || kernel < 0 || kernel > 1 || !n_out) return 1;
+    hipSetDevice(h->cfg.device);
+    hipStreamSynchronize(h->stream);
+    time_collect(h);
+    const int64_t n = (int64_t)h->t_samples[kernel].size();
+    *n_out = n;
+    if (out_ms) for (int64_t i = 0; i < n && i < capacity; ++i) out_ms[i] = h->t_samples[kernel][(size_t)i];
     return 0;
 }
 int pte_timing_get(const pte_engine *hc, int kernel, double *total_ms, int64_t *launches) {

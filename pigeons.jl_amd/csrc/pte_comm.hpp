@@ -1,0 +1,85 @@
+// pte_comm.hpp -- RCCL reached at run time (dlopen), so that libpte.so has no link-time dependency on
+// librccl and shares whichever copy the host process already mapped (PyTorch-ROCm bundles its own
+// librccl.so with the same SONAME; a Julia host gets /opt/rocm/lib/librccl.so.1).
+//
+// Only the point-to-point pair that the boundary exchange needs (ncclSend / ncclRecv inside one group on
+// the engine's stream) plus the three small collectives a host without MPI wants around a round
+// (barrier = all-reduce of one word, all-reduce MAX for timing, all-gather of the reduced recorders).
+// This is what replaces the reference's MPI transport, src/mpi_utils/Entangler.jl:118-180 (`transmit!`)
+// and :188-251 (`all_reduce_deterministically` -- here recorders are keyed by chain / pair, so a plain
+// gather in rank order is already deterministic).
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <string>
+
+namespace pte {
+
+struct RcclApi {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    std::string where;
+};
+
+// Returns nullptr and fills `err` when no RCCL can be mapped.  Search order: a copy already in the process
+// (RTLD_NOLOAD by SONAME), $PTE_RCCL_LIB, the loader's search path, /opt/rocm/lib.
+inline RcclApi *rccl_api(std::string &err) {
+    static RcclApi api;
+    static bool tried = false;
+    static std::string first_err;
+    if (api.lib) return &api;
+    if (tried) { err = first_err; return nullptr; }
+    tried = true;
+    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    std::string where = "librccl.so.1 (already mapped)";
+    if (!lib) {
+        const char *env = std::getenv("PTE_RCCL_LIB");
+        const char *cands[] = {env, "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+        for (const char *c : cands) {
+            if (!c || !*c) continue;
+            lib = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+            if (lib) { where = c; break; }
+        }
+    }
+    if (!lib) {
+        const char *e = dlerror();
+        first_err = std::string("RCCL is not available (dlopen librccl.so.1: ") + (e ? e : "not found") + ")";
+        err = first_err;
+        return nullptr;
+    }
+    bool ok = true;
+    auto sym = [&](const char *name) { void *p = dlsym(lib, name); if (!p) { ok = false; first_err = std::string("RCCL lacks symbol ") + name; } return p; };
+#define PTE_RCCL_SYM(field, name) api.field = reinterpret_cast<decltype(api.field)>(sym(name))
+    PTE_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+    PTE_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+    PTE_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    PTE_RCCL_SYM(CommCount, "ncclCommCount");
+    PTE_RCCL_SYM(Send, "ncclSend");
+    PTE_RCCL_SYM(Recv, "ncclRecv");
+    PTE_RCCL_SYM(GroupStart, "ncclGroupStart");
+    PTE_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+    PTE_RCCL_SYM(AllReduce, "ncclAllReduce");
+    PTE_RCCL_SYM(AllGather, "ncclAllGather");
+    PTE_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+    PTE_RCCL_SYM(GetVersion, "ncclGetVersion");
+#undef PTE_RCCL_SYM
+    if (!ok) { err = first_err; return nullptr; }
+    api.lib = lib;
+    api.where = where;
+    return &api;
+}
+
+}  // namespace pte

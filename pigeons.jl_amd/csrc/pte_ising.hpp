@@ -140,6 +140,7 @@ namespace pte {
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned lds_word(const unsigned *w, int i) { return (unsigned)__builtin_amdgcn_readfirstlane((int)w[i]); }
 
+#ifdef PTE_TEST_KERNELS   // scalar bit-packed sweep: dominated by k_explore_ising_spec, kept in libpte_test.so for A/B parity
 __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingParams ip) {
     extern __shared__ unsigned words[];
     const int lane = lane_id();
@@ -252,6 +253,8 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
     if (lane == 0) { e.suff[slot] = (double)spp; e.rng[2 * slot] = seed; }
     record_after_explore(e, cl, c, slot, lane, lp_before, (double)spp, 0.0);
 }
+
+#endif  // PTE_TEST_KERNELS
 
 // ---------------------------------------------------------------------------------------------
 // k_explore_ising_spec: the bit-packed sweep with the 64 lanes as hypotheses, the way k_explore_slice7/8

@@ -13,7 +13,10 @@ LIB_PATH = os.environ.get("PTE_LIB") or os.path.join(PKG_ROOT, "lib", "libpte.so
 TARGET_MVN_SCALED_PRECISION, TARGET_TEST_SWAPPER, TARGET_FUNNEL, TARGET_ISING = 0, 1, 2, 3
 EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA, EXPLORER_ISING_METROPOLIS, EXPLORER_MALA = 0, 1, 2, 3, 4, 5
 RECORD_ROUND_TRIP, RECORD_INDEX_PROCESS, RECORD_ONLINE, RECORD_TRACES, RECORD_ENERGY_AC1, RECORD_TRACES_EXTENDED = 1, 2, 4, 8, 16, 32
-ABI_VERSION = 1
+ABI_VERSION = 2
+KERNEL_DEFAULT, KERNEL_SLICE_SEQUENTIAL, KERNEL_ISING_BITS, KERNEL_ISING_BYTES = 0, 1, 101, 102
+COMM_ID_BYTES = 128
+TEST_LIB_PATH = os.path.join(PKG_ROOT, "lib", "libpte_test.so")    # -DPTE_TEST_KERNELS build: every kernel generation (parity tests, bisecting)
 
 
 class PteConfig(C.Structure):
@@ -32,6 +35,7 @@ class PteConfig(C.Structure):
         ("am_p0", C.c_double), ("am_p1", C.c_double),
         ("am_preconditioner", C.c_int32),
         ("rank", C.c_int32), ("world_size", C.c_int32), ("explorer2", C.c_int32), ("n_chains_variational", C.c_int64),
+        ("debug_kernel", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -46,26 +50,28 @@ EXPORTS = [
     "pte_get_swap_acceptance", "pte_get_log_sum_ratio", "pte_get_round_trip",
     "pte_get_index_process", "pte_get_explorer_stats", "pte_get_automala_stats",
     "pte_get_online", "pte_get_state", "pte_set_state",
-    "pte_timing_reset", "pte_timing_get", "pte_test_rng_fill", "pte_test_sqr_norm",
+    "pte_timing_reset", "pte_timing_get", "pte_timing_get_samples", "pte_test_rng_fill", "pte_test_sqr_norm",
     "pte_shard_info", "pte_swap_begin", "pte_swap_finish", "pte_boundary_payload_bytes",
     "pte_boundary_export", "pte_boundary_import", "pte_get_index_process_shard", "pte_get_replica_ids",
     "pte_get_stream", "pte_shard_message_bytes", "pte_shard_set_buffers", "pte_shard_scan_begin",
     "pte_shard_scan_finish", "pte_shard_sync",
     "pte_get_online_log_density", "pte_get_energy_ac1", "pte_get_traces", "pte_set_variational_reference",
+    "pte_comm_unique_id", "pte_comm_init", "pte_comm_destroy", "pte_comm_info", "pte_comm_barrier",
+    "pte_comm_allreduce", "pte_comm_allgather", "pte_group_run_scans", "pte_kernel_name",
 ]
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load libpte.so; raise PteError (never fall back) if it is not built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(path=None):
+    """Load libpte.so (or the build at `path`, e.g. TEST_LIB_PATH); raise PteError -- never fall back -- if it is missing."""
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise PteError(
             "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
     try:
         # PyTorch-ROCm bundles its own libamdhip64; loading it FIRST makes libpte bind to the same HIP
         # runtime, so that torch device tensors / RCCL and the engine can share streams and pointers in
@@ -73,7 +79,7 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     dp, ip, up = C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
     vp = C.c_void_p
     L.pte_default_config.argtypes = [C.POINTER(PteConfig)]
@@ -99,6 +105,7 @@ def load():
     L.pte_set_state.argtypes = [vp, dp, ip, up]
     L.pte_timing_reset.argtypes = [vp, C.c_int]
     L.pte_timing_get.argtypes = [vp, C.c_int, dp, ip]
+    L.pte_timing_get_samples.argtypes = [vp, C.c_int, dp, C.c_int64, ip]
     L.pte_test_rng_fill.argtypes = [C.c_int32, up, C.c_int32, C.c_int64, dp]
     L.pte_test_sqr_norm.argtypes = [C.c_int32, dp, C.c_int64, C.c_int64, dp]
     i32p = C.POINTER(C.c_int32)
@@ -123,8 +130,19 @@ def load():
     L.pte_shard_scan_begin.argtypes = [vp, C.c_int64, i32p]
     L.pte_shard_scan_finish.argtypes = [vp, C.c_int64]
     L.pte_shard_sync.argtypes = [vp, ip]
+    u8p = C.POINTER(C.c_uint8)
+    L.pte_comm_unique_id.argtypes = [u8p]
+    L.pte_comm_init.argtypes = [vp, u8p]
+    L.pte_comm_destroy.argtypes = [vp]
+    L.pte_comm_info.argtypes = [vp, i32p, i32p, ip]
+    L.pte_comm_barrier.argtypes = [vp]
+    L.pte_comm_allreduce.argtypes = [vp, dp, C.c_int64, C.c_int32]
+    L.pte_comm_allgather.argtypes = [vp, C.c_void_p, C.c_int64, C.c_void_p]
+    L.pte_group_run_scans.argtypes = [C.POINTER(vp), C.c_int32, C.c_int64, C.c_int64]
+    L.pte_kernel_name.argtypes = [vp]
+    L.pte_kernel_name.restype = C.c_char_p
     for name in EXPORTS:
-        if name not in ("pte_last_error", "pte_boundary_payload_bytes", "pte_get_stream", "pte_shard_message_bytes"):
+        if name not in ("pte_last_error", "pte_boundary_payload_bytes", "pte_get_stream", "pte_shard_message_bytes", "pte_kernel_name"):
             getattr(L, name).restype = C.c_int
-    _lib = L
+    _libs[path] = L
     return L

@@ -24,8 +24,8 @@ def _up(a):
 
 
 class Engine:
-    def __init__(self, **kw):
-        self.L = _lib.load()
+    def __init__(self, test_build=False, **kw):
+        self.L = _lib.load(_lib.TEST_LIB_PATH if test_build else None)   # test_build: libpte_test.so (every kernel generation)
         cfg = PteConfig()
         self.L.pte_default_config(C.byref(cfg))
         tp = kw.pop("target_params", None)
@@ -183,6 +183,46 @@ class Engine:
         self._chk(self.L.pte_shard_sync(self.h, _ip(n)))
         return n
 
+    # --- transport behind the ABI (include/pte.h: pte_comm_*): RCCL send/recv enqueued by the library itself
+    def comm_init(self, id_bytes):
+        """Collective over the ranks: ncclCommInitRank with the id rank 0 obtained from comm_unique_id()."""
+        buf = (C.c_uint8 * _lib.COMM_ID_BYTES).from_buffer_copy(bytes(id_bytes))
+        self._chk(self.L.pte_comm_init(self.h, buf))
+
+    def comm_destroy(self):
+        self._chk(self.L.pte_comm_destroy(self.h))
+
+    def comm_info(self):
+        """(kind, n_ranks_seen, boundary_swaps[2])"""
+        k = np.zeros(1, dtype=np.int32); n = np.zeros(1, dtype=np.int32); b = np.zeros(2, dtype=np.int64)
+        i32p = C.POINTER(C.c_int32)
+        self._chk(self.L.pte_comm_info(self.h, k.ctypes.data_as(i32p), n.ctypes.data_as(i32p), _ip(b)))
+        return int(k[0]), int(n[0]), b
+
+    def comm_barrier(self):
+        self._chk(self.L.pte_comm_barrier(self.h))
+
+    def comm_allreduce(self, values, op="max"):
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._chk(self.L.pte_comm_allreduce(self.h, _dp(v), v.size, 0 if op == "max" else 1))
+        return v
+
+    def comm_allgather_bytes(self, payload):
+        """All ranks obtain [payload of rank 0, payload of rank 1, ...]; payloads may differ in length."""
+        world = int(self.cfg.world_size)
+        lens = np.zeros(world)
+        lens[int(self.cfg.rank)] = len(payload)
+        lens = self.comm_allreduce(lens, op="sum").astype(np.int64)
+        m = int(lens.max())
+        send = np.zeros(max(m, 1), dtype=np.uint8)
+        send[:len(payload)] = np.frombuffer(payload, dtype=np.uint8)
+        recv = np.zeros(max(m, 1) * world, dtype=np.uint8)
+        self._chk(self.L.pte_comm_allgather(self.h, send.ctypes.data_as(C.c_void_p), max(m, 1), recv.ctypes.data_as(C.c_void_p)))
+        return [recv[r * max(m, 1): r * max(m, 1) + int(lens[r])].tobytes() for r in range(world)]
+
+    def kernel_name(self):
+        return (self.L.pte_kernel_name(self.h) or b"").decode()
+
     def explorer_stats(self):
         am = np.zeros(self.K); ss = np.zeros(self.K)
         an = np.zeros(self.K, dtype=np.int64); sn = np.zeros(self.K, dtype=np.int64)
@@ -247,6 +287,35 @@ class Engine:
         ms = np.zeros(1); n = np.zeros(1, dtype=np.int64)
         self._chk(self.L.pte_timing_get(self.h, kernel, _dp(ms), _ip(n)))
         return float(ms[0]), int(n[0])
+
+
+def _timing_samples(self, kernel):
+    """per-launch durations (ms) of kernel 0 = explore / 1 = swap since the last timing_reset"""
+    n = np.zeros(1, dtype=np.int64)
+    self._chk(self.L.pte_timing_get_samples(self.h, kernel, None, 0, _ip(n)))
+    out = np.zeros(max(int(n[0]), 1))
+    self._chk(self.L.pte_timing_get_samples(self.h, kernel, _dp(out), out.size, _ip(n)))
+    return out[:int(n[0])]
+
+
+Engine.timing_samples = _timing_samples
+
+
+def comm_unique_id():
+    """128 opaque bytes (ncclGetUniqueId) that rank 0 hands to every rank before Engine.comm_init."""
+    L = _lib.load()
+    buf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+    if L.pte_comm_unique_id(buf) != 0:
+        raise PteError(L.pte_last_error(None).decode())
+    return bytes(buf)
+
+
+def group_run_scans(engines, first_scan, n_scans):
+    """pte_group_run_scans: G shard engines of this process (engines[g] = rank g), messages by device copies."""
+    L = engines[0].L
+    arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+    if L.pte_group_run_scans(arr, len(engines), first_scan, n_scans) != 0:
+        raise PteError(L.pte_last_error(engines[0].h).decode())
 
 
 def test_rng_fill(seed_gamma, kind, n, device=0):

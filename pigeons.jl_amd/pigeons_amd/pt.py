@@ -300,10 +300,16 @@ class PT:
     Sharding (not in the reference's PT; replaces its MPI `EntangledReplicas`):
       n_shards=G           G chain-shards driven from this process (LoopbackShards; single-GPU tests;
                            device_messages=True: the device-resident exchange kernels of the RCCL path)
-      rank=r, world=G      this process owns shard r of G (DistShard over torch.distributed)
+                           transport="group": the library's own pte_group_run_scans
+      rank=r, world=G      this process owns shard r of G.  HIP engines: RcclShard -- the boundary exchange is RCCL
+                           send/recv inside libpte (pte_comm_init; comm_id = the 128-byte id if the caller already
+                           distributed it, else it is broadcast over torch.distributed).  transport="host" (and
+                           engines without comm_init: the CPU tests' oracle shards): DistShard, host-driven over gloo.
+    debug_kernel           pte_config.debug_kernel (0 = the default kernel)
     """
 
-    def __init__(self, inputs: Inputs, n_shards=1, rank=0, world=1, dist_device=None, engine_factory=None, device_messages=False):
+    def __init__(self, inputs: Inputs, n_shards=1, rank=0, world=1, dist_device=None, engine_factory=None, device_messages=False,
+                 transport=None, comm_id=None, debug_kernel=0):
         self.inputs = inputs
         target = inputs.target
         explorer = inputs.explorer if inputs.explorer is not None else default_explorer(target)
@@ -380,15 +386,23 @@ class PT:
         else:
             kw.update(explorer_kw(explorer))
         make = engine_factory or Engine
+        if debug_kernel:
+            kw.update(debug_kernel=debug_kernel)
+            if debug_kernel not in (_lib.KERNEL_SLICE_SEQUENTIAL, _lib.KERNEL_ISING_BYTES):
+                kw.update(test_build=True)              # the dominated generations live in libpte_test.so only
         self.shards = None
         if n_shards > 1:
             from .sharded import LoopbackShards
-            self.shards = LoopbackShards([make(rank=g, world_size=n_shards, **kw) for g in range(n_shards)], device_messages=device_messages)
+            self.shards = LoopbackShards([make(rank=g, world_size=n_shards, **kw) for g in range(n_shards)], device_messages=device_messages,
+                                         transport=transport)
             self.replicas = self.shards.engines[0]
         elif world > 1:
-            from .sharded import DistShard
+            from .sharded import DistShard, RcclShard
             self.replicas = make(rank=rank, world_size=world, **kw)
-            self.shards = DistShard(self.replicas, rank, world, device=dist_device)
+            if transport != "host" and hasattr(self.replicas, "comm_init"):
+                self.shards = RcclShard(self.replicas, rank, world, id_bytes=comm_id)
+            else:
+                self.shards = DistShard(self.replicas, rank, world, device=dist_device)
         else:
             self.replicas = make(**kw)
 

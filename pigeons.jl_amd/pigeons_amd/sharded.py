@@ -8,16 +8,19 @@ a replica owns travels with it, so the output is identical for any G -- the refe
 "parallelism invariance" (docs/src/distributed.md:37-58; distributed swap! src/swap/swap.jl:79-102,
 which instead shards by replica and moves chain labels with 4 any-to-any transmits per scan).
 
-Two transports drive the same per-shard calls (include/pte.h: pte_swap_begin / pte_swap_finish /
-pte_boundary_export / pte_boundary_import):
-  * LoopbackShards -- G engines in ONE process (tests on a single GPU; bytes move by plain copies);
-  * DistShard      -- one engine per process, torch.distributed point-to-point between neighbour
-                      ranks (backend nccl == RCCL over xGMI for device payloads; gloo on CPU).
-With the nccl backend DistShard uses the device-resident variant (pte_shard_scan_begin / _finish): the
-boundary SwapStat and, speculatively, the replica payload travel in ONE message per active side and
-scan, RCCL send/recv are enqueued on the engine's HIP stream, the receiver decides and applies the
-payload on the device -- no host synchronisation inside the scan loop.  LoopbackShards(device_messages=
-True) drives the same kernels on one GPU (device-to-device copies) for the parity tests.
+Drivers (all produce bit-identical results):
+  * RcclShard      -- production, one engine per process / GPU.  The transport lives BEHIND the C ABI
+                      (include/pte.h: pte_comm_init + pte_run_scans): libpte enqueues ncclSend / ncclRecv of
+                      ONE message per active side and scan {SwapStat, speculative payload} on the engine's
+                      own HIP stream between its pack and decide kernels -- no host synchronisation inside
+                      the scan loop, no torch.distributed on the data path (this replaces the reference's
+                      src/mpi_utils/Entangler.jl).  Python only hands the 128-byte communicator id around.
+  * LoopbackShards -- G engines in ONE process (tests on a single GPU): transport="group" is the library's
+                      pte_group_run_scans (stream-ordered device copies, same kernels as RcclShard);
+                      device_messages=True drives the same kernels step by step from Python;
+                      default: the two-phase calls with host copies.
+  * DistShard      -- host-driven two-phase exchange over torch.distributed point-to-point (gloo); this is
+                      what the CPU tests run with oracle-backed shards (world_size 2).
 A shard "engine" is anything with the Engine methods used below (the HIP Engine in production; the
 oracle-backed shard in the CPU tests).
 """
@@ -83,8 +86,9 @@ def local_reduced(eng):
 class LoopbackShards:
     """G shard engines in one process, run scan-synchronously; boundary bytes move by host copies."""
 
-    def __init__(self, engines, device_messages=False):
+    def __init__(self, engines, device_messages=False, transport=None):
         self.engines = list(engines)
+        self.transport = transport                      # "group": pte_group_run_scans (the library drives the G engines)
         self.G = len(self.engines)
         self.N = self.engines[0].N
         self.d = self.engines[0].d
@@ -118,6 +122,11 @@ class LoopbackShards:
         self.n_boundary_swaps = int(sum(e.shard_sync()[1] for e in E))
 
     def run_scans(self, first_scan, n_scans):
+        if self.transport == "group":
+            from .engine import group_run_scans
+            group_run_scans(self.engines, first_scan, n_scans)
+            self.n_boundary_swaps = int(sum(e.comm_info()[2].sum() for e in self.engines)) // 2   # both sides count an applied swap
+            return
         if self.device_messages:
             return self._run_scans_device(first_scan, n_scans)
         E, G = self.engines, self.G
@@ -166,8 +175,76 @@ class LoopbackShards:
         return x, chain, rng
 
 
+class RcclShard:
+    """One shard per process; the boundary exchange is RCCL send/recv enqueued by libpte itself (pte_comm_*).
+
+    `id_bytes`: the communicator id of rank 0's comm_unique_id(), already distributed by the caller; or
+    `bcast(obj_or_None) -> obj`: any broadcast-from-rank-0 callable (default: torch.distributed's, when a process
+    group exists).  Only these 128 bytes ever go through the host-side launcher."""
+
+    def __init__(self, engine, rank, world, id_bytes=None, bcast=None):
+        from .engine import comm_unique_id
+        self.e, self.rank, self.world = engine, rank, world
+        self.N, self.d = engine.N, engine.d
+        self.n_boundary_swaps = 0
+        if id_bytes is None:
+            if bcast is None:
+                import torch.distributed as dist
+                if not dist.is_initialized():
+                    raise RuntimeError("RcclShard needs id_bytes, a bcast callable, or an initialised torch.distributed group")
+
+                def bcast(obj):
+                    box = [obj]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+            msg = None
+            if rank == 0:
+                try:
+                    msg = ("ok", comm_unique_id())
+                except Exception as exc:                  # every rank must fail, not only rank 0
+                    msg = ("error", repr(exc))
+            kind, val = bcast(msg)
+            if kind != "ok":
+                raise RuntimeError("rank 0 could not create the RCCL communicator id: %s" % val)
+            id_bytes = val
+        engine.comm_init(id_bytes)                       # collective: ncclCommInitRank
+        self.n_ranks_seen = engine.comm_info()[1]
+
+    def run_scans(self, first_scan, n_scans):
+        self.e.run_scans(first_scan, n_scans)            # explore + swap + boundary exchange, all inside libpte
+        self.n_boundary_swaps = int(self.e.comm_info()[2].sum())
+
+    def barrier(self):
+        self.e.comm_barrier()
+
+    def allreduce_max(self, values):
+        return self.e.comm_allreduce(values, "max")
+
+    def _allgather(self, obj):
+        import pickle
+        return [pickle.loads(b) for b in self.e.comm_allgather_bytes(pickle.dumps(obj, protocol=4))]
+
+    def reduce(self):
+        """All ranks obtain the same global reduced recorders (all-gather of the local slices, rank order)."""
+        return combine_reduced(self._allgather(local_reduced(self.e)), self.N, self.d)
+
+    def set_schedule(self, betas):
+        self.e.set_schedule(betas)
+
+    def states(self):
+        xs, cs, rs = self.e.states()
+        parts = self._allgather((self.e.replica_ids(), xs, cs, rs))
+        N, d = self.N, self.d
+        x = np.zeros((N, d)); chain = np.zeros(N, dtype=np.int64); rng = np.zeros((N, 2), dtype=np.uint64)
+        for ids, xx, cc, rr in parts:
+            x[ids] = xx; chain[ids] = cc; rng[ids] = rr
+        return x, chain, rng
+
+
 class DistShard:
-    """One shard per process; neighbours talk through torch.distributed point-to-point."""
+    """One shard per process; the HOST moves the boundary bytes between the two phases of the swap through
+    torch.distributed point-to-point (gloo).  Three host synchronisations per scan -- the CPU tests' driver
+    (oracle-backed shards) and the fallback of a host that has no RCCL; production uses RcclShard."""
 
     def __init__(self, engine, rank, world, device=None, group=None):
         import torch
@@ -183,41 +260,6 @@ class DistShard:
         self.stat_send = [torch.zeros(2, dtype=torch.float64, device=self.device) for _ in range(2)]
         self.stat_recv = [torch.zeros(2, dtype=torch.float64, device=self.device) for _ in range(2)]
         self.n_boundary_swaps = 0
-        # device-resident exchange: RCCL ops ordered on the engine's own HIP stream
-        import os
-        self.stream_ordered = (self.on_device and dist.get_backend(group) == "nccl" and hasattr(engine, "shard_scan_begin")
-                               and os.environ.get("PTE_DIST_HOST_DRIVEN", "0") != "1")
-        if self.stream_ordered:
-            try:
-                mw = engine.message_words()
-                self.msg = [torch.zeros(mw, dtype=torch.float64, device=self.device) for _ in range(4)]   # send_lo, recv_lo, send_hi, recv_hi
-                engine.shard_set_buffers(*[t.data_ptr() for t in self.msg])
-                self.stream = torch.cuda.ExternalStream(engine.stream_ptr(), device=self.device)
-                self.debug_sync = os.environ.get("PTE_DIST_SYNC", "0") == "1"
-            except Exception as exc:                    # keep the run alive on the host-driven exchange (same results)
-                import warnings
-                warnings.warn("stream-ordered boundary exchange unavailable (%r); using the host-driven exchange" % (exc,))
-                self.stream_ordered = False
-
-    def _run_scans_stream_ordered(self, first_scan, n_scans):
-        e, torch, dist = self.e, self.torch, self.dist
-        with torch.cuda.stream(self.stream):
-            for s in range(first_scan, first_scan + n_scans):
-                active = e.shard_scan_begin(s)           # explore + SwapStats + pack, enqueued
-                ops = []
-                for sd in (0, 1):
-                    if active[sd]:
-                        peer = self.rank - 1 if sd == 0 else self.rank + 1
-                        ops.append(dist.P2POp(dist.isend, self.msg[2 * sd], peer, self.group))
-                        ops.append(dist.P2POp(dist.irecv, self.msg[2 * sd + 1], peer, self.group))
-                if ops:
-                    for r in dist.batch_isend_irecv(ops):
-                        r.wait()                          # nccl: orders the current stream after the transfer, no host block
-                if self.debug_sync:
-                    torch.cuda.synchronize(self.device)
-                e.shard_scan_finish(s)                   # decide + conditional import, enqueued
-        n = e.shard_sync()
-        self.n_boundary_swaps = int(n[0] + n[1])
 
     def _exchange(self, sides, send, recv):
         dist = self.dist
@@ -231,8 +273,6 @@ class DistShard:
                 r.wait()
 
     def run_scans(self, first_scan, n_scans):
-        if self.stream_ordered:
-            return self._run_scans_stream_ordered(first_scan, n_scans)
         e, torch = self.e, self.torch
         for s in range(first_scan, first_scan + n_scans):
             e.explore(s)

@@ -48,15 +48,35 @@ def build(force=False):
     return LIB_PATH
 
 
-_lib = None
+def build_native():
+    """The oracle compiled for THIS machine's cores (-O3 -march=native; still -ffp-contract=off and no fast-math, so the
+    results stay bit-identical): bench.py's cpu_baseline leg.  Built where it runs -- a native build must not travel to a
+    box with other cores -- and named after the CPU it was built for."""
+    import hashlib
+    try:
+        info = open("/proc/cpuinfo").read()
+        key = "".join(ln for ln in info.splitlines(True) if ln.startswith(("model name", "flags")))[:20000]
+    except OSError:
+        key = "unknown"
+    out = os.path.join(ORACLE_DIR, "_build", "libpt_oracle_native_%s.so" % hashlib.sha1(key.encode()).hexdigest()[:10])
+    src = os.path.join(ORACLE_DIR, "pt_oracle.c")
+    if not os.path.exists(out) or os.path.getmtime(src) > os.path.getmtime(out):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.run(["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
+                        "-shared", "-o", out, src, "-lm"], check=True, capture_output=True, cwd=ORACLE_DIR)
+    return out
 
 
-def lib():
-    global _lib
-    if _lib is not None:
-        return _lib
-    build()
-    L = C.CDLL(LIB_PATH)
+_libs = {}
+
+
+def lib(path=None):
+    if path is None:
+        build()
+        path = LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    L = C.CDLL(path)
     dp, ip, up = C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
     L.po_rng_new.restype = Rng
     L.po_rng_new.argtypes = [C.c_uint64]
@@ -132,7 +152,7 @@ def lib():
     L.po_shard_replica_ids.argtypes = [C.c_void_p, ip]
     L.po_shard_index_process.restype = C.c_int64
     L.po_shard_index_process.argtypes = [C.c_void_p, ip, ip]
-    _lib = L
+    _libs[path] = L
     return L
 
 
@@ -179,8 +199,8 @@ class OracleRng:
 class OraclePT:
     """The reference's `pigeons()` loop restated on the CPU."""
 
-    def __init__(self, **kw):
-        self.L = lib()
+    def __init__(self, lib_path=None, **kw):
+        self.L = lib(lib_path)
         self.cfg = Config()
         self.L.po_default_config(C.byref(self.cfg))
         for k, v in kw.items():

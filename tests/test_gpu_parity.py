@@ -23,11 +23,11 @@ def P():
     return pigeons_amd
 
 
-def _mk(P, N, d, rounds, explorer, seed=1, record=None):
+def _mk(P, N, d, rounds, explorer, seed=1, record=None, debug_kernel=0):
     exp = {"toy": P.ToyExplorer(), "slice": P.SliceSampler()}[explorer]
     record = record or [P.round_trip, P.index_process, P.log_sum_ratio, P.online]
     pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=exp, seed=seed,
-                       record=record, show_report=False))
+                       record=record, show_report=False), debug_kernel=debug_kernel)
     ref = O.OraclePT(n_chains=N, dim=d, seed=seed, record_online=1,
                      explorer={"toy": O.EXPLORER_TOY, "slice": O.EXPLORER_SLICE}[explorer])
     return pt, ref
@@ -149,14 +149,30 @@ def test_slice_sampler_parity_d1024(P):
         _check_round(P, pt, ref)
 
 
-@pytest.mark.parametrize("impl", ["1", "2", "5", "7", "8"])
+@pytest.mark.parametrize("impl", [1, 2, 5, 7, 8])
 @pytest.mark.parametrize("N,d,rounds,seed", [(7, 64, 4, 2), (4, 65, 4, 3), (5, 3, 6, 1), (6, 200, 3, 7), (3, 1024, 2, 1)])
-def test_every_slice_kernel_version_matches_oracle(P, monkeypatch, impl, N, d, rounds, seed):
-    """All SliceSampler kernels (PTE_SLICE_IMPL selects; the default is the fastest) are the same function."""
-    monkeypatch.setenv("PTE_SLICE_IMPL", impl)
-    pt, ref = _mk(P, N, d, rounds, "slice", seed=seed)
+def test_every_slice_kernel_version_matches_oracle(P, impl, N, d, rounds, seed):
+    """All SliceSampler kernel generations are the same function.  pte_config.debug_kernel selects: 1 (the sequential
+    kernel) ships in libpte.so, 2 / 5 / 7 (and 8 named explicitly) only in the test build libpte_test.so."""
+    pt, ref = _mk(P, N, d, rounds, "slice", seed=seed, debug_kernel=impl)
+    assert pt.replicas.kernel_name() == {1: "k_explore_slice", 2: "k_explore_slice2", 5: "k_explore_slice5", 7: "k_explore_slice7", 8: "k_explore_slice8"}[impl]
     for _ in range(rounds):
         _check_round(P, pt, ref)
+
+
+def test_product_library_refuses_kernels_it_does_not_contain(P):
+    """libpte.so holds the default kernels and their exact fallbacks only; anything else fails loudly in pte_create
+    (nothing is selected through the environment)."""
+    from pigeons_amd.engine import Engine
+    from pigeons_amd import _lib
+    for dk in (2, 5, 7, 3, 99, _lib.KERNEL_ISING_BITS):
+        with pytest.raises(P.PteError, match="debug_kernel"):
+            Engine(n_chains=4, dim=8, explorer=_lib.EXPLORER_SLICE, debug_kernel=dk)
+    with pytest.raises(P.PteError, match="debug_kernel"):
+        Engine(n_chains=4, dim=8, explorer=_lib.EXPLORER_TOY, debug_kernel=1)
+    e = Engine(n_chains=4, dim=8, explorer=_lib.EXPLORER_SLICE, debug_kernel=_lib.KERNEL_SLICE_SEQUENTIAL)
+    assert e.kernel_name() == "k_explore_slice"
+    assert Engine(n_chains=4, dim=8, explorer=_lib.EXPLORER_SLICE).kernel_name() == "k_explore_slice8"
 
 
 @pytest.mark.parametrize("N,d,rounds", [(16, 128, 6), (5, 1024, 4), (33, 7, 6)])
@@ -340,7 +356,7 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)     # both ranks share cuda:0 (nccl refuses that)
 mk = lambda: P.Inputs(target=P.toy_mvn_target(70), n_chains=8, n_rounds=5, explorer=P.SliceSampler(), show_report=False,
                       record=[P.round_trip, P.index_process, P.log_sum_ratio])
-pt = P.PT(mk(), rank=rank, world=world, dist_device=torch.device("cuda", 0))   # device payload buffers
+pt = P.PT(mk(), rank=rank, world=world, dist_device=torch.device("cuda", 0), transport="host")   # host-driven two-phase exchange, device payload buffers
 one = P.PT(mk()) if rank == 0 else None
 ok = True
 for _ in range(5):
@@ -360,7 +376,7 @@ dist.destroy_process_group()
 
 
 def test_dist_shard_two_ranks_device_payloads(P, tmp_path):
-    """DistShard (the multi-GPU driver) with device-resident payload buffers, two ranks over gloo on one GPU."""
+    """DistShard (the host-driven two-phase driver) with device-resident payload buffers, two ranks over gloo on one GPU."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker.py"
@@ -375,20 +391,19 @@ def test_dist_shard_two_ranks_device_payloads(P, tmp_path):
     assert res["ok"] and res["boundary_swaps"] > 0, res
 
 
-NCCL_WORLD1_WORKER = r'''
+RCCL_WORLD1_WORKER = r'''
 import os, sys, json
 import numpy as np
 sys.path[:0] = [%(root)r, %(root)r + "/pigeons.jl_amd", %(root)r + "/tests"]
-import torch, torch.distributed as dist
 import pigeons_amd as P
-from pigeons_amd.sharded import DistShard
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from pigeons_amd.engine import comm_unique_id
 mk = lambda: P.Inputs(target=P.toy_mvn_target(70), n_chains=8, n_rounds=4, explorer=P.SliceSampler(), show_report=False,
                       record=[P.round_trip, P.index_process, P.log_sum_ratio])
-pt = P.PT(mk()); one = P.PT(mk())
-pt.shards = DistShard(pt.replicas, 0, 1, device=torch.device("cuda", 0))
-ok = bool(pt.shards.stream_ordered)
+one = P.PT(mk())
+from pigeons_amd.sharded import RcclShard
+pt = P.PT(mk())
+pt.shards = RcclShard(pt.replicas, 0, 1, id_bytes=comm_unique_id())       # ncclCommInitRank inside libpte, no torch.distributed
+ok = pt.shards.n_ranks_seen == 1 and pt.replicas.comm_info()[0] == 1
 for _ in range(4):
     P.next_round(pt); red = P.run_one_round(pt); P.adapt(pt, red)
     P.next_round(one); ra = P.run_one_round(one); P.adapt(one, ra)
@@ -396,24 +411,54 @@ for _ in range(4):
     ok &= bool(np.array_equal(ra.swap_acceptance_pr[0], red.swap_acceptance_pr[0]))
 x, chain, rng = pt.shards.states(); xa, ca, ga = one.replicas.states()
 ok &= bool(np.array_equal(x, xa) and np.array_equal(chain, ca) and np.array_equal(rng, ga))
-print(json.dumps({"ok": ok}))
-dist.destroy_process_group()
+pt.shards.barrier()
+ok &= float(pt.shards.allreduce_max([3.5])[0]) == 3.5
+print(json.dumps({"ok": ok, "torch_distributed_loaded": "torch.distributed" in sys.modules and sys.modules["torch.distributed"].is_initialized()}))
 '''
 
 
-def test_dist_shard_stream_ordered_driver_on_rccl_world1(P, tmp_path):
-    """The stream-ordered RCCL driver (engine kernels + collectives enqueued on the engine's HIP stream through
-    torch.cuda.ExternalStream) with a 1-rank nccl group: no peers, but the enqueue / sync / reduce plumbing runs."""
+def test_rccl_transport_behind_the_abi_world1(P, tmp_path):
+    # The RCCL transport of libpte (pte_comm_unique_id / pte_comm_init / collectives; RCCL mapped with dlopen) on a 1-rank
+    # communicator: no peers, but communicator creation, the sharded pte_run_scans entry, the gather plumbing run --
+    # and no torch.distributed process group exists anywhere in the process.
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker1.py"
-    script.write_text(NCCL_WORLD1_WORKER % {"root": root})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="1", RANK="0")
-    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    script.write_text(RCCL_WORLD1_WORKER % {"root": root})
+    p = subprocess.run([sys.executable, str(script)], env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert lines, (p.stdout[-2000:], p.stderr[-2000:])
-    assert json.loads(lines[-1])["ok"]
+    res = json.loads(lines[-1])
+    assert res["ok"] and not res["torch_distributed_loaded"], res
+
+
+@pytest.mark.parametrize("G,N,d,explorer", [(2, 8, 70, "slice"), (4, 8, 33, "slice"), (3, 9, 20, "toy"), (8, 16, 130, "slice"), (4, 4, 16, "slice")])
+def test_group_transport_equals_single_engine(P, G, N, d, explorer):
+    # pte_group_run_scans: G engines of one process driven by the library itself (stream-ordered device copies between the
+    # pack and decide kernels, cross-stream events) -- the kernels and the ordering of the RCCL path, bit-identical to G = 1.
+    exp = lambda: P.SliceSampler() if explorer == "slice" else P.ToyExplorer()
+    mk = lambda: P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=6, explorer=exp(), show_report=False, seed=5,
+                          record=[P.round_trip, P.index_process, P.log_sum_ratio])
+    one = P.PT(mk()); grp = P.PT(mk(), n_shards=G, transport="group")
+    for _ in range(6):
+        P.next_round(one); ra = P.run_one_round(one); P.adapt(one, ra)
+        P.next_round(grp); rb = P.run_one_round(grp); P.adapt(grp, rb)
+        assert np.array_equal(ra.index_process, rb.index_process) and ra.round_trip == rb.round_trip
+        assert np.array_equal(ra.swap_acceptance_pr[0], rb.swap_acceptance_pr[0])
+        assert np.array_equal(ra.log_sum_ratio[0], rb.log_sum_ratio[0])
+    xa, ca, ga = one.replicas.states(); xb, cb, gb = grp.shards.states()
+    assert np.array_equal(xa, xb) and np.array_equal(ca, cb) and np.array_equal(ga, gb)
+    if N > G:
+        assert grp.shards.n_boundary_swaps > 0
+
+
+def test_sharded_run_scans_without_a_communicator_fails_loudly(P):
+    from pigeons_amd.engine import Engine
+    from pigeons_amd import _lib
+    e = Engine(n_chains=8, dim=8, explorer=_lib.EXPLORER_SLICE, rank=0, world_size=2)
+    with pytest.raises(P.PteError, match="pte_comm_init"):
+        e.run_scans(1, 2)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -595,20 +640,20 @@ def test_config5_ising_full_size_properties(P):
 
 
 @pytest.mark.parametrize("L,N", [(32, 5), (64, 4)])
-def test_ising_bitpacked_kernel_equals_byte_kernel_and_oracle(P, L, N, monkeypatch):
-    """L % 32 == 0 selects the lane-speculative bit-packed kernel; PTE_ISING_IMPL = bits / bytes select the scalar
-    bit-packed and the byte-lattice kernels.  All three are the same function."""
-    mk = lambda: P.PT(P.Inputs(target=P.IsingLogPotential(0.5, L), n_chains=N, n_rounds=3, show_report=False, seed=7,
-                               record=[P.round_trip, P.index_process, P.log_sum_ratio]))
+def test_ising_bitpacked_kernel_equals_byte_kernel_and_oracle(P, L, N):
+    """L % 32 == 0 selects the lane-speculative bit-packed kernel; debug_kernel = PTE_KERNEL_ISING_BITS / _BYTES select the
+    scalar bit-packed (test build) and the byte-lattice kernels.  All three are the same function."""
+    from pigeons_amd import _lib
+    mk = lambda dk: P.PT(P.Inputs(target=P.IsingLogPotential(0.5, L), n_chains=N, n_rounds=3, show_report=False, seed=7,
+                                  record=[P.round_trip, P.index_process, P.log_sum_ratio]), debug_kernel=dk)
     pts = {}
-    for impl in ("spec", "bits", "bytes"):
-        monkeypatch.setenv("PTE_ISING_IMPL", impl)
-        pts[impl] = mk()
+    for impl, dk in (("spec", 0), ("bits", _lib.KERNEL_ISING_BITS), ("bytes", _lib.KERNEL_ISING_BYTES)):
+        pts[impl] = mk(dk)
+        assert pts[impl].replicas.kernel_name() == {"spec": "k_explore_ising_spec", "bits": "k_explore_ising_bits", "bytes": "k_explore_ising"}[impl]
     ref = O.OraclePT(target=O.TARGET_ISING, explorer=O.EXPLORER_ISING, dim=L * L, p0=0.5, n_chains=N, seed=7, slice_n_passes=3)
     for _ in range(3):
         ref.run_round()
         for impl, x in pts.items():
-            monkeypatch.setenv("PTE_ISING_IMPL", impl)
             P.next_round(x); r = P.run_one_round(x); P.adapt(x, r)
             assert np.array_equal(r.index_process, ref.index_process()), impl
             np.testing.assert_allclose(P.stepping_stone_pair(x), ref.stepping_stone_pair(), rtol=RTOL)
@@ -841,34 +886,33 @@ def test_checkpoint_resume_equals_uninterrupted_run(P, tmp_path, name):
     assert np.array_equal(more.reduced_recorders.index_process, ra.index_process)
 
 
-@pytest.mark.parametrize("impl", ["1", "8"])
-def test_slice_parameters_off_the_defaults(P, monkeypatch, impl):
+@pytest.mark.parametrize("impl", [1, 0])
+def test_slice_parameters_off_the_defaults(P, impl):
     """w, p, n_passes away from the defaults (small p / w exercise the doubling budget and the exact path)."""
-    monkeypatch.setenv("PTE_SLICE_IMPL", impl)
     for w, p, n_passes in [(0.5, 1, 2), (2.0, 3, 1), (30.0, 20, 2)]:
         N, d, rounds = 5, 20, 4
         rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.online]
         pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=P.SliceSampler(w=w, p=p, n_passes=n_passes),
-                           record=rec, show_report=False))
+                           record=rec, show_report=False), debug_kernel=impl)
         ref = O.OraclePT(n_chains=N, dim=d, explorer=O.EXPLORER_SLICE, record_online=1, slice_w=w, slice_p=p, slice_n_passes=n_passes)
         for _ in range(rounds):
             _check_round(P, pt, ref)
 
 
-def test_slice_kernel_many_replicas_equals_sequential_kernel(P, monkeypatch):
+def test_slice_kernel_many_replicas_equals_sequential_kernel(P):
     """More than 256 x 11 replicas on one GPU run the default SliceSampler kernel with the 256-draw window (10 KB of LDS, 16
     resident replicas per CU); same bits as the plain sequential kernel (which the oracle pins at small sizes)."""
     def run(impl):
-        monkeypatch.setenv("PTE_SLICE_IMPL", impl)
         pt = P.PT(P.Inputs(target=P.toy_mvn_target(70), n_chains=3000, n_rounds=3, seed=11, explorer=P.SliceSampler(),
-                           record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False))
+                           record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False), debug_kernel=impl)
+        assert pt.replicas.kernel_name() == ("k_explore_slice" if impl == 1 else "k_explore_slice8_lds10k")
         out = []
         for _ in range(3):
             P.next_round(pt); red = P.run_one_round(pt); P.adapt(pt, red)
             out.append((red.index_process.copy(), red.swap_acceptance_pr[0].copy(), red.explorer_n_steps[0].copy()))
         return out, pt.replicas.states()
-    a, sa = run("1")
-    b, sb = run("8")
+    a, sa = run(1)
+    b, sb = run(0)
     for ra, rb in zip(a, b):
         for x, y in zip(ra, rb):
             assert np.array_equal(x, y)
@@ -892,12 +936,11 @@ def test_slice_special_states(P):
         _check_round(P, pt, ref)
 
 
-def test_slice_max_iter_error_is_raised_by_every_kernel(P, monkeypatch):
+def test_slice_max_iter_error_is_raised_by_every_kernel(P):
     """slice_shrink!'s "Maximum number of iterations reached" (SliceSampler.jl:179-185) with max_iter below the speculation depth."""
-    for impl in ["1", "8"]:
-        monkeypatch.setenv("PTE_SLICE_IMPL", impl)
+    for impl in [1, 0]:
         pt = P.PT(P.Inputs(target=P.toy_mvn_target(50), n_chains=4, n_rounds=6, explorer=P.SliceSampler(w=1000.0, max_iter=2),
-                           record=[P.log_sum_ratio], show_report=False))
+                           record=[P.log_sum_ratio], show_report=False), debug_kernel=impl)
         with pytest.raises(P.PteError, match="Maximum number of iterations"):
             for _ in range(6):
                 P.next_round(pt); P.run_one_round(pt)
