@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (weak) / in total (strong)")
     ap.add_argument("--explorer", default="slice", choices=["slice", "toy"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--round-trip-rounds", type=int, default=11,
+    ap.add_argument("--round-trip-rounds", type=int, default=15,
                     help="untimed leg after the timed region: rounds 1..R of the reference's round loop with schedule "
                          "adaptation; the round-trip rate is read off the last round (2^R scans).  0 = skip")
     return ap.parse_args()

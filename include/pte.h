@@ -30,6 +30,7 @@
 #define PTE_H
 
 #include <stdint.h>
+#include "pte_rng_policy.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -255,9 +256,15 @@ int pte_timing_get(const pte_engine *h, int kernel, double *total_ms, int64_t *l
 /* the individual launch durations behind pte_timing_get (min / median / max of the timed region); out_ms may be NULL */
 int pte_timing_get_samples(const pte_engine *h, int kernel, double *out_ms, int64_t capacity, int64_t *n_out);
 
+/* The conventions of Julia's Random stdlib that no fixture from a live Julia pins yet (include/pte_rng_policy.h: the
+ * ziggurat tail formula, the bit rand(rng, Bool) takes).  One word per device, read by every engine of this process on
+ * that device; the default is PTE_RNG_POLICY_DEFAULT.  Never read from the environment. */
+int pte_set_rng_policy(int32_t device, uint32_t policy);
+int pte_get_rng_policy(int32_t device, uint32_t *policy);
+
 /* RNG building blocks exposed for parity tests of the device samplers: fill `n` draws from the
  * stream (seed, gamma) on the device, in the reference's sequential order.
- * kind: 0 = rand (Float64 in [0,1)), 1 = randn, 2 = randexp.  Returns the advanced stream. */
+ * kind: 0 = rand (Float64 in [0,1)), 1 = randn, 2 = randexp, 3 = rand(rng, Bool) as 0.0 / 1.0.  Returns the advanced stream. */
 int pte_test_rng_fill(int32_t device, uint64_t *seed_gamma /*2, in-out*/, int32_t kind, int64_t n, double *out);
 /* sqr_norm of each row of x [rows][d] with the engine's fixed reduction tree. */
 int pte_test_sqr_norm(int32_t device, const double *x, int64_t rows, int64_t d, double *out);

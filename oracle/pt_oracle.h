@@ -33,6 +33,13 @@ po_rng   po_rng_split(po_rng *r);            /* split(rng)                      
 double   po_rand(po_rng *r);                 /* rand(rng)    :: Float64 in [0,1)   */
 double   po_randn(po_rng *r);                /* randn(rng)   (ziggurat)            */
 double   po_randexp(po_rng *r);              /* randexp(rng) (ziggurat)            */
+int      po_rand_bool_pub(po_rng *r);        /* rand(rng, Bool)                    */
+/* the oracle's own ziggurat tables (built at load time in binary128): which = 0 ki, 1 wi, 2 fi, 3 ke, 4 we, 5 fe */
+void     po_zig_table(int which, void *out /*256 x 8 bytes*/);
+void     po_zig_install(int which, const void *in /*256 x 8 bytes*/);
+/* include/pte_rng_policy.h: process-wide; returns != 0 on an invalid policy */
+int      po_set_rng_policy(uint32_t policy);
+uint32_t po_get_rng_policy(void);
 
 /* ---- numerics ------------------------------------------------------------ */
 double po_sqr_norm(const double *x, int64_t d);       /* fixed pairwise tree       */

@@ -1337,6 +1337,21 @@ int pte_timing_get(const pte_engine *hc, int kernel, double *total_ms, int64_t *
     return 0;
 }
 
+// include/pte_rng_policy.h: one word per device, read by every engine of this process on that device
+int pte_set_rng_policy(int32_t device, uint32_t policy) {
+    if (policy & ~PTE_RNG_POLICY_VALID_MASK) return fail(nullptr, "pte_set_rng_policy: invalid policy 0x%x", policy);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, "pte_set_rng_policy: no HIP device %d", device);
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_rng_policy), &policy, sizeof policy);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    return e == hipSuccess ? 0 : fail(nullptr, "pte_set_rng_policy: %s", hipGetErrorString(e));
+}
+int pte_get_rng_policy(int32_t device, uint32_t *policy) {
+    if (!policy) return 1;
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, "pte_get_rng_policy: no HIP device %d", device);
+    hipError_t e = hipMemcpyFromSymbol(policy, HIP_SYMBOL(g_rng_policy), sizeof *policy);
+    return e == hipSuccess ? 0 : fail(nullptr, "pte_get_rng_policy: %s", hipGetErrorString(e));
+}
+
 int pte_test_rng_fill(int32_t device, uint64_t *sg, int32_t kind, int64_t n, double *out) {
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, "pte_test_rng_fill: no HIP device");
     uint64_t *d_sg = nullptr; double *d_out = nullptr;

@@ -10,10 +10,17 @@
 
 #define ZIG_TABLE_ATTR __device__
 #include "zig_tables.h"
+#include "../../include/pte_rng_policy.h"
 
 namespace pte {
 
 constexpr uint64_t MASK52 = 0x000fffffffffffffULL;
+
+// include/pte_rng_policy.h: the conventions of Julia's Random that no fixture pins yet, one word per device, set by
+// pte_set_rng_policy (hipMemcpyToSymbol).  Read on the ziggurat tails (~3e-4 of the draws) and by the Bernoulli refresh only.
+__device__ unsigned g_rng_policy = PTE_RNG_POLICY_DEFAULT;
+__device__ __forceinline__ double zig_tail_neglog(double u) { return (g_rng_policy & PTE_RNG_TAIL_LOG1P) ? -log1p(-u) : -log(u); }
+__device__ __forceinline__ unsigned rng_bool_bit() { return PTE_RNG_POLICY_BOOL_BIT(g_rng_policy); }
 
 // ---- SplittableRandom (SplittableRandoms.jl 0.1 == Java SplittableRandom) --------------------
 // The k-th output of a stream is mix64(seed0 + k*gamma): counter based, so 64 lanes can
@@ -117,8 +124,8 @@ __device__ inline double randn_seq(SeqRng &r);
 __device__ inline double randn_unlikely(SeqRng &r, int idx, int64_t rabs, double x) {
     if (idx == 0) {
         for (;;) {
-            double xx = -ZIG_NOR_INV_R * log(r.rand());
-            double yy = -log(r.rand());
+            double xx = ZIG_NOR_INV_R * zig_tail_neglog(r.rand());
+            double yy = zig_tail_neglog(r.rand());
             if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? (-ZIG_NOR_R - xx) : (ZIG_NOR_R + xx);
         }
     } else if ((ZIG_FI[idx - 1] - ZIG_FI[idx]) * r.rand() + ZIG_FI[idx] < exp(-0.5 * x * x)) {
@@ -135,8 +142,8 @@ __device__ inline double randn_seq(SeqRng &r) {
         if ((uint64_t)rabs < ZIG_KI[idx]) return x;
         if (idx == 0) {
             for (;;) {
-                double xx = -ZIG_NOR_INV_R * log(r.rand());
-                double yy = -log(r.rand());
+                double xx = ZIG_NOR_INV_R * zig_tail_neglog(r.rand());
+                double yy = zig_tail_neglog(r.rand());
                 if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? (-ZIG_NOR_R - xx) : (ZIG_NOR_R + xx);
             }
         } else if ((ZIG_FI[idx - 1] - ZIG_FI[idx]) * r.rand() + ZIG_FI[idx] < exp(-0.5 * x * x)) {
@@ -151,7 +158,7 @@ __device__ inline double randexp_from_raw(SeqRng &r, uint64_t raw) {
         int idx = (int)(ri & 0xFF);
         double x = (double)ri * ZIG_WE[idx];
         if (ri < ZIG_KE[idx]) return x;
-        if (idx == 0) return ZIG_EXP_R - log(r.rand());
+        if (idx == 0) return ZIG_EXP_R + zig_tail_neglog(r.rand());
         if ((ZIG_FE[idx - 1] - ZIG_FE[idx]) * r.rand() + ZIG_FE[idx] < exp(-x)) return x;
         raw = r.next();
     }

@@ -57,7 +57,8 @@ __global__ __launch_bounds__(64) void k_explore_ising(EngineDev e, IsingParams i
 
     if (is_ref_chain(e, c)) {
         // iid_bernoulli!: site s (row-major, i outer / j inner) <- rand(rng, Bool) = low bit of draw s+1
-        for (int s = lane; s < d; s += 64) spins[s] = (unsigned char)(mix64(seed + (uint64_t)(s + 1) * gamma) & 1ull);
+        const unsigned bb = rng_bool_bit();              // include/pte_rng_policy.h (default 0: `% Bool`)
+        for (int s = lane; s < d; s += 64) spins[s] = (unsigned char)((mix64(seed + (uint64_t)(s + 1) * gamma) >> bb) & 1ull);
         seed += (uint64_t)d * gamma;
         __syncthreads();
         const long long spp = ising_recompute(spins, L, lane);
@@ -157,7 +158,8 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
     if (is_ref_chain(e, c)) {
         for (int wd = lane; wd < NW; wd += 64) {
             unsigned v = 0;
-            for (int t = 0; t < 32; ++t) v |= (unsigned)(mix64(seed + (uint64_t)(32 * wd + t + 1) * gamma) & 1ull) << t;
+            const unsigned bb = rng_bool_bit();
+            for (int t = 0; t < 32; ++t) v |= (unsigned)((mix64(seed + (uint64_t)(32 * wd + t + 1) * gamma) >> bb) & 1ull) << t;
             words[wd] = v;
         }
         seed += (uint64_t)d * gamma;
@@ -284,7 +286,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
 
     for (int wd = lane; wd < NW; wd += 64) {
         unsigned v = 0;
-        if (refresh) { for (int t = 0; t < 32; ++t) v |= (unsigned)(mix64(seed + (uint64_t)(32 * wd + t + 1) * gamma) & 1ull) << t; }
+        if (refresh) { const unsigned bb = rng_bool_bit(); for (int t = 0; t < 32; ++t) v |= (unsigned)((mix64(seed + (uint64_t)(32 * wd + t + 1) * gamma) >> bb) & 1ull) << t; }
         else         { for (int t = 0; t < 32; ++t) v |= (xrow[32 * wd + t] != 0.0 ? 1u : 0u) << t; }
         words[wd] = v;
     }

@@ -690,9 +690,13 @@ __global__ __launch_bounds__(256) void k_boundary_apply(EngineDev e, const doubl
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_test_rng(uint64_t *sg, int kind, int64_t n, double *out) {
     const int lane = lane_id();
-    if (kind == 0) {
+    if (kind == 0 || kind == 3) {
         uint64_t seed = sg[0], gamma = sg[1];
-        for (int64_t i = lane; i < n; i += 64) out[i] = u52_to_unit(mix64(seed + (uint64_t)(i + 1) * gamma));
+        const unsigned bb = rng_bool_bit();
+        for (int64_t i = lane; i < n; i += 64) {
+            const uint64_t raw = mix64(seed + (uint64_t)(i + 1) * gamma);
+            out[i] = kind == 0 ? u52_to_unit(raw) : (double)((raw >> bb) & 1ull);
+        }
         __syncthreads();
         if (lane == 0) sg[0] = seed + (uint64_t)n * gamma;
     } else if (kind == 1) {

@@ -16,6 +16,11 @@ RECORD_ROUND_TRIP, RECORD_INDEX_PROCESS, RECORD_ONLINE, RECORD_TRACES, RECORD_EN
 ABI_VERSION = 2
 KERNEL_DEFAULT, KERNEL_SLICE_SEQUENTIAL, KERNEL_ISING_BITS, KERNEL_ISING_BYTES = 0, 1, 101, 102
 COMM_ID_BYTES = 128
+RNG_TAIL_LOG1P = 1                      # include/pte_rng_policy.h
+
+
+def rng_bool_bit(k):
+    return (k & 63) << 8
 TEST_LIB_PATH = os.path.join(PKG_ROOT, "lib", "libpte_test.so")    # -DPTE_TEST_KERNELS build: every kernel generation (parity tests, bisecting)
 
 
@@ -58,6 +63,7 @@ EXPORTS = [
     "pte_get_online_log_density", "pte_get_energy_ac1", "pte_get_traces", "pte_set_variational_reference",
     "pte_comm_unique_id", "pte_comm_init", "pte_comm_destroy", "pte_comm_info", "pte_comm_barrier",
     "pte_comm_allreduce", "pte_comm_allgather", "pte_group_run_scans", "pte_kernel_name",
+    "pte_set_rng_policy", "pte_get_rng_policy",
 ]
 
 _libs = {}
@@ -139,6 +145,8 @@ def load(path=None):
     L.pte_comm_allreduce.argtypes = [vp, dp, C.c_int64, C.c_int32]
     L.pte_comm_allgather.argtypes = [vp, C.c_void_p, C.c_int64, C.c_void_p]
     L.pte_group_run_scans.argtypes = [C.POINTER(vp), C.c_int32, C.c_int64, C.c_int64]
+    L.pte_set_rng_policy.argtypes = [C.c_int32, C.c_uint32]
+    L.pte_get_rng_policy.argtypes = [C.c_int32, C.POINTER(C.c_uint32)]
     L.pte_kernel_name.argtypes = [vp]
     L.pte_kernel_name.restype = C.c_char_p
     for name in EXPORTS:

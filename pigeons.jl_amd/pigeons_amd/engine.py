@@ -301,6 +301,21 @@ def _timing_samples(self, kernel):
 Engine.timing_samples = _timing_samples
 
 
+def set_rng_policy(policy, device=0, test_build=False):
+    """include/pte_rng_policy.h: ziggurat tail formula / rand(rng, Bool) bit; one word per device and per loaded library."""
+    L = _lib.load(_lib.TEST_LIB_PATH if test_build else None)
+    if L.pte_set_rng_policy(device, policy) != 0:
+        raise PteError(L.pte_last_error(None).decode())
+
+
+def get_rng_policy(device=0):
+    L = _lib.load()
+    out = C.c_uint32(0)
+    if L.pte_get_rng_policy(device, C.byref(out)) != 0:
+        raise PteError(L.pte_last_error(None).decode())
+    return int(out.value)
+
+
 def comm_unique_id():
     """128 opaque bytes (ncclGetUniqueId) that rank 0 hands to every rank before Engine.comm_init."""
     L = _lib.load()

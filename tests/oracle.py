@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "_build", "libpt_oracle.so")
 
+ZIG_NAMES = ("ki", "wi", "fi", "ke", "we", "fe")
 TARGET_MVN, TARGET_TEST_SWAPPER, TARGET_FUNNEL, TARGET_ISING = 0, 1, 2, 3
 EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA, EXPLORER_ISING, EXPLORER_MALA = 0, 1, 2, 3, 4, 5
 
@@ -40,7 +41,7 @@ class Rng(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("pt_oracle.c", "pt_oracle.h", "zig_tables.h", "Makefile")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("pt_oracle.c", "pt_oracle.h", "Makefile")] + [os.path.join(ROOT, "include", "pte_rng_policy.h")]
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
@@ -63,7 +64,7 @@ def build_native():
     if not os.path.exists(out) or os.path.getmtime(src) > os.path.getmtime(out):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         subprocess.run(["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
-                        "-shared", "-o", out, src, "-lm"], check=True, capture_output=True, cwd=ORACLE_DIR)
+                        "-shared", "-o", out, src, "-lquadmath", "-lm"], check=True, capture_output=True, cwd=ORACLE_DIR)
     return out
 
 
@@ -87,6 +88,15 @@ def lib(path=None):
     for f in ("po_rand", "po_randn", "po_randexp"):
         getattr(L, f).restype = C.c_double
         getattr(L, f).argtypes = [C.POINTER(Rng)]
+    L.po_rand_bool_pub.restype = C.c_int
+    L.po_rand_bool_pub.argtypes = [C.POINTER(Rng)]
+    L.po_zig_table.restype = None
+    L.po_zig_table.argtypes = [C.c_int, C.c_void_p]
+    L.po_zig_install.restype = None
+    L.po_zig_install.argtypes = [C.c_int, C.c_void_p]
+    L.po_set_rng_policy.restype = C.c_int
+    L.po_set_rng_policy.argtypes = [C.c_uint32]
+    L.po_get_rng_policy.restype = C.c_uint32
     L.po_sqr_norm.restype = C.c_double
     L.po_sqr_norm.argtypes = [dp, C.c_int64]
     L.po_logaddexp.restype = C.c_double
@@ -153,7 +163,27 @@ def lib(path=None):
     L.po_shard_index_process.restype = C.c_int64
     L.po_shard_index_process.argtypes = [C.c_void_p, ip, ip]
     _libs[path] = L
+    _install_reference_tables(L)
     return L
+
+
+REFERENCE_FIXTURE = os.path.join(ROOT, "tests", "golden", "reference_pigeons.json")
+
+
+def _install_reference_tables(L):
+    """Once tools/gen_golden.jl has produced the live-reference fixture, the oracle samples with Julia's OWN ziggurat tables
+    (the product gets them through tools/import_tables.py); its binary128 derivation stays readable (zig_table(derived=True))."""
+    if not os.path.exists(REFERENCE_FIXTURE):
+        return False
+    import json
+    t = json.load(open(REFERENCE_FIXTURE)).get("tables")
+    if not t:
+        return False
+    for i, name in enumerate(ZIG_NAMES):
+        a = np.array([int(v) for v in t[name]], dtype=np.uint64)
+        assert a.shape == (256,)
+        L.po_zig_install(i, a.ctypes.data)
+    return True
 
 
 def _dp(a):
@@ -166,6 +196,26 @@ def _ip(a):
 
 def _up(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint64))
+
+
+RNG_TAIL_LOG1P = 1
+
+
+def rng_bool_bit(k):
+    return (k & 63) << 8
+
+
+def zig_table(name, derived=False):
+    """256 uint64 bit patterns: the table the oracle samples with, or (derived=True) its own binary128 derivation --
+    the same thing until the live-reference fixture installs Julia's tables."""
+    out = np.zeros(256, dtype=np.uint64)
+    lib().po_zig_table(ZIG_NAMES.index(name) + (8 if derived else 0), out.ctypes.data)
+    return out
+
+
+def set_rng_policy(policy):
+    if lib().po_set_rng_policy(policy) != 0:
+        raise ValueError("invalid rng policy %r" % (policy,))
 
 
 class OracleRng:
@@ -190,6 +240,9 @@ class OracleRng:
 
     def randexp(self):
         return self.L.po_randexp(C.byref(self.r))
+
+    def rand_bool(self):
+        return self.L.po_rand_bool_pub(C.byref(self.r))
 
     @property
     def state(self):

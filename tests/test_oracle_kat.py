@@ -40,11 +40,9 @@ def test_rand_is_in_unit_interval_with_52_bits():
 
 def test_ziggurat_table_pins():
     """The four entries of Julia's tables recalled in SURVEY.md App. B."""
-    src = open(O.ORACLE_DIR + "/zig_tables.h").read()
-    assert "0x0007799ec012f7b2ULL" in src.split("ZIG_KI[256] = {")[1][:40]
-    assert "0x000e290a13924be3ULL" in src.split("ZIG_KE[256] = {")[1][:40]
-    assert float.fromhex(src.split("ZIG_WI[256] = {")[1].split(",")[0].strip()) == 1.7367254121602630e-15
-    assert float.fromhex(src.split("ZIG_WE[256] = {")[1].split(",")[0].strip()) == 1.9311480126418366e-15
+    assert int(O.zig_table("ki", derived=True)[0]) == 0x0007799ec012f7b2 and int(O.zig_table("ke", derived=True)[0]) == 0x000e290a13924be3
+    assert O.zig_table("wi", derived=True).view(np.float64)[0] == 1.7367254121602630e-15
+    assert O.zig_table("we", derived=True).view(np.float64)[0] == 1.9311480126418366e-15
 
 
 def test_randn_randexp_moments():

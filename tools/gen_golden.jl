@@ -1,45 +1,62 @@
-# gen_golden.jl -- INERT in the build image (no Julia).  Run on any machine with Julia >= 1.8 and Pigeons.jl:
+# gen_golden.jl -- INERT in the build image (no Julia).  ONE command on any machine with Julia >= 1.8, Pigeons.jl and a
+# checkout of this repo:
 #
-#     julia --project=. tools/gen_golden.jl > tests/golden/reference_pigeons.json
+#     julia --project=<env with Pigeons, SplittableRandoms, Distributions, LogDensityProblems, ForwardDiff> \
+#           tools/gen_golden.jl > tests/golden/reference_pigeons.json && python tools/import_tables.py
 #
 # It records what the CPU oracle and the HIP engine are compared against bit for bit (SURVEY.md 8(c), tier 3):
-# raw RNG streams of the replicas' SplittableRandoms and a few seeded runs of the real reference.  Once the file is
-# committed, tests/test_golden.py::test_*_against_live_reference stop skipping and the "parity unpinned" notes in
-# oracle/pt_oracle.h, DESIGN.md and tests/golden can go.
+#   * Julia's own ziggurat tables Random.ki / wi / fi / ke / we / fe, all 6 x 256 entries as bit patterns
+#     (tools/import_tables.py installs them into pigeons.jl_amd/csrc/zig_tables.h; tests/oracle.py installs them into the oracle);
+#   * raw streams of a replica's SplittableRandom: 4096 rand / randn / randexp per seed (several slow-path and tail draws each)
+#     and 1024 rand(rng, Bool) -- these decide the conventions named in include/pte_rng_policy.h;
+#   * seeded runs of the real reference: C1 with SliceSampler / ToyExplorer, AutoMALA on the MVN path, a two-leg TestSwapper
+#     run, a C5-shaped Ising run (examples/ising.jl, base_length 8) and a C3-shaped funnel run with AutoMALA.
+# Once the file is committed, tests/test_golden.py::test_*_against_live_reference and tests/test_zig_tables.py stop skipping
+# and either go green or name the first differing table entry / draw.
 using Pigeons, SplittableRandoms, Random
 
 bits(x::Float64) = string(reinterpret(UInt64, x))          # exact, as a decimal string
-bits(v::AbstractVector{Float64}) = [bits(x) for x in v]
+bits(x::UInt64) = string(x)
+bits(v::AbstractVector) = [bits(x) for x in v]
 
-function rng_streams(seed)
+tables() = Dict("ki" => bits(collect(UInt64, Random.ki)), "wi" => bits(collect(Float64, Random.wi)), "fi" => bits(collect(Float64, Random.fi)),
+                "ke" => bits(collect(UInt64, Random.ke)), "we" => bits(collect(Float64, Random.we)), "fe" => bits(collect(Float64, Random.fe)),
+                "ziggurat_nor_r" => bits(Float64(Random.ziggurat_nor_r)), "ziggurat_exp_r" => bits(Float64(Random.ziggurat_exp_r)))
+
+function rng_streams(seed; n = 4096, nbool = 1024)
     master = SplittableRandom(seed)
     r = split(master)                                       # replica 1's stream (src/utils/misc.jl:21-31)
-    a = deepcopy(r); b = deepcopy(r); c = deepcopy(r); d = deepcopy(r)
+    a = deepcopy(r); b = deepcopy(r); c = deepcopy(r); d = deepcopy(r); e = deepcopy(r)
     Dict("seed" => seed,
-         "rand" => bits([rand(a) for _ in 1:64]),
-         "randn" => bits([randn(b) for _ in 1:64]),
-         "randexp" => bits([randexp(c) for _ in 1:64]),
-         "rand_bool" => [rand(d, Bool) for _ in 1:64])
+         "stream" => [string(r.seed), string(r.gamma)],
+         "u64" => [string(rand(e, UInt64)) for _ in 1:16],
+         "rand" => bits([rand(a) for _ in 1:n]),
+         "randn" => bits([randn(b) for _ in 1:n]),
+         "randexp" => bits([randexp(c) for _ in 1:n]),
+         "rand_bool" => [rand(d, Bool) ? 1 : 0 for _ in 1:nbool])
 end
 
-function run(; kwargs...)
+function run(; state_of = r -> r.state, kwargs...)
     pt = pigeons(; seed = 1, show_report = false,
                  record = [index_process, round_trip, swap_acceptance_pr, log_sum_ratio, Pigeons.explorer_n_steps], kwargs...)
     n = Pigeons.n_chains(pt.inputs)
     ip = pt.reduced_recorders.index_process                 # Dict replica -> Vector{chain} of the last round
     sw = Pigeons.value(pt.reduced_recorders.swap_acceptance_pr)
+    reps = Pigeons.locals(pt.replicas)
     Dict("n_chains" => n,
          "index_process_last_round" => [ip[i] for i in 1:n],           # 1-based chains
          "schedule" => bits(pt.shared.tempering.schedule.grids),
          "swap_acceptance_mean" => bits([Pigeons.value(sw[(i, i + 1)]) for i in 1:(n - 1)]),
-         "stepping_stone_pair" => bits(collect(Pigeons.stepping_stone_pair(pt))),
+         "stepping_stone_pair" => bits(collect(Float64, Pigeons.stepping_stone_pair(pt))),
          "round_trip" => [Pigeons.n_tempered_restarts(pt), Pigeons.n_round_trips(pt)],
-         "final_states" => [bits(r.state) for r in Pigeons.locals(pt.replicas)],
-         "final_chains" => [r.chain for r in Pigeons.locals(pt.replicas)])
+         "final_states" => [bits(collect(Float64, vec(state_of(r)))) for r in reps],
+         "final_chains" => [r.chain for r in reps],
+         "final_rng" => [[string(r.rng.seed), string(r.rng.gamma)] for r in reps])
 end
 
-out = Dict(
+out = Dict{String,Any}(
     "pigeons_version" => string(pkgversion(Pigeons)), "julia_version" => string(VERSION),
+    "tables" => tables(),
     "rng" => [rng_streams(s) for s in 1:3],
     "c1_slice" => run(target = toy_mvn_target(2), n_chains = 10, n_rounds = 5, explorer = SliceSampler()),
     "c1_toy" => run(target = toy_mvn_target(2), n_chains = 10, n_rounds = 5),
@@ -47,8 +64,43 @@ out = Dict(
     "test_swapper_two_legs" => run(target = Pigeons.TestSwapper(0.5), n_chains = 5, n_chains_variational = 5, n_rounds = 8),
 )
 
+# C5-shaped: the Ising example of the reference (examples/ising.jl), base_length 8, IsingMetropolis(3)
+try
+    include(joinpath(pkgdir(Pigeons), "examples", "ising.jl"))
+    out["ising8"] = run(target = IsingLogPotential(1.0, 8), n_chains = 6, n_rounds = 5,
+                        state_of = r -> Float64.(permutedims(r.state.matrix)))      # row-major matrix[i,j] -> state[i*L + j]
+catch err
+    out["ising8_error"] = sprint(showerror, err)
+end
+
+# C3-shaped: Neal's funnel (test/supporting/dimensional-analysis.jl:33-48) from a normal reference of precision 1/9, AutoMALA
+try
+    @eval using Distributions, LogDensityProblems, ForwardDiff
+    @eval begin
+        struct GoldenFunnel; dim::Int; end
+        (p::GoldenFunnel)(x) = LogDensityProblems.logdensity(p, x)
+        LogDensityProblems.dimension(p::GoldenFunnel) = p.dim
+        LogDensityProblems.capabilities(::Type{GoldenFunnel}) = LogDensityProblems.LogDensityOrder{0}()
+        function LogDensityProblems.logdensity(p::GoldenFunnel, z)
+            s = 0.0
+            y = z[1]
+            s += logpdf(Normal(0.0, 3.0), y)
+            sigma = exp(y / 2.0)
+            for i in 2:p.dim
+                s += logpdf(Normal(0.0, sigma), z[i])
+            end
+            return s
+        end
+        Pigeons.initialization(p::GoldenFunnel, ::AbstractRNG, ::Int64) = zeros(p.dim)
+    end
+    out["funnel8_automala"] = Base.invokelatest(() -> run(target = GoldenFunnel(8),
+        reference = Pigeons.ScaledPrecisionNormalLogPotential(1.0 / 9.0, 8), n_chains = 6, n_rounds = 6, explorer = AutoMALA()))
+catch err
+    out["funnel8_error"] = sprint(showerror, err)
+end
+
 # minimal JSON writer (no extra dependency)
-json(x::AbstractString) = "\"" * x * "\""
+json(x::AbstractString) = "\"" * replace(x, "\\" => "\\\\", "\"" => "\\\"", "\n" => "\\n") * "\""
 json(x::Bool) = x ? "true" : "false"
 json(x::Number) = string(x)
 json(x::AbstractVector) = "[" * join(json.(x), ",") * "]"
