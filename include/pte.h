@@ -86,8 +86,10 @@ typedef struct pte_config {
     uint64_t seed;               /* Inputs.seed                                                            */
     int64_t  max_scans_per_round;/* capacity of the index-process buffer, 2^n_rounds                       */
     double   target_params[4];   /* MVN: {precision0, precision1}; TestSwapper: {accept pr};
-                                    FUNNEL: {reference precision}; ISING: {beta}, dim = base_length^2,
-                                    state = 0/1 spins as f64, row-major matrix[i,j] -> state[i*L + j]           */
+                                    FUNNEL: {reference precision}; ISING: {beta}, dim = base_length^2; across the ABI
+                                    (pte_get_state / pte_set_state / traces / online) a state is 0/1 spins as f64,
+                                    row-major matrix[i,j] -> state[i*L + j]; in HBM and in boundary messages the
+                                    lattice is bit-packed (8 KiB at base_length 256)                               */
     /* SliceSampler fields (SliceSampler.jl:8-20) */
     double   slice_w;
     int32_t  slice_p;
@@ -193,12 +195,12 @@ int pte_swap_begin(pte_engine *h, int64_t scan, double *stats_out, int32_t *acti
 /* phase 2: nbr_stats[4] = SwapStats received from the lower / upper neighbour (ignored where inactive);
  * decisions, recorders, chain relabelling of local pairs; accepted_out[2] = boundary swap accepted. */
 int pte_swap_finish(pte_engine *h, int64_t scan, const double *nbr_stats, int32_t *accepted_out);
-int64_t pte_boundary_payload_bytes(const pte_engine *h);            /* 8 * (d + 6) */
+int64_t pte_boundary_payload_bytes(const pte_engine *h);            /* 8 * (sw + 6), sw = d (f64 coordinates) or ceil(ceil(d/32)/2) (bit-packed Ising lattice) */
 int pte_boundary_export(pte_engine *h, int side, void *dst, int dst_is_device);
 int pte_boundary_import(pte_engine *h, int side, const void *src, int src_is_device);
 /* Device-resident, stream-ordered variant of the two phases (no host round trip per scan): the boundary
  * chain's SwapStat and -- speculatively -- its replica's payload are packed into one message of
- * pte_shard_message_bytes() = 8 (d + 8) bytes per active side; the caller moves send -> neighbour's recv
+ * pte_shard_message_bytes() = 8 (sw + 8) bytes per active side; the caller moves send -> neighbour's recv
  * with stream-ordered transfers (RCCL send/recv enqueued on pte_get_stream(), replacing the reference's
  * MPI transmits, src/mpi_utils/Entangler.jl:118-180) and the receiving engine decides and applies the
  * payload on the device iff the swap is accepted.  All four buffers are caller-owned device memory.

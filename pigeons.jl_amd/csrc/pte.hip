@@ -463,6 +463,11 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     if (cfg->explorer == PTE_EXPLORER_ISING_METROPOLIS) h->ising_impl = cfg->debug_kernel == PTE_KERNEL_ISING_BITS ? 1 : (cfg->debug_kernel == PTE_KERNEL_ISING_BYTES ? 2 : 0);
     EngineDev &e = h->dev;
     e.N = N; e.K = K; e.c0 = h->c0; e.d = d; e.ld = (d + 1) & ~(int64_t)1;
+    e.sw = d;
+    if (ising) {            // spins bit-packed in HBM (examples/ising.jl:18-22 keeps a BitMatrix): ceil(d/32) words, 8 KiB at L = 256
+        const int64_t lw = (d + 31) / 32;
+        e.ld = (lw + 1) / 2; e.sw = e.ld;
+    }
     e.record_flags = cfg->record_flags; e.target = cfg->target; e.test_swapper_pr = cfg->target_params[0];
     const int64_t dd = d > 0 ? d : 1;
     int rc = 0;
@@ -475,7 +480,7 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.stat, (size_t)(2 * K));
     rc |= dev_alloc(h, &e.nbr_stat, 4);
     rc |= dev_alloc(h, &e.bflag, 2);
-    rc |= dev_alloc(h, &h->d_payload, (size_t)(dd + 8));
+    rc |= dev_alloc(h, &h->d_payload, (size_t)((e.sw > 0 ? e.sw : 1) + 8));
     rc |= dev_alloc(h, &h->d_napplied, 2);
     rc |= dev_alloc(h, &e.suff, (size_t)K);
     rc |= dev_alloc(h, &h->d_nhp, (size_t)N);
@@ -880,7 +885,7 @@ int pte_swap_finish(pte_engine *h, int64_t scan, const double *nbr_stats, int32_
     time_collect(h);
     return rc;
 }
-int64_t pte_boundary_payload_bytes(const pte_engine *h) { return h ? (int64_t)sizeof(double) * (h->d + 6) : 0; }
+int64_t pte_boundary_payload_bytes(const pte_engine *h) { return h ? (int64_t)sizeof(double) * (h->dev.sw + 6) : 0; }
 int pte_boundary_export(pte_engine *h, int side, void *dst, int dst_is_device) {
     if (!h || !dst || side < 0 || side > 1) return 1;
     HIP_OK(h, hipSetDevice(h->cfg.device));
@@ -908,7 +913,7 @@ int pte_boundary_import(pte_engine *h, int side, const void *src, int src_is_dev
 
 // ---- device-resident, stream-ordered boundary exchange -------------------------------------------
 void *pte_get_stream(const pte_engine *h) { return h ? (void *)h->stream : nullptr; }
-int64_t pte_shard_message_bytes(const pte_engine *h) { return h ? (int64_t)sizeof(double) * (h->d + 8) : 0; }
+int64_t pte_shard_message_bytes(const pte_engine *h) { return h ? (int64_t)sizeof(double) * (h->dev.sw + 8) : 0; }
 int pte_shard_set_buffers(pte_engine *h, void *send_lo, void *recv_lo, void *send_hi, void *recv_hi) {
     if (!h) return 1;
     h->msg_send[0] = (double *)send_lo; h->msg_recv[0] = (double *)recv_lo;
@@ -981,7 +986,7 @@ namespace {
 // engine-owned message buffers {send_lo, recv_lo, send_hi, recv_hi}, d + 8 words each, unless the caller installed its own
 int ensure_msg_buffers(pte_engine *h) {
     if (h->msg_send[0] && h->msg_recv[0] && h->msg_send[1] && h->msg_recv[1]) return 0;
-    const size_t w = (size_t)(h->d + 8);
+    const size_t w = (size_t)(h->dev.sw + 8);
     if (!h->own_msg && dev_alloc(h, &h->own_msg, 4 * w)) return 1;
     HIP_OK(h, hipStreamSynchronize(h->stream));
     h->msg_send[0] = h->own_msg;         h->msg_recv[0] = h->own_msg + w;
@@ -1000,7 +1005,7 @@ int run_scans_sharded(pte_engine *h, int64_t first_scan, int64_t n_scans) {
     RcclApi *api = rccl_api(err);
     if (!api) return fail(h, "%s", err.c_str());
     if (ensure_msg_buffers(h)) return 1;
-    const size_t words = (size_t)(h->d + 8);
+    const size_t words = (size_t)(h->dev.sw + 8);
     for (int64_t s = first_scan; s < first_scan + n_scans; ++s) {
         int32_t active[2];
         if (pte_shard_scan_begin(h, s, active)) return 1;
@@ -1146,7 +1151,7 @@ int pte_group_run_scans(pte_engine *const *hs, int32_t G, int64_t first_scan, in
         if (!h->ev_pack) HIP_OK(h, hipEventCreateWithFlags(&h->ev_pack, hipEventDisableTiming));
         if (!h->ev_copied) HIP_OK(h, hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming));
     }
-    const size_t bytes = sizeof(double) * (size_t)(h0->d + 8);
+    const size_t bytes = sizeof(double) * (size_t)(h0->dev.sw + 8);
     std::vector<int32_t> act((size_t)(2 * G));
     for (int64_t s = first_scan; s < first_scan + n_scans; ++s) {
         for (int g = 0; g < G; ++g) {
@@ -1248,7 +1253,12 @@ int pte_get_state(const pte_engine *hc, double *state, int64_t *chain, uint64_t 
     if (!h) return 1;
     HIP_OK(h, hipSetDevice(h->cfg.device));
     const int64_t N = h->K, d = h->d;
-    if (state && d > 0)
+    const bool ising = h->cfg.target == PTE_TARGET_ISING;
+    std::vector<uint32_t> packed;
+    if (state && d > 0 && ising) {      // the Replica.state contract of the ABI stays 0.0 / 1.0 per site; the device row is bit-packed
+        packed.resize((size_t)(N * h->dev.ld * 2));
+        HIP_OK(h, hipMemcpyAsync(packed.data(), h->dev.x, sizeof(double) * N * h->dev.ld, hipMemcpyDeviceToHost, h->stream));
+    } else if (state && d > 0)
         HIP_OK(h, hipMemcpy2DAsync(state, sizeof(double) * d, h->dev.x, sizeof(double) * h->dev.ld,
                                    sizeof(double) * d, N, hipMemcpyDeviceToHost, h->stream));
     std::vector<int32_t> ch(N);
@@ -1256,6 +1266,11 @@ int pte_get_state(const pte_engine *hc, double *state, int64_t *chain, uint64_t 
     if (rng) HIP_OK(h, hipMemcpyAsync(rng, h->dev.rng, sizeof(uint64_t) * 2 * N, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));
     if (chain) for (int64_t i = 0; i < N; ++i) chain[i] = ch[i];
+    if (!packed.empty())
+        for (int64_t r = 0; r < N; ++r) {
+            const uint32_t *w = packed.data() + (size_t)(r * h->dev.ld * 2);
+            for (int64_t sI = 0; sI < d; ++sI) state[r * d + sI] = (double)((w[sI >> 5] >> (sI & 31)) & 1u);
+        }
     return 0;
 }
 
@@ -1263,7 +1278,15 @@ int pte_set_state(pte_engine *h, const double *state, const int64_t *chain, cons
     if (!h) return 1;
     HIP_OK(h, hipSetDevice(h->cfg.device));
     const int64_t N = h->K, d = h->d;
-    if (state && d > 0)
+    std::vector<uint32_t> packed;
+    if (state && d > 0 && h->cfg.target == PTE_TARGET_ISING) {
+        packed.assign((size_t)(N * h->dev.ld * 2), 0u);
+        for (int64_t r = 0; r < N; ++r) {
+            uint32_t *w = packed.data() + (size_t)(r * h->dev.ld * 2);
+            for (int64_t sI = 0; sI < d; ++sI) if (state[r * d + sI] != 0.0) w[sI >> 5] |= 1u << (sI & 31);
+        }
+        HIP_OK(h, hipMemcpyAsync(h->dev.x, packed.data(), sizeof(double) * N * h->dev.ld, hipMemcpyHostToDevice, h->stream));
+    } else if (state && d > 0)
         HIP_OK(h, hipMemcpy2DAsync(h->dev.x, sizeof(double) * h->dev.ld, state, sizeof(double) * d,
                                    sizeof(double) * d, N, hipMemcpyHostToDevice, h->stream));
     std::vector<int32_t> ch(N), inv(N, -1);

@@ -49,8 +49,15 @@ __global__ __launch_bounds__(64) void k_explore_ising(EngineDev e, IsingParams i
     if (cl >= e.K) return;
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];
-    const int L = ip.L, d = L * L;
-    double *xrow = e.x + (int64_t)slot * e.ld;
+    const int L = ip.L, d = L * L, NW = (d + 31) >> 5;
+    unsigned *wrow = reinterpret_cast<unsigned *>(e.x + (int64_t)slot * e.ld);     // the lattice bit-packed in HBM: site s -> bit s & 31 of word s >> 5
+    auto store_lattice = [&]() {                                                    // LDS bytes -> HBM bits (call after a barrier)
+        for (int wd = lane; wd < NW; wd += 64) {
+            unsigned v = 0;
+            for (int t = 0; t < 32 && 32 * wd + t < d; ++t) v |= (unsigned)(spins[32 * wd + t] & 1u) << t;
+            wrow[wd] = v;
+        }
+    };
     uint64_t seed = e.rng[2 * slot];
     const uint64_t gamma = e.rng[2 * slot + 1];
     const double lp_before = lp_before_explore(e, c, slot);
@@ -62,12 +69,12 @@ __global__ __launch_bounds__(64) void k_explore_ising(EngineDev e, IsingParams i
         seed += (uint64_t)d * gamma;
         __syncthreads();
         const long long spp = ising_recompute(spins, L, lane);
-        for (int s = lane; s < d; s += 64) xrow[s] = spins[s] ? 1.0 : 0.0;
+        store_lattice();
         if (lane == 0) { e.suff[slot] = (double)spp; e.rng[2 * slot] = seed; }
         record_after_explore(e, cl, c, slot, lane, lp_before, (double)spp, 0.0);
         return;
     }
-    for (int s = lane; s < d; s += 64) spins[s] = xrow[s] != 0.0 ? 1 : 0;
+    for (int s = lane; s < d; s += 64) spins[s] = (unsigned char)((wrow[s >> 5] >> (s & 31)) & 1u);
     __syncthreads();
     long long spp = (long long)e.suff[slot];
     const double beta = e.beta[c], bt = ip.beta_target;
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(64) void k_explore_ising(EngineDev e, IsingParams i
         }
     }
     __syncthreads();
-    for (int s = lane; s < d; s += 64) xrow[s] = spins[s] ? 1.0 : 0.0;
+    store_lattice();
     if (lane == 0) { e.suff[slot] = (double)spp; e.rng[2 * slot] = seed + (uint64_t)p * gamma; }
     record_after_explore(e, cl, c, slot, lane, lp_before, (double)spp, 0.0);
 }
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];
     const int L = ip.L, d = L * L, W = L >> 5, NW = d >> 5;
-    double *xrow = e.x + (int64_t)slot * e.ld;
+    unsigned *wrow = reinterpret_cast<unsigned *>(e.x + (int64_t)slot * e.ld);     // bit-packed lattice in HBM, same word layout as the LDS copy
     uint64_t seed = e.rng[2 * slot];
     const uint64_t gamma = e.rng[2 * slot + 1];
     const double lp_before = lp_before_explore(e, c, slot);
@@ -164,11 +171,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
         }
         seed += (uint64_t)d * gamma;
     } else {
-        for (int wd = lane; wd < NW; wd += 64) {
-            unsigned v = 0;
-            for (int t = 0; t < 32; ++t) v |= (xrow[32 * wd + t] != 0.0 ? 1u : 0u) << t;
-            words[wd] = v;
-        }
+        for (int wd = lane; wd < NW; wd += 64) words[wd] = wrow[wd];
     }
     __syncthreads();
     long long spp;
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
         seed += (uint64_t)p * gamma;
     }
     __syncthreads();
-    for (int s = lane; s < d; s += 64) xrow[s] = ((words[s >> 5] >> (s & 31)) & 1u) ? 1.0 : 0.0;
+    for (int wd = lane; wd < NW; wd += 64) wrow[wd] = words[wd];
     if (lane == 0) { e.suff[slot] = (double)spp; e.rng[2 * slot] = seed; }
     record_after_explore(e, cl, c, slot, lane, lp_before, (double)spp, 0.0);
 }
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];
     const int L = ip.L, d = L * L, W = L >> 5, NW = d >> 5;
-    double *xrow = e.x + (int64_t)slot * e.ld;
+    unsigned *wrow = reinterpret_cast<unsigned *>(e.x + (int64_t)slot * e.ld);     // bit-packed lattice in HBM, same word layout as the LDS copy
     uint64_t seed = e.rng[2 * slot];
     const uint64_t gamma = e.rng[2 * slot + 1];
     const double lp_before = lp_before_explore(e, c, slot);
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
     for (int wd = lane; wd < NW; wd += 64) {
         unsigned v = 0;
         if (refresh) { const unsigned bb = rng_bool_bit(); for (int t = 0; t < 32; ++t) v |= (unsigned)((mix64(seed + (uint64_t)(32 * wd + t + 1) * gamma) >> bb) & 1ull) << t; }
-        else         { for (int t = 0; t < 32; ++t) v |= (xrow[32 * wd + t] != 0.0 ? 1u : 0u) << t; }
+        else         { v = wrow[wd]; }
         words[wd] = v;
     }
     if (refresh) seed += (uint64_t)d * gamma;
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
     }
     __syncthreads();
     const long long spp = recompute();
-    for (int s = lane; s < d; s += 64) xrow[s] = ((words[s >> 5] >> (s & 31)) & 1u) ? 1.0 : 0.0;
+    for (int wd = lane; wd < NW; wd += 64) wrow[wd] = words[wd];
     if (lane == 0) { e.suff[slot] = (double)spp; e.rng[2 * slot] = seed; }
     record_after_explore(e, cl, c, slot, lane, lp_before, (double)spp, 0.0);
 }

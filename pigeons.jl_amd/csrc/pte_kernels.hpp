@@ -3,6 +3,8 @@
 // Layout in HBM (struct-of-arrays over replica *slots*; a replica's state never moves inside a
 // GPU, only its chain label does -- "swap betas, not states", reference src/swap/swap.jl:123-125):
 //   x[slot][ld]           f64  replica state, one contiguous row per slot (coalesced 512 B per wave)
+//                              Ising: the row is the lattice BIT-PACKED (site s = i*L + j -> bit s & 31 of 32-bit word s >> 5,
+//                              8 KiB at L = 256; examples/ising.jl:18-22 keeps a BitMatrix too), ld = ceil(ceil(d/32) / 2)
 //   rng[slot][2]          u64  SplittableRandom (seed, gamma) of the replica
 //   chain_of_slot[slot]   i32  Replica.chain          slot_of_chain[chain] i32 (inverse permutation)
 //   suff[slot]            f64  sufficient statistic of the state for the swap: sum_i x_i^2
@@ -18,7 +20,8 @@ namespace pte {
 enum { ERR_NONE = 0, ERR_NAN_RATIO = 1, ERR_SLICE_SUPPORT = 2, ERR_SLICE_INVALID_LP = 3, ERR_SLICE_MAX_ITER = 4 };
 
 struct EngineDev {
-    int64_t N, d, ld;          // N: GLOBAL number of chains
+    int64_t N, d, ld;          // N: GLOBAL number of chains; ld: 8-byte words per state row
+    int64_t sw;                // 8-byte words of a replica's state in a boundary message: d (f64 coordinates); Ising: ld (bit-packed spins)
     int64_t K, c0;             // this engine owns chains [c0, c0+K) and K replica slots
     int64_t *replica_id;       // [slot] global replica index (travels with the replica across shards)
     double *stat;              // [2K] SwapStat (log_ratio, uniform) of every local chain (two-phase swap)
@@ -131,16 +134,22 @@ __device__ __forceinline__ double iid_refresh(const EngineDev &e, int slot, doub
     return S;
 }
 
+// coordinate i of the state of `slot` as the reference's sample sees it (Ising: spin 0.0 / 1.0 out of the bit-packed row)
+__device__ __forceinline__ double state_value(const EngineDev &e, int slot, int64_t i) {
+    const double *xrow = e.x + (int64_t)slot * e.ld;
+    if (e.target == 3) return (double)((reinterpret_cast<const uint32_t *>(xrow)[i >> 5] >> (i & 31)) & 1u);
+    return xrow[i];
+}
+
 // Target-chain online statistics (reference src/pt/pigeons.jl:110-115,
 // src/recorders/OnlineStateRecorder.jl:87-96): per-coordinate Welford mean / M2 of the recorded sample
 // extract_sample(state::Array, lp) = [state; lp(state)] (src/pt/state.jl:79), so d + 1 entries.
 // `which`: 0 / 1 = first / second target chain (two legs: one accumulator set each, merged on the host)
 __device__ __forceinline__ void record_online(const EngineDev &e, int slot, int lane, double lp, int which) {
-    const double *xrow = e.x + (int64_t)slot * e.ld;
     double *mean = e.on_mean + which * (e.d + 1), *m2 = e.on_m2 + which * (e.d + 1);
     int64_t n = e.on_n[which] + 1;
     for (int64_t i = lane; i <= e.d; i += 64) {
-        double v = (i < e.d) ? xrow[i] : lp, mu = mean[i];
+        double v = (i < e.d) ? state_value(e, slot, i) : lp, mu = mean[i];
         double mu2 = mu + (v - mu) / (double)n;
         m2[i] += (v - mu) * (v - mu2);
         mean[i] = mu2;
@@ -191,10 +200,9 @@ __device__ __forceinline__ void record_after_explore_impl(const EngineDev &e, in
     }
     if ((f & 8u) && (tgt || (f & 32u))) {                  // traces[(chain, scan)] = [state; lp]; 32: inputs.extended_traces
         __threadfence_block();
-        const double *xrow = e.x + (int64_t)slot * e.ld;
         const int64_t ntgt = (e.tgt_b != e.tgt_a) ? 2 : 1;
         double *row = e.traces + ((f & 32u) ? (e.trace_idx * e.K + cl) : (e.trace_idx * ntgt + which)) * (e.d + 1);
-        for (int64_t i = lane; i < e.d; i += 64) row[i] = xrow[i];
+        for (int64_t i = lane; i < e.d; i += 64) row[i] = state_value(e, slot, i);
         if (lane == 0) row[e.d] = lp;
     }
 }
@@ -607,36 +615,37 @@ __global__ __launch_bounds__(256) void k_swap_decide(EngineDev e, int even) {
     e.slot_of_chain_alt[new_cl] = slot;
 }
 
-// payload layout (8-byte words): [0..d) state, d: sum x^2, d+1,d+2: rng, d+3: replica id, d+4: round-trip state, d+5: suff2
+// payload layout (8-byte words, sw = e.sw state words: d coordinates, or the bit-packed Ising row):
+// [0..sw) state, sw: sum x^2 / sum_pair_products, sw+1,sw+2: rng, sw+3: replica id, sw+4: round-trip state, sw+5: suff2
 __global__ __launch_bounds__(256) void k_boundary_export(EngineDev e, int side, double *buf) {
     const int slot = e.slot_of_chain[side == 0 ? 0 : e.K - 1];
     const double *xrow = e.x + (int64_t)slot * e.ld;
-    for (int64_t i = threadIdx.x; i < e.d; i += blockDim.x) buf[i] = xrow[i];
+    for (int64_t i = threadIdx.x; i < e.sw; i += blockDim.x) buf[i] = xrow[i];
     if (threadIdx.x == 0) {
-        buf[e.d] = e.suff[slot];
-        unsigned long long *w = reinterpret_cast<unsigned long long *>(buf + e.d + 1);
+        buf[e.sw] = e.suff[slot];
+        unsigned long long *w = reinterpret_cast<unsigned long long *>(buf + e.sw + 1);
         w[0] = e.rng[2 * slot]; w[1] = e.rng[2 * slot + 1];
         w[2] = (unsigned long long)e.replica_id[slot];
         w[3] = (unsigned long long)e.rt_state[slot];
-        buf[e.d + 5] = e.suff2[slot];
+        buf[e.sw + 5] = e.suff2[slot];
     }
 }
 __global__ __launch_bounds__(256) void k_boundary_import(EngineDev e, int side, const double *buf) {
     const int slot = e.slot_of_chain[side == 0 ? 0 : e.K - 1];
     double *xrow = e.x + (int64_t)slot * e.ld;
-    for (int64_t i = threadIdx.x; i < e.d; i += blockDim.x) xrow[i] = buf[i];
+    for (int64_t i = threadIdx.x; i < e.sw; i += blockDim.x) xrow[i] = buf[i];
     if (threadIdx.x == 0) {
-        e.suff[slot] = buf[e.d];
-        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(buf + e.d + 1);
+        e.suff[slot] = buf[e.sw];
+        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(buf + e.sw + 1);
         e.rng[2 * slot] = w[0]; e.rng[2 * slot + 1] = w[1];
         e.replica_id[slot] = (int64_t)w[2];
         e.rt_state[slot] = (int64_t)w[3];
-        e.suff2[slot] = buf[e.d + 5];
+        e.suff2[slot] = buf[e.sw + 5];
     }
 }
 
 // ---- device-resident boundary exchange (no host round trip per scan) -----------------------------
-// message layout (8-byte words): [0] log_ratio, [1] uniform of the boundary chain, [2 .. d+8) payload.
+// message layout (8-byte words): [0] log_ratio, [1] uniform of the boundary chain, [2 .. sw+8) payload.
 // The payload travels speculatively with the SwapStat; the receiver applies it iff the swap is accepted
 // (both sides take the same decision from the same two stats).
 __global__ __launch_bounds__(256) void k_boundary_pack(EngineDev e, int active0, int active1, double *msg0, double *msg1) {
@@ -647,15 +656,15 @@ __global__ __launch_bounds__(256) void k_boundary_pack(EngineDev e, int active0,
     const int slot = e.slot_of_chain[cl];
     const double *xrow = e.x + (int64_t)slot * e.ld;
     double *buf = msg + 2;
-    for (int64_t i = threadIdx.x; i < e.d; i += blockDim.x) buf[i] = xrow[i];
+    for (int64_t i = threadIdx.x; i < e.sw; i += blockDim.x) buf[i] = xrow[i];
     if (threadIdx.x == 0) {
         msg[0] = e.stat[2 * cl]; msg[1] = e.stat[2 * cl + 1];
-        buf[e.d] = e.suff[slot];
-        unsigned long long *w = reinterpret_cast<unsigned long long *>(buf + e.d + 1);
+        buf[e.sw] = e.suff[slot];
+        unsigned long long *w = reinterpret_cast<unsigned long long *>(buf + e.sw + 1);
         w[0] = e.rng[2 * slot]; w[1] = e.rng[2 * slot + 1];
         w[2] = (unsigned long long)e.replica_id[slot];
         w[3] = (unsigned long long)e.rt_state[slot];
-        buf[e.d + 5] = e.suff2[slot];
+        buf[e.sw + 5] = e.suff2[slot];
     }
 }
 __global__ void k_boundary_stats_in(EngineDev e, int active0, int active1, const double *msg0, const double *msg1) {
@@ -673,14 +682,14 @@ __global__ __launch_bounds__(256) void k_boundary_apply(EngineDev e, const doubl
     const double *buf = (side == 0 ? msg0 : msg1) + 2;
     const int slot = e.slot_of_chain[side == 0 ? 0 : e.K - 1];
     double *xrow = e.x + (int64_t)slot * e.ld;
-    for (int64_t i = threadIdx.x; i < e.d; i += blockDim.x) xrow[i] = buf[i];
+    for (int64_t i = threadIdx.x; i < e.sw; i += blockDim.x) xrow[i] = buf[i];
     if (threadIdx.x == 0) {
-        e.suff[slot] = buf[e.d];
-        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(buf + e.d + 1);
+        e.suff[slot] = buf[e.sw];
+        const unsigned long long *w = reinterpret_cast<const unsigned long long *>(buf + e.sw + 1);
         e.rng[2 * slot] = w[0]; e.rng[2 * slot + 1] = w[1];
         e.replica_id[slot] = (int64_t)w[2];
         e.rt_state[slot] = (int64_t)w[3];
-        e.suff2[slot] = buf[e.d + 5];
+        e.suff2[slot] = buf[e.sw + 5];
         n_applied[side] += 1;
     }
 }
