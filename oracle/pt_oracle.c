@@ -474,6 +474,9 @@ struct po_pt {
 
 const char *po_last_error(const po_pt *pt) { return pt->err; }
 int64_t po_round(const po_pt *pt) { return pt->round; }
+/* resume: PT(exec_folder; round) restores shared.iterators (src/pt/checkpoint.jl:19-54); replicas / schedule / explorer
+ * adaptation come in through po_set_states / po_set_schedule / po_set_explorer_adaptation */
+void po_set_round(po_pt *pt, int64_t round) { pt->round = round; pt->scan = 0; }
 
 void po_default_config(po_config *c) {
     memset(c, 0, sizeof(*c));

@@ -106,6 +106,7 @@ int         po_begin_round(po_pt *pt);                 /* round += 1, scan = 0  
 int         po_run_scans(po_pt *pt, int64_t n_scans);  /* explore!+communicate!    */
 int         po_end_round(po_pt *pt);                   /* reduce_recorders!, adapt */
 int64_t     po_round(const po_pt *pt);
+void        po_set_round(po_pt *pt, int64_t round);   /* resume from a checkpoint: shared.iterators.round (src/pt/checkpoint.jl:19-54) */
 
 /* ---- chain-sharded operation (world_size >= 1): same calls as include/pte.h's two-phase swap ---- */
 int     po_shard_explore(po_pt *pt, int64_t scan);

@@ -670,6 +670,9 @@ def pigeons(pt_or_none=None, **kwargs):
     pt = pt_or_none if pt_or_none is not None else PT(Inputs(**kwargs))
     if exec_folder is not None:
         pt.exec_folder = exec_folder
+    elif pt.inputs.checkpoint and getattr(pt, "exec_folder", None) is None:
+        from .checkpoint import next_exec_folder           # the reference always has an exec folder when checkpoint = true
+        pt.exec_folder = next_exec_folder()                # (results/all/<time stamp>, src/pt/pigeons.jl:20, checkpoint.jl:110-113)
     while next_round(pt):
         reduced = run_one_round(pt)
         pt = adapt(pt, reduced)

@@ -261,6 +261,9 @@ class DistShard:
         self.stat_recv = [torch.zeros(2, dtype=torch.float64, device=self.device) for _ in range(2)]
         self.n_boundary_swaps = 0
 
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
     def _exchange(self, sides, send, recv):
         dist = self.dist
         ops = []

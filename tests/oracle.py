@@ -117,6 +117,8 @@ def lib(path=None):
     L.po_run_scans.argtypes = [C.c_void_p, C.c_int64]
     L.po_round.restype = C.c_int64
     L.po_round.argtypes = [C.c_void_p]
+    L.po_set_round.restype = None
+    L.po_set_round.argtypes = [C.c_void_p, C.c_int64]
     L.po_get_states.argtypes = [C.c_void_p, dp, ip, up]
     L.po_get_schedule.argtypes = [C.c_void_p, dp]
     L.po_set_schedule.argtypes = [C.c_void_p, dp]
@@ -288,6 +290,10 @@ class OraclePT:
     @property
     def round(self):
         return int(self.L.po_round(self.h))
+
+    def set_round(self, r):
+        """resume: shared.iterators.round of a checkpoint (src/pt/checkpoint.jl:19-54)"""
+        self.L.po_set_round(self.h, r)
 
     def set_states(self, x=None, chain=None, rng=None):
         xa = None if x is None else np.ascontiguousarray(x, dtype=np.float64)

@@ -6,6 +6,7 @@ round trips, step counts) bit-exact; floating-point recorders / schedule within 
 except where a ziggurat slow path went through libm vs ocml log/exp (<= 1 ulp apart).
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -866,7 +867,8 @@ def test_checkpoint_resume_equals_uninterrupted_run(P, tmp_path, name):
             return P.Inputs(target=P.IsingLogPotential(0.7, 8), n_chains=5, n_rounds=n_rounds, record=rec, show_report=False, checkpoint=True)
         ex = {"slice": P.SliceSampler(), "automala": P.AutoMALA(), "slice+automala": P.Compose(P.SliceSampler(), P.AutoMALA())}[name]
         return P.Inputs(target=P.toy_mvn_target(12), n_chains=6, n_rounds=n_rounds, explorer=ex, record=rec, show_report=False, checkpoint=True)
-    straight = P.pigeons(P.PT(mk(6)))
+    import dataclasses
+    straight = P.pigeons(P.PT(dataclasses.replace(mk(6), checkpoint=False)))
     folder = str(tmp_path / "exec")
     first = P.pigeons(P.PT(mk(3)), exec_folder=folder)
     assert P.latest_checkpoint_folder(folder) == 3
@@ -884,6 +886,70 @@ def test_checkpoint_resume_equals_uninterrupted_run(P, tmp_path, name):
     # a live PT can be extended as well (increment_n_rounds!(pt, k))
     more = P.pigeons(P.increment_n_rounds(first, 3))
     assert np.array_equal(more.reduced_recorders.index_process, ra.index_process)
+
+
+@pytest.mark.parametrize("name", ["slice", "automala", "ising"])
+def test_checkpoint_resumed_on_the_oracle(P, tmp_path, name):
+    """SURVEY.md 8(f) rank 3 against the ORACLE, not against the engine itself: the checkpoint the engine writes after round 3
+    (replica files = what pte_get_state returns; schedule and explorer adaptation from shared) is loaded into a fresh CPU
+    oracle, which continues rounds 4..6 -- and must land exactly where the uninterrupted oracle and the resumed engine land."""
+    import pickle
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio]
+    N = 6
+    if name == "ising":
+        inputs = lambda n: P.Inputs(target=P.IsingLogPotential(0.7, 8), n_chains=N, n_rounds=n, record=rec, show_report=False, checkpoint=True)
+        okw = dict(target=O.TARGET_ISING, explorer=O.EXPLORER_ISING, dim=64, p0=0.7, n_chains=N, slice_n_passes=3)
+    else:
+        ex = lambda: P.SliceSampler() if name == "slice" else P.AutoMALA()
+        inputs = lambda n: P.Inputs(target=P.toy_mvn_target(12), n_chains=N, n_rounds=n, explorer=ex(), record=rec, show_report=False, checkpoint=True)
+        okw = dict(dim=12, n_chains=N, explorer=O.EXPLORER_SLICE if name == "slice" else O.EXPLORER_AUTOMALA, am_preconditioner=2)
+    folder = str(tmp_path / "exec")
+    P.pigeons(P.PT(inputs(3)), exec_folder=folder)                      # engine: rounds 1..3, checkpoint after each
+    straight = O.OraclePT(**okw)
+    for _ in range(6):
+        straight.run_round()
+    # the oracle resumes from the ENGINE's files
+    ck = os.path.join(folder, "round=3", "checkpoint")
+    reps = [np.load(os.path.join(ck, "replica=%d.npz" % (i + 1))) for i in range(N)]
+    assert [int(r["replica_index"]) for r in reps] == list(range(1, N + 1))
+    shared = pickle.load(open(os.path.join(ck, "shared.pkl"), "rb"))
+    resumed = O.OraclePT(**okw)
+    resumed.set_states(x=np.stack([r["state"] for r in reps]), chain=np.array([int(r["chain"]) - 1 for r in reps]),
+                       rng=np.stack([r["rng"] for r in reps]).astype(np.uint64))
+    resumed.set_schedule(shared.tempering.schedule.grids)
+    if name == "automala":
+        resumed.set_explorer_adaptation(shared.explorer.step_size, shared.explorer.estimated_target_std_deviations)
+    resumed.set_round(shared.iterators.round)
+    for _ in range(3):
+        resumed.run_round()
+    tol = dict(rtol=1e-9, atol=0)
+    assert np.array_equal(resumed.index_process(), straight.index_process()) and resumed.round_trip() == straight.round_trip()
+    np.testing.assert_allclose(resumed.schedule(), straight.schedule(), **tol)
+    xa, ca, ga = straight.states(); xb, cb, gb = resumed.states()
+    assert np.array_equal(ca, cb) and np.array_equal(ga, gb)
+    np.testing.assert_allclose(xb, xa, rtol=1e-9, atol=1e-300)
+    # ... and the engine resumed from the same folder agrees with both
+    dev = P.pigeons(P.load_checkpoint(folder, n_rounds_increment=3))
+    assert np.array_equal(dev.reduced_recorders.index_process, straight.index_process())
+    xd, cd, gd = dev.replicas.states()
+    assert np.array_equal(cd, ca) and np.array_equal(gd, ga)
+    np.testing.assert_allclose(xd, xa, rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(dev.shared.tempering.schedule.grids, straight.schedule(), **tol)
+
+
+def test_checkpoint_without_a_folder_gets_the_reference_default(P, tmp_path, monkeypatch):
+    """Inputs(checkpoint=True) with no exec folder: results/all/<time stamp> under the working directory, as the reference's
+    next_exec_folder does -- not a silent no-op -- and an explicit folder passed to write_checkpoint leaves pt.exec_folder alone."""
+    monkeypatch.chdir(tmp_path)
+    pt = P.pigeons(target=P.toy_mvn_target(3), n_chains=4, n_rounds=2, show_report=False, checkpoint=True)
+    assert pt.exec_folder.startswith(os.path.join("results", "all")) and P.latest_checkpoint_folder(pt.exec_folder) == 2
+    assert os.path.realpath(os.path.join("results", "latest")) == os.path.realpath(pt.exec_folder)
+    before = pt.exec_folder
+    from pigeons_amd.checkpoint import write_checkpoint
+    write_checkpoint(pt, str(tmp_path / "elsewhere"))
+    assert pt.exec_folder == before and P.latest_checkpoint_folder(str(tmp_path / "elsewhere")) == 2
+    again = P.pigeons(P.load_checkpoint(before, n_rounds_increment=1))
+    assert again.shared.iterators.round == 3
 
 
 @pytest.mark.parametrize("impl", [1, 0])
@@ -1076,7 +1142,8 @@ def test_gaussian_reference_survives_a_checkpoint(P, tmp_path):
     mk = lambda n: P.Inputs(target=P.Funnel(5), reference=P.ScaledPrecisionNormalLogPotential(1.0 / 9.0, 5), n_chains=5, n_chains_variational=4,
                             variational=P.GaussianReference(first_tuning_round=2), n_rounds=n, explorer=P.AutoMALA(),
                             record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False, checkpoint=True)
-    straight = P.pigeons(P.PT(mk(6)))
+    import dataclasses
+    straight = P.pigeons(P.PT(dataclasses.replace(mk(6), checkpoint=False)))
     folder = str(tmp_path / "exec")
     P.pigeons(P.PT(mk(3)), exec_folder=folder)
     resumed = P.pigeons(P.load_checkpoint(folder, n_rounds_increment=3))

@@ -88,7 +88,8 @@ def test_checkpoint_roundtrip_on_the_cpu(P, tmp_path):
     """write_checkpoint / load_checkpoint (reference src/pt/checkpoint.jl) over the oracle-backed engine: resume == uninterrupted."""
     mk = lambda n: P.Inputs(target=P.toy_mvn_target(4), n_chains=5, n_rounds=n, explorer=P.Compose(P.SliceSampler(), P.AutoMALA()),
                             record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False, checkpoint=True)
-    straight = P.pigeons(P.PT(mk(6), engine_factory=OracleEngine))
+    import dataclasses
+    straight = P.pigeons(P.PT(dataclasses.replace(mk(6), checkpoint=False), engine_factory=OracleEngine))
     folder = str(tmp_path / "exec")
     P.pigeons(P.PT(mk(3), engine_factory=OracleEngine), exec_folder=folder)
     assert P.latest_checkpoint_folder(folder) == 3
