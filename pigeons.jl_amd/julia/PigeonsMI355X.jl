@@ -14,7 +14,7 @@ const libpte = "libpte.so"
 # mirror of `pte_config` (include/pte.h) -- field order and types must match
 Base.@kwdef mutable struct PteConfig
     struct_size::UInt32 = 0
-    abi_version::UInt32 = 1
+    abi_version::UInt32 = 2
     device::Int32 = 0
     target::Int32 = 0
     explorer::Int32 = 1
@@ -38,6 +38,8 @@ Base.@kwdef mutable struct PteConfig
     world_size::Int32 = 1
     explorer2::Int32 = 0        # Compose(explorer, explorer2)
     n_chains_variational::Int64 = 0   # StabilizedPT with variational == nothing
+    debug_kernel::Int32 = 0     # PTE_KERNEL_*: 0 = the default kernel of the explorer (never read from the environment)
+    reserved0::Int32 = 0
 end
 
 """Device-resident `replicas` (informal interface src/replicas/replicas.jl:11-40)."""
@@ -112,6 +114,38 @@ function reduce_recorders!(pt, r::DeviceReplicas, timed)
     # pte_get_index_process (+1 for 1-based chains), pte_get_explorer_stats.
     Pigeons.record_timed_if_requested!(recorders, :round, timed)
     return recorders
+end
+
+# ---- distributed runs: one Julia process per GPU (the reference's MPI layout, docs/src/distributed.md), chains sharded ----
+# The reference's transport (src/mpi_utils/Entangler.jl:118-180 `transmit!`, swap! over EntangledReplicas src/swap/swap.jl:79-102)
+# is replaced by RCCL send/recv that libpte enqueues itself; Julia only hands the 128-byte communicator id around once.
+# With MPI.jl (what Pigeons already depends on for its distributed mode):
+#
+#     id = zeros(UInt8, 128)
+#     MPI.Comm_rank(comm) == 0 && check0(ccall((:pte_comm_unique_id, libpte), Cint, (Ptr{UInt8},), id))
+#     MPI.Bcast!(id, 0, comm)
+#     cfg.rank = MPI.Comm_rank(comm); cfg.world_size = MPI.Comm_size(comm); cfg.device = local_rank
+#     r = create_replicas(...)                                   # pte_create: this rank's chains [rank*N/G, (rank+1)*N/G)
+#     comm_init!(r, id)                                          # collective: ncclCommInitRank inside libpte
+#
+# and from then on run_one_round! above is unchanged: pte_run_scans on a sharded engine performs explore, the two swap
+# phases and the boundary exchange (one {SwapStat, payload} message per active side and scan) on the engine's HIP stream.
+comm_init!(r::DeviceReplicas, id::Vector{UInt8}) =
+    check(r, ccall((:pte_comm_init, libpte), Cint, (Ptr{Cvoid}, Ptr{UInt8}), r.handle, id))
+
+# reduce_recorders!(pt, ::EntangledReplicas) (src/recorders/recorders.jl:86): recorders are keyed by chain / pair, so the
+# reduction is a concatenation in rank order -- pte_comm_allgather moves the per-rank slices without MPI
+function allgather(r::DeviceReplicas, mine::Vector{UInt8}, world::Int)
+    out = zeros(UInt8, length(mine) * world)
+    check(r, ccall((:pte_comm_allgather, libpte), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int64, Ptr{UInt8}), r.handle, mine, length(mine), out))
+    return out
+end
+barrier(r::DeviceReplicas) = check(r, ccall((:pte_comm_barrier, libpte), Cint, (Ptr{Cvoid},), r.handle))
+
+# One Julia process driving G GPUs (no MPI at all): G engines with cfg.rank = g - 1, cfg.world_size = G, cfg.device = g - 1
+function run_scans_group!(rs::Vector{DeviceReplicas}, first_scan, n_scans)
+    hs = [r.handle for r in rs]
+    check(rs[1], ccall((:pte_group_run_scans, libpte), Cint, (Ptr{Ptr{Cvoid}}, Int32, Int64, Int64), hs, length(hs), first_scan, n_scans))
 end
 
 # adapt_tempering -> new Schedule -> discretize on the device (src/tempering/NonReversiblePT.jl:46-66)
