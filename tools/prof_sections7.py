@@ -5,15 +5,18 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "pigeons.jl_amd")]
 lib = os.path.join(ROOT, "gpurun_out", "libpte_prof.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                "-Wno-unused-value", "-DPTE_PROFILE_SECTIONS", *(["-DPTE_DEBUG_S7"] if os.environ.get("S7DBG") else []), "-o", lib, os.path.join(ROOT, "pigeons.jl_amd/csrc/pte.hip")], check=True)
-os.environ["PTE_SLICE_IMPL"] = os.environ.get("S_IMPL", "7")
+                "-Wno-unused-value", "-DPTE_PROFILE_SECTIONS", "-DPTE_TEST_KERNELS", *(["-DPTE_DEBUG_S7"] if os.environ.get("S7DBG") else []), "-o", lib, os.path.join(ROOT, "pigeons.jl_amd/csrc/pte.hip"), "-ldl"], check=True)
 from pigeons_amd import _lib
 _lib.LIB_PATH = lib
+DK = int(os.environ.get("S_IMPL", "7"))
 import numpy as np
 import pigeons_amd as P
 N, d = (64 if os.environ.get('S_IMPL') == '8' else 128), 1024
 pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=10, explorer=P.SliceSampler(), show_report=False,
                    record=[P.online, P.log_sum_ratio]))
+assert DK in (7, 8)
+if DK == 7:
+    pt = P.PT(pt.inputs, debug_kernel=7)          # (the engine loads _lib.LIB_PATH: the profile build holds every generation)
 scans = 8
 pt.replicas.run_scans(1, scans)
 pt.replicas.reduce()

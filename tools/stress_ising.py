@@ -6,9 +6,10 @@ import numpy as np
 import pigeons_amd as P
 
 def run(impl, L, N, beta, seed, rounds, n_steps):
-    os.environ["PTE_ISING_IMPL"] = impl
+    from pigeons_amd import _lib
     pt = P.PT(P.Inputs(target=P.IsingLogPotential(beta, L), n_chains=N, n_rounds=rounds, seed=seed, explorer=P.IsingMetropolis(n_steps=n_steps),
-                       record=[P.round_trip, P.index_process, P.log_sum_ratio, P.energy_ac1], show_report=False))
+                       record=[P.round_trip, P.index_process, P.log_sum_ratio, P.energy_ac1], show_report=False),
+              debug_kernel=_lib.KERNEL_ISING_BYTES if impl == "bytes" else 0)
     out = []
     for _ in range(rounds):
         P.next_round(pt); red = P.run_one_round(pt); P.adapt(pt, red)

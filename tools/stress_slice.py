@@ -1,4 +1,4 @@
-"""One-off stress: the default SliceSampler kernel against the plain sequential kernel (PTE_SLICE_IMPL=1) on many
+"""One-off stress: the default SliceSampler kernel against the plain sequential kernel (pte_config.debug_kernel = 1) on many
 seeds / shapes / parameters -- both on the GPU, so large sizes are cheap.  Everything must be bit-identical."""
 import os, sys, itertools
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,9 +7,8 @@ import numpy as np
 import pigeons_amd as P
 
 def run(impl, N, d, seed, rounds, w, p):
-    os.environ["PTE_SLICE_IMPL"] = impl
     pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, seed=seed, explorer=P.SliceSampler(w=w, p=p),
-                       record=[P.round_trip, P.index_process, P.log_sum_ratio, P.energy_ac1], show_report=False))
+                       record=[P.round_trip, P.index_process, P.log_sum_ratio, P.energy_ac1], show_report=False), debug_kernel=impl)
     out = []
     for _ in range(rounds):
         P.next_round(pt); red = P.run_one_round(pt); P.adapt(pt, red)
@@ -22,8 +21,8 @@ params = [(10.0, 20), (1.0, 20), (0.2, 4), (100.0, 20)]
 seed0 = int(os.environ.get("STRESS_SEED0", "1")); nseeds = int(os.environ.get("STRESS_NSEEDS", "6")); extra = int(os.environ.get("STRESS_EXTRA_ROUNDS", "0"))
 for (N, d), (w, p), seed in itertools.product(shapes, params, range(seed0, seed0 + nseeds)):
     rounds = (4 if d >= 1000 else 5) + extra
-    a, sa = run("1", N, d, seed, rounds, w, p)
-    b, sb = run(os.environ.get("STRESS_IMPL", "8"), N, d, seed, rounds, w, p)
+    a, sa = run(1, N, d, seed, rounds, w, p)
+    b, sb = run(int(os.environ.get("STRESS_IMPL", "0")), N, d, seed, rounds, w, p)      # 0 = the default kernel; 2 / 5 / 7: test build
     ok = all(np.array_equal(x, y) for ra, rb in zip(a, b) for x, y in zip(ra, rb)) and all(np.array_equal(x, y) for x, y in zip(sa, sb))
     n += 1
     if not ok:
