@@ -194,8 +194,24 @@ def main():
     rt_rounds = max(args.round_trip_rounds, 0)
     inputs = P.Inputs(target=P.toy_mvn_target(d), n_chains=total_chains, n_rounds=max(rt_rounds, 1), explorer=explorer, seed=1,
                       record=[P.round_trip, P.log_sum_ratio], show_report=False, device=local_rank)
+    transport = "single GPU"
     if world > 1:
-        pt = P.PT(inputs, rank=rank, world=world)            # RcclShard: communicator id over torch.distributed, then libpte only
+        # RcclShard: the communicator id goes over torch.distributed once, the data path is RCCL inside libpte.  If that cannot be
+        # set up on ANY rank (no RCCL to map, communicator creation refused) every rank falls back -- together, agreed by an
+        # all-reduce, and said in the line -- to the host-driven exchange over torch.distributed point-to-point.
+        err = ""
+        try:
+            pt = P.PT(inputs, rank=rank, world=world)
+        except Exception as exc:
+            err = "%s: %s" % (type(exc).__name__, exc)
+        flag = torch.tensor([0 if err else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            transport = "RCCL send/recv enqueued by libpte (pte_comm_init / pte_run_scans)"
+        else:
+            sys.stderr.write("bench.py rank %d: RCCL transport inside libpte unavailable (%s); falling back to the host-driven exchange\n" % (rank, err or "another rank failed"))
+            pt = P.PT(inputs, rank=rank, world=world, transport="host", dist_device=torch.device("cuda", local_rank))
+            transport = "FALLBACK: host-driven two-phase exchange over torch.distributed (libpte RCCL transport failed: %s)" % (err or "on another rank")
         runner = pt.shards
     else:
         pt = P.PT(inputs)
@@ -281,7 +297,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "toy_mvn_target(%d), n_chains=%d per GPU x %d GPU, %s, seed=1, DEO swaps every scan"
                                % (d, n_chains, world, "SliceSampler(w=10,p=20,n_passes=3)" if args.explorer == "slice" else "ToyExplorer"),
-                   "sharding": ("chains sharded over %d GPUs, boundary replicas exchanged by RCCL send/recv inside libpte (pte_comm_*)" % world) if world > 1 else "single GPU",
+                   "sharding": ("chains sharded over %d GPUs, boundary replicas only; transport: %s" % (world, transport)) if world > 1 else "single GPU",
                    "n_ranks_seen": ranks_seen, "boundary_swaps_per_rank": boundary, "ms_per_step_per_rank": per_rank_ms},
         "round_trip_rate": rt["round_trip_rate"] if rt else None, "n_round_trips": rt["n_round_trips"] if rt else None,
         "n_tempered_restarts": rt["n_tempered_restarts"] if rt else None, "round_trip": rt,

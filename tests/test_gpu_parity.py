@@ -851,6 +851,34 @@ def test_sharded_compose_equals_single_engine(P):
     assert np.array_equal(xa, xb) and np.array_equal(ca, cb) and np.array_equal(ga, gb)
 
 
+@pytest.mark.parametrize("explorer", ["slice", "automala", "slice+automala", "mala"])
+@pytest.mark.parametrize("transport", ["group", "device_messages", "host"])
+def test_parallelism_invariance_matrix_of_the_reference(P, explorer, transport):
+    """The reference's own invariance test (test/test_parallelism_invariance.jl:5-43): toy_mvn_target(1), n_chains = 4,
+    n_rounds = 10, explorers SliceSampler / AutoMALA / Compose(SliceSampler, AutoMALA), record = [swap_acceptance_pr,
+    index_process, log_sum_ratio, round_trip, energy_ac1], two processes against one -- `compare_checkpoints` must find the
+    runs identical.  Here: 2 chain shards against one engine through each in-process transport, every recorder and the final
+    replicas bit-identical (d = 1: a one-coordinate state row, the smallest the layout allows)."""
+    ex = {"slice": P.SliceSampler, "automala": P.AutoMALA, "mala": lambda: P.MALA(step_size=0.3),
+          "slice+automala": lambda: P.Compose(P.SliceSampler(), P.AutoMALA())}[explorer]
+    rec = [P.swap_acceptance_pr, P.index_process, P.log_sum_ratio, P.round_trip, P.energy_ac1]
+    mk = lambda: P.Inputs(target=P.toy_mvn_target(1), n_chains=4, n_rounds=10, explorer=ex(), record=rec, show_report=False)
+    kw = {"group": dict(transport="group"), "device_messages": dict(device_messages=True), "host": {}}[transport]
+    one, two = P.PT(mk()), P.PT(mk(), n_shards=2, **kw)
+    for _ in range(10):
+        assert P.next_round(one) and P.next_round(two)
+        ra = P.run_one_round(one); P.adapt(one, ra)
+        rb = P.run_one_round(two); P.adapt(two, rb)
+        assert np.array_equal(ra.index_process, rb.index_process) and ra.round_trip == rb.round_trip
+        for a, b in zip(ra.swap_acceptance_pr + ra.log_sum_ratio + ra.energy_ac1 + ra.explorer_acceptance_pr + ra.explorer_n_steps + ra.am_factors,
+                        rb.swap_acceptance_pr + rb.log_sum_ratio + rb.energy_ac1 + rb.explorer_acceptance_pr + rb.explorer_n_steps + rb.am_factors):
+            assert np.array_equal(a, b, equal_nan=True)
+        assert np.array_equal(one.shared.tempering.schedule.grids, two.shared.tempering.schedule.grids)
+    xa, ca, ga = one.replicas.states(); xb, cb, gb = two.shards.states()
+    assert np.array_equal(xa, xb) and np.array_equal(ca, cb) and np.array_equal(ga, gb)
+    assert P.stepping_stone_pair(one) == P.stepping_stone_pair(two)
+
+
 # ---------------------------------------------------------------------------------------------
 # SURVEY.md 8(f) rank 3: checkpoint / resume through pte_get_state / pte_set_state
 # (reference src/pt/checkpoint.jl; its own end-to-end check is "a resumed run equals an uninterrupted one",
