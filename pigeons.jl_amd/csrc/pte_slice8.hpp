@@ -162,6 +162,12 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 const double xold = s_x[(l + hg) & (BLK - 1)];   // not yet updated in this pass
                 int idx0 = p + hrel;
                 double E = s_e[idx0];
+                // every draw the head and the budgeted doubling steps can need is requested in the same LDS round trip as E
+                // (the positions only move for lane 0, in the rare branch below, which re-reads them)
+                double u0 = s_u[idx0 + 1];
+                double Vd[S8_BD];
+#pragma unroll
+                for (int it = 0; it < S8_BD; ++it) Vd[it] = s_u[idx0 + 2 + it];
                 int ex0 = 0;
                 if (__builtin_expect((ballot64(E != E) & 1ull) != 0ull, 0)) {
                     // the certain hypothesis needs the ziggurat's slow path for its exponential (2.3 % of the coordinates):
@@ -174,13 +180,12 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                         if (lane == 0) { E = Ex; idx0 += ex0; }
                         Sest += Ex * inv_abs_nhp;            // not among the window's fast-path exponentials summed into Sest
                         ex_total += ex0;
+                        u0 = s_u[idx0 + 1];
+#pragma unroll
+                        for (int it = 0; it < S8_BD; ++it) Vd[it] = s_u[idx0 + 2 + it];
                     }
                 }
                 const int ex = (lane == 0) ? ex0 : 0;
-                const double u0 = s_u[idx0 + 1];
-                double Vd[S8_BD];                             // the draws of the budgeted doubling steps, loaded with the head's
-#pragma unroll
-                for (int it = 0; it < S8_BD; ++it) Vd[it] = s_u[idx0 + 2 + it];
                 const double Q = xold * xold - E * inv_nhp;
                 const double Bq = Sest + fabs(Q);
                 double dmin = INFINITY;
