@@ -181,6 +181,9 @@ __device__ inline double wave_randn_block(SeqRng &r, int lane, int n_valid /*uni
         double x = (double)((u & 1) ? -rabs : rabs) * wi[idx];            // tables: global, or staged in LDS by the caller
         bool active = (lane >= start) && (lane < n_valid);
         bool ok = (uint64_t)rabs < ki[idx];
+#ifdef PTE_MEASURE_ALWAYS_FAST      // measurement builds only (tools/bench_toy.py): what the fast path alone would cost -- changes the samples
+        ok = true;
+#endif
         uint64_t failmask = ballot64(active && !ok);
         int f = failmask ? (int)__builtin_ctzll(failmask) : n_valid;
         if (active && lane < f) out = x;
