@@ -1,0 +1,53 @@
+"""bench.py's contract with the driver: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line carrying the metric,
+`roofline` and `cpu_baseline`; for N > 1 the process launches its own ranks and fails loudly when a rank fails."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BASELINE = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+
+
+def test_launcher_spawns_ranks_and_propagates_their_failure():
+    """No GPU here: both ranks die in their first HIP call; the launcher (which itself must not touch the GPU, so it imports
+    neither torch nor libpte) reports every rank's exit code and exits non-zero instead of hanging or printing a line."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU (on a GPU box the ranks would run)")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "ranks exited with" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_world_size_must_match_gpus():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"))
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_has_the_contract_fields():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--round-trip-rounds", "4"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["metric"] == BASELINE["metric"] and j["unit"] == "replica-steps/s" and j["dtype"] == "f64"
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["higher_is_better"] is True and j["vs_baseline"] is None
+    assert j["scaling"] == "weak" and j["data"] == "synthetic" and "workload" in j["config"] and "model" not in j["config"]
+    assert abs(j["value"] - 1024 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k_explore_slice8"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["launches"] == 3
+    assert r["algorithmic_bytes_per_launch"] == (16 * 1024 + 32) * 1024
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["avg_launch_ms"] <= j["ms_per_step"] and r["launch_ms_min_median_max"][0] <= r["launch_ms_min_median_max"][2]
+    c = j["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "replica-steps/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    rt = j["round_trip"]
+    assert rt["rounds"] == 4 and rt["scans_in_last_round"] == 16 and rt["global_barrier"] > 0
