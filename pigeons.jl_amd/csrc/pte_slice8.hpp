@@ -410,7 +410,10 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 const int kn = cnt + succ_off;
                 const bool inw = (unsigned)kn < (unsigned)succ_wd;
                 const uint64_t vmask = ballot64(valid);
-                const int packed = (valid && lane != 0) ? (int)(0x80000000u | (unsigned)cnt | (inw ? (unsigned)(kn + succ_base) << 8 : 0u)) : 0;
+                // packed word of a valid hypothesis of level >= 1: bits 0-7 its draw count, bits 8-13 its successor lane (0: none),
+                // bit 16 "one more coordinate done" -- so that ONE masked add per level accumulates both the draws consumed (low
+                // half) and the coordinates retired (high half) of the true path
+                const int packed = (valid && lane != 0) ? (int)(0x10000u | (unsigned)cnt | (inw ? (unsigned)(kn + succ_base) << 8 : 0u)) : 0;
 #ifdef PTE_PROFILE_SECTIONS
                 asm volatile("" :: "v"(packed));
 #endif
@@ -419,21 +422,21 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 {
                     const int cnt0 = __builtin_amdgcn_readlane(cnt, 0);
                     const int k1 = cnt0 - LO[1];
-                    int o = gdone ? cnt0 : 0;
+                    int acc = gdone ? cnt0 : 0;
                     int cur = (gdone && (unsigned)k1 < (unsigned)WD[1]) ? BASE[1] + k1 : 0;
                     uint64_t tmask = 1ull;
 #pragma unroll
                     for (int g = 1; g < G; ++g) {
                         const int pk = __builtin_amdgcn_readlane(packed, cur);
                         tmask |= 1ull << cur;
-                        o += pk & 0xFF;
-                        gdone += (int)((unsigned)pk >> 31);
-                        cur = (pk >> 8) & 63;
+                        acc += pk & 0x100FF;
+                        cur = (int)(((unsigned)pk >> 8) & 63u);
                     }
                     tmask &= vmask;                           // (a path ends AT an invalid lane: its bit was set above)
                     if (__builtin_amdgcn_inverse_ballot_w64(tmask)) s_x[(l + hg) & (BLK - 1)] = xf;
                     __builtin_amdgcn_wave_barrier();
-                    p += o;
+                    p += acc & 0xFFFF;
+                    gdone += acc >> 16;
                     l += gdone;
                 }
 #ifdef PTE_PROFILE_SECTIONS
