@@ -270,7 +270,8 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                     "v_cndmask_b32 v99, v101, v99, vcc\n" \
                     "v_min_f64 v[104:105], v[104:105], |v[102:103]|\n" \
                     "v_cmpx_ngt_f64 vcc, 0, v[102:103]\n"
-                    asm volatile("s_mov_b64 %[sv], exec\n"
+                    asm volatile(".p2align 3\n"           // hand-written stream at an 8-byte phase (MI355X_MICROARCH.md: the 4 mod 8 phase costs ~1 % here)
+                                 "s_mov_b64 %[sv], exec\n"
                                  PTE_S8_STEP("%[u0]") PTE_S8_STEP("%[u1]") PTE_S8_STEP("%[u2]") PTE_S8_STEP("%[u3]")
                                  PTE_S8_STEP("%[u4]") PTE_S8_STEP("%[u5]")
 #if PTE_S8_BS >= 7
