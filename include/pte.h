@@ -50,10 +50,13 @@ enum {
 enum {
     PTE_EXPLORER_NONE     = 0,           /* `nothing` (TestSwapper)                                        */
     PTE_EXPLORER_TOY      = 1,           /* ToyExplorer:  src/explorers/ToyExplorer.jl:5-14                */
-    PTE_EXPLORER_SLICE    = 2,           /* SliceSampler: src/explorers/SliceSampler.jl:8-237 -- the Float64-coordinate methods on
-                                            the scaled-precision MVN path ONLY.  Not on the device: its Bool / Integer coordinate
-                                            variants (:65-86,136-142,189) and a generic log_potential under it (:105-118);
-                                            pte_create refuses those combinations and the caller keeps the reference CPU path */
+    PTE_EXPLORER_SLICE    = 2,           /* SliceSampler: src/explorers/SliceSampler.jl:8-237 -- the Float64-coordinate methods, on
+                                            the scaled-precision MVN path (closed-form single-coordinate update, the fast kernels)
+                                            and on the interpolated funnel path (the log potential evaluated in full per proposal,
+                                            as slice_sample! does for any log_potential :105-118; dim <= 1024).  Not on the
+                                            device: its Bool / Integer coordinate variants (:65-86,136-142,189) -- no device target
+                                            has integer coordinates (Ising has its own explorer) -- and a GaussianReference under it;
+                                            pte_create / pte_set_variational_reference refuse those, the caller keeps the CPU path */
     PTE_EXPLORER_AUTOMALA = 3,           /* AutoMALA:     src/explorers/AutoMALA.jl:29-294                 */
     PTE_EXPLORER_ISING_METROPOLIS = 4,   /* IsingMetropolis: examples/ising.jl:91-116 (n_steps in slice_n_passes) */
     PTE_EXPLORER_MALA     = 5            /* MALA:         src/explorers/MALA.jl:19-105 (am_* fields; step size fixed) */

@@ -266,7 +266,27 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
         DISPATCH_NLU(h->nlu, k_explore_toy, dim3((unsigned)N), dim3(64), h->stream, h->dev);
         time_end(h);
         break;
-    case PTE_EXPLORER_SLICE: {
+    case PTE_EXPLORER_SLICE:
+        if (h->cfg.target == PTE_TARGET_FUNNEL) {
+            // SliceSampler on the interpolated path: the register-resident kernel of the Langevin family in its slice mode
+            // (full log potential per evaluation, as the reference's slice_sample! does for any log_potential)
+            AmParams ap{};
+            ap.slice = 1; ap.slice_w = h->cfg.slice_w; ap.slice_p = h->cfg.slice_p; ap.slice_n_passes = h->cfg.slice_n_passes;
+            ap.slice_max_iter = h->cfg.slice_max_iter;
+            ap.ref_prec = h->cfg.target_params[0]; ap.log3 = std::log(3.0);
+            const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
+            time_begin(h, 0);
+            switch (E) {
+            case 1: hipLaunchKernelGGL((k_explore_automala<1, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
+            case 2: hipLaunchKernelGGL((k_explore_automala<2, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
+            case 4: hipLaunchKernelGGL((k_explore_automala<4, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
+            case 8: hipLaunchKernelGGL((k_explore_automala<8, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
+            default: hipLaunchKernelGGL((k_explore_automala<16, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
+            }
+            time_end(h);
+            break;
+        }
+        {
         SliceParams sp{h->cfg.slice_w, h->cfg.slice_p, h->cfg.slice_n_passes, h->cfg.slice_max_iter};
         time_begin(h, 0);
         if (h->slice_impl == 1) {          // PTE_KERNEL_SLICE_SEQUENTIAL: the plain sequential kernel (exact fallback, bisecting)
@@ -410,10 +430,13 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
         return fail(nullptr, "pte_create: target %d has no device log-potential; use the reference CPU path", cfg->target);
     auto grad_based = [](int k) { return k == PTE_EXPLORER_AUTOMALA || k == PTE_EXPLORER_MALA; };
     const bool uses_grad = grad_based(cfg->explorer) || grad_based(cfg->explorer2);
-    if (funnel && !(grad_based(cfg->explorer) && (cfg->explorer2 == PTE_EXPLORER_NONE || grad_based(cfg->explorer2))))
-        return fail(nullptr, "pte_create: the funnel path is implemented for AutoMALA / MALA only; use the reference CPU path");
-    if (uses_grad && (cfg->dim < 1 || cfg->dim > 1024))
-        return fail(nullptr, "pte_create: AutoMALA / MALA keep the replica in registers, dim must be in 1..1024 (got %lld)", (long long)cfg->dim);
+    auto on_path = [&](int k) { return grad_based(k) || k == PTE_EXPLORER_SLICE; };
+    if (funnel && !(on_path(cfg->explorer) && (cfg->explorer2 == PTE_EXPLORER_NONE || on_path(cfg->explorer2))))
+        return fail(nullptr, "pte_create: the funnel path is implemented for AutoMALA / MALA / SliceSampler (and Compose of them); use the reference CPU path");
+    if ((uses_grad || funnel) && (cfg->dim < 1 || cfg->dim > 1024))
+        return fail(nullptr, "pte_create: AutoMALA / MALA (and every explorer of the funnel path) keep the replica in registers, dim must be in 1..1024 (got %lld)", (long long)cfg->dim);
+    if (funnel && cfg->debug_kernel != 0)
+        return fail(nullptr, "pte_create: debug_kernel %d is not available on the funnel path (one register-resident kernel serves it)", cfg->debug_kernel);
     if (cfg->explorer2 != PTE_EXPLORER_NONE) {           // Compose(first, second)
         auto composable = [&](int k) { return k == PTE_EXPLORER_SLICE || grad_based(k); };
         if (!composable(cfg->explorer) || !composable(cfg->explorer2))
@@ -1188,6 +1211,7 @@ const char *pte_kernel_name(const pte_engine *h) {
     switch (h->cfg.explorer) {
     case PTE_EXPLORER_TOY: return "k_explore_toy";
     case PTE_EXPLORER_SLICE:
+        if (h->cfg.target == PTE_TARGET_FUNNEL) return "k_explore_automala";      // its SliceSampler mode
         switch (h->slice_impl) {
         case 1: return "k_explore_slice"; case 2: return "k_explore_slice2"; case 5: return "k_explore_slice5";
         case 7: return "k_explore_slice7";
@@ -1229,6 +1253,8 @@ int pte_set_variational_reference(pte_engine *h, const double *mean, const doubl
     if (!mean || !std_dev || !uses) { e.v_use = nullptr; return 0; }
     if (h->cfg.target != PTE_TARGET_FUNNEL) return fail(h, "pte_set_variational_reference: only the interpolated (funnel) path has a replaceable reference");
     if (h->world != 1) return fail(h, "pte_set_variational_reference: single engine only");
+    if (h->cfg.explorer == PTE_EXPLORER_SLICE || h->cfg.explorer2 == PTE_EXPLORER_SLICE)
+        return fail(h, "pte_set_variational_reference: a GaussianReference under SliceSampler is not implemented on the device; use the reference CPU path");
     if (dim != h->d) return fail(h, "pte_set_variational_reference: expected %lld coordinates", (long long)h->d);
     const int64_t d = h->d;
     std::vector<double> buf((size_t)(5 * d));

@@ -25,6 +25,8 @@ struct AmParams {
     const double *target_std;   // [d] or nullptr (== `nothing`: identity, no draw)
     int use_mh;             // scan != 1
     int mala;               // 1: MALA (src/explorers/MALA.jl:74-97) -- fixed step size, one leapfrog, always MH
+    int slice;              // 1: SliceSampler on this path (SliceSampler.jl:24-237) with the full log potential per evaluation
+    double slice_w; int slice_p, slice_n_passes, slice_max_iter;
     double ref_prec;        // funnel: precision of the normal reference
     double log3;            // log(3.0) from the host libm
 };
@@ -115,6 +117,17 @@ struct AmTarget {
             if (lane == 0) (*g)[0] = gy;
         }
         return lp;
+    }
+    // log_potentials[chain](x) as a plain callable: InterpolatedLogPotential(x) (src/paths/InterpolatedLogPotential.jl:9-16)
+    // WITH its beta == 0 / beta == 1 short-circuits -- what SliceSampler evaluates (the AD form below has none)
+    __device__ __forceinline__ double path_lp(const double (&x)[E]) const {
+        const double S = sqr_norm_regs<E>(x);
+        if (TGT == TGT_MVN) return nhp * S;
+        if (beta == 0.0) return ref_lp(x, S);
+        if (beta == 1.0) return funnel(x, nullptr);
+        const double l1 = ref_lp(x, S);
+        const double l2 = funnel(x, nullptr);
+        return omb * l1 + beta * l2;
     }
     // LogDensityProblems.logdensity
     __device__ __forceinline__ double logdensity(const double (&x)[E]) const {
@@ -310,6 +323,82 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         return exponent;
     };
 
+    if (ap.slice) {
+        // ---- step!(::SliceSampler) on a path without a closed-form single-coordinate update: the reference's procedure as it
+        // stands (slice_sample! :43-62, slice_sample_coord! :89-95, slice_double :97-126, slice_shrink! :144-186, slice_accept
+        // :192-237), every log potential evaluated in full (E wave reductions of the fixed tree + the funnel's exp / log),
+        // the replica's stream consumed through 64 buffered draws.  All control flow is uniform: every value it branches on
+        // comes out of a wave reduction.
+        WaveDraws dr;
+        dr.init(r.seed, r.gamma, lane);
+        double lp = T.path_lp(x);                               // cached_log_potential (:32-41)
+        if (lp == -INFINITY) { if (lane == 0) set_error(e, ERR_SLICE_SUPPORT, (int)c, -1); return; }
+        const double w = ap.slice_w, w11 = 1.1 * ap.slice_w;
+        for (int pass = 0; pass < ap.slice_n_passes && !err; ++pass) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const int nl = (int)max((int64_t)0, min((int64_t)64, d - 64 * (int64_t)j));
+                for (int l = 0; l < nl && !err; ++l) {
+                    const double xold = readlane_f64(x[j], l);
+                    auto eval = [&](double v) -> double { x[j] = (lane == l) ? v : x[j]; return T.path_lp(x); };   // pointer[] = v; lp(state)
+                    double Ex;
+                    {
+                        const uint64_t raw = dr.next_raw(lane);
+                        const uint64_t ri = raw & MASK52;
+                        const int idx = (int)(ri & 0xFF);
+                        Ex = (double)ri * ZIG_WE[idx];
+                        if (!(ri < ZIG_KE[idx])) { SeqRng sq = dr.to_seq(); Ex = randexp_from_raw(sq, raw); dr.from_seq(sq, lane); }
+                    }
+                    const double z = lp - Ex;
+                    double L = xold - w * dr.rand(lane);
+                    double R = L + w;
+                    int K = ap.slice_p;
+                    double lp_L = eval(L), lp_R = eval(R);
+                    while (K > 0 && (z < lp_L || z < lp_R)) {
+                        const double V = dr.rand(lane);
+                        if (V <= 0.5) { L = L - (R - L); lp_L = eval(L); }
+                        else { R = R + (R - L); lp_R = eval(R); }
+                        K -= 1;
+                    }
+                    steps_sum += ap.slice_p - K; steps_n += 1;
+                    double Lbar = L, Rbar = R;
+                    bool done = false;
+                    for (int n = 1; n <= ap.slice_max_iter; ++n) {
+                        const double newpos = Lbar + dr.rand(lane) * (Rbar - Lbar);
+                        const double newlp = eval(newpos);
+                        bool take = z < newlp;
+                        if (take) {                              // slice_accept
+                            double Lhat = L, Rhat = R, aL = lp_L, aR = lp_R;
+                            bool Rstale = false, Lstale = false, D = false;
+                            while (Rhat - Lhat > w11) {
+                                const double Mid = (Lhat + Rhat) / 2.0;
+                                if ((xold < Mid && newpos >= Mid) || (xold >= Mid && newpos < Mid)) D = true;
+                                if (newpos < Mid) { Rhat = Mid; Rstale = true; } else { Lhat = Mid; Lstale = true; }
+                                if (D) {
+                                    if (Lstale) { aL = eval(Lhat); Lstale = false; }
+                                    if (Rstale) { aR = eval(Rhat); Rstale = false; }
+                                    if (z >= aL && z >= aR) { take = false; break; }
+                                }
+                            }
+                            acc_sum += take ? 1.0 : 0.0; acc_n += 1;
+                        }
+                        if (take) {
+                            x[j] = (lane == l) ? newpos : x[j]; lp = newlp;
+                            steps_sum += n; steps_n += 1; done = true; break;
+                        }
+                        if (newpos < xold) Lbar = newpos; else Rbar = newpos;
+                        if (jl_isapprox(Lbar, Rbar)) {
+                            lp = eval(xold);
+                            steps_sum += n; steps_n += 1; done = true; break;
+                        }
+                    }
+                    if (!done) { if (lane == 0) set_error(e, ERR_SLICE_MAX_ITER, (int)c, 64 * j + l); return; }
+                    if (!isfinite(lp)) { if (lane == 0) set_error(e, ERR_SLICE_INVALID_LP, (int)c, 64 * j + l); return; }
+                }
+            }
+        }
+        r.seed = dr.final_seed();
+    } else
     for (int it = 0; it < ap.n_refresh && !err; ++it) {
 #pragma unroll
         for (int j = 0; j < E; ++j) {

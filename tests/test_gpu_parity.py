@@ -575,6 +575,75 @@ def test_config3_funnel_full_size_properties(P):
 
 
 # ---------------------------------------------------------------------------------------------
+# SliceSampler on a path WITHOUT a closed-form single-coordinate update (slice_sample! takes any
+# log_potential, SliceSampler.jl:105-118): the interpolated funnel path, every proposal a full log-potential evaluation.
+# ---------------------------------------------------------------------------------------------
+def _mk_slice_funnel(P, N, d, rounds, seed=1, explorer=None, okw=None):
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio]
+    inp = P.Inputs(target=P.Funnel(d), reference=P.ScaledPrecisionNormalLogPotential(1.0 / 9.0, d), n_chains=N, n_rounds=rounds,
+                   explorer=explorer or P.SliceSampler(), seed=seed, record=rec, show_report=False)
+    ref = O.OraclePT(n_chains=N, dim=d, seed=seed, target=O.TARGET_FUNNEL, p0=1.0 / 9.0, **(okw or dict(explorer=O.EXPLORER_SLICE)))
+    return P.PT(inp), ref
+
+
+def _check_funnel_round(P, pt, ref, rtol=1e-6):
+    assert P.next_round(pt)
+    red = P.run_one_round(pt); P.adapt(pt, red)
+    ref.run_round()
+    assert np.array_equal(red.index_process, ref.index_process()) and red.round_trip == ref.round_trip()
+    ss, sn = red.explorer_n_steps; am, an = red.explorer_acceptance_pr
+    amr, anr, ssr, snr = ref.explorer_stats()
+    assert np.array_equal(sn, snr) and np.array_equal(ss, ssr) and np.array_equal(an, anr)      # every step count, exactly
+    np.testing.assert_allclose(am, amr, rtol=rtol)
+    m, n = red.swap_acceptance_pr; mr, nr = ref.swap_pr()
+    assert np.array_equal(n, nr)
+    np.testing.assert_allclose(m, mr, rtol=rtol, atol=1e-300)
+    np.testing.assert_allclose(pt.shared.tempering.schedule.grids, ref.schedule(), rtol=rtol)
+    np.testing.assert_allclose(P.stepping_stone_pair(pt), ref.stepping_stone_pair(), rtol=rtol)
+    x, chain, rng = pt.replicas.states(); xr, cr, rr = ref.states()
+    assert np.array_equal(chain, cr) and np.array_equal(rng, rr)                                # same draws consumed by every replica
+    np.testing.assert_allclose(x, xr, rtol=rtol, atol=1e-12)
+
+
+@pytest.mark.parametrize("N,d,rounds,seed", [(6, 3, 5, 1), (5, 64, 4, 2), (4, 65, 4, 3), (5, 128, 3, 1), (1, 4, 4, 5)])
+def test_slice_sampler_on_the_funnel_path_parity(P, N, d, rounds, seed):
+    pt, ref = _mk_slice_funnel(P, N, d, rounds, seed)
+    assert pt.replicas.kernel_name() == "k_explore_automala"       # the register-resident path kernel, in its SliceSampler mode
+    for _ in range(rounds):
+        _check_funnel_round(P, pt, ref)
+
+
+def test_slice_sampler_funnel_compose_shards_and_errors(P):
+    # Compose(SliceSampler, AutoMALA) on the funnel path against the oracle
+    pt, ref = _mk_slice_funnel(P, 5, 20, 4, explorer=P.Compose(P.SliceSampler(), P.AutoMALA()),
+                               okw=dict(explorer=O.EXPLORER_SLICE, explorer2=O.EXPLORER_AUTOMALA, am_preconditioner=2))
+    for _ in range(4):
+        _check_funnel_round(P, pt, ref)
+    # chain shards (the library's group transport) == one engine, bit for bit
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio]
+    mk = lambda: P.Inputs(target=P.Funnel(12), reference=P.ScaledPrecisionNormalLogPotential(1.0 / 9.0, 12), n_chains=8, n_rounds=5,
+                          explorer=P.SliceSampler(), record=rec, show_report=False, seed=3)
+    one, many = P.PT(mk()), P.PT(mk(), n_shards=4, transport="group")
+    for _ in range(5):
+        P.next_round(one); ra = P.run_one_round(one); P.adapt(one, ra)
+        P.next_round(many); rb = P.run_one_round(many); P.adapt(many, rb)
+        assert np.array_equal(ra.index_process, rb.index_process) and np.array_equal(ra.explorer_n_steps[0], rb.explorer_n_steps[0])
+    xa, ca, ga = one.replicas.states(); xb, cb, gb = many.shards.states()
+    assert np.array_equal(xa, xb) and np.array_equal(ca, cb) and np.array_equal(ga, gb)
+    # slice_shrink!'s iteration cap is an error here too; a GaussianReference under it is refused, not approximated
+    bad = P.PT(P.Inputs(target=P.Funnel(6), reference=P.ScaledPrecisionNormalLogPotential(1.0 / 9.0, 6), n_chains=4, n_rounds=6,
+                        explorer=P.SliceSampler(w=1000.0, max_iter=2), record=[P.log_sum_ratio], show_report=False))
+    with pytest.raises(P.PteError, match="Maximum number of iterations"):
+        for _ in range(6):
+            P.next_round(bad); P.run_one_round(bad)
+    with pytest.raises(P.PteError, match="GaussianReference under SliceSampler"):
+        v = P.PT(P.Inputs(target=P.Funnel(6), reference=P.ScaledPrecisionNormalLogPotential(1.0 / 9.0, 6), n_chains=4, n_rounds=4,
+                          explorer=P.SliceSampler(), variational=P.GaussianReference(first_tuning_round=1), show_report=False))
+        for _ in range(3):
+            P.next_round(v); r = P.run_one_round(v); P.adapt(v, r)
+
+
+# ---------------------------------------------------------------------------------------------
 # 2-D Ising (BASELINE configs[4], reference examples/ising.jl): integer path.  Spins, chains, RNG
 # counters and the index process must be bit-exact; sum_pair_products is an integer.
 # ---------------------------------------------------------------------------------------------
