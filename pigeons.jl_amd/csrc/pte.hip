@@ -277,11 +277,11 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
             const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
             time_begin(h, 0);
             switch (E) {
-            case 1: hipLaunchKernelGGL((k_explore_automala<1, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
-            case 2: hipLaunchKernelGGL((k_explore_automala<2, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
-            case 4: hipLaunchKernelGGL((k_explore_automala<4, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
-            case 8: hipLaunchKernelGGL((k_explore_automala<8, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
-            default: hipLaunchKernelGGL((k_explore_automala<16, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
+            case 1: hipLaunchKernelGGL((k_explore_automala<1, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
+            case 2: hipLaunchKernelGGL((k_explore_automala<2, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
+            case 4: hipLaunchKernelGGL((k_explore_automala<4, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
+            case 8: hipLaunchKernelGGL((k_explore_automala<8, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
+            default: hipLaunchKernelGGL((k_explore_automala<16, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
             }
             time_end(h);
             break;
@@ -1211,7 +1211,7 @@ const char *pte_kernel_name(const pte_engine *h) {
     switch (h->cfg.explorer) {
     case PTE_EXPLORER_TOY: return "k_explore_toy";
     case PTE_EXPLORER_SLICE:
-        if (h->cfg.target == PTE_TARGET_FUNNEL) return "k_explore_automala";      // its SliceSampler mode
+        if (h->cfg.target == PTE_TARGET_FUNNEL) return "k_explore_automala";      // its SliceSampler instantiation
         switch (h->slice_impl) {
         case 1: return "k_explore_slice"; case 2: return "k_explore_slice2"; case 5: return "k_explore_slice5";
         case 7: return "k_explore_slice7";

@@ -162,7 +162,9 @@ struct AmTarget {
     }
 };
 
-template <int E, int TGT>
+// SLICE = true instantiates the same prologue (reference-chain refresh, state load) and epilogue (swap statistics, recorders)
+// around the SliceSampler sweep instead of the Langevin refreshes: a separate kernel, so that neither pays for the other's registers.
+template <int E, int TGT, bool SLICE = false>
 __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams ap) {
     constexpr int NLU = (E == 1 ? 0 : E == 2 ? 1 : E == 4 ? 2 : E == 8 ? 3 : 4);
     const int lane = lane_id();
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         return exponent;
     };
 
-    if (ap.slice) {
+    if constexpr (SLICE) {
         // ---- step!(::SliceSampler) on a path without a closed-form single-coordinate update: the reference's procedure as it
         // stands (slice_sample! :43-62, slice_sample_coord! :89-95, slice_double :97-126, slice_shrink! :144-186, slice_accept
         // :192-237), every log potential evaluated in full (E wave reductions of the fixed tree + the funnel's exp / log),

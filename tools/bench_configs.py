@@ -18,6 +18,8 @@ run("metric toy_mvn(1024) N=1024 SliceSampler", P.Inputs(target=P.toy_mvn_target
 run("toy_mvn(1024) N=1024 ToyExplorer (HBM-bound explore)", P.Inputs(target=P.toy_mvn_target(1024), n_chains=1024, record=rec, n_rounds=20, show_report=False), 256, 16)
 run("toy_mvn(4096) N=8192 ToyExplorer", P.Inputs(target=P.toy_mvn_target(4096), n_chains=8192, record=rec, n_rounds=20, show_report=False), 64, 8)
 run("C3 funnel(128) N=1024 AutoMALA", P.Inputs(target=P.Funnel(128), reference=P.ScaledPrecisionNormalLogPotential(1/9., 128), n_chains=1024, explorer=P.AutoMALA(), record=rec, n_rounds=20, show_report=False), 64, 8)
-run("funnel(128) N=1024 SliceSampler (full log potential per proposal)", P.Inputs(target=P.Funnel(128), reference=P.ScaledPrecisionNormalLogPotential(1/9., 128), n_chains=1024, explorer=P.SliceSampler(), record=rec, n_rounds=20, show_report=False), 16, 4)
+# (at d = 128 the coordinate-wise sampler started from zeros(d) walks y = z[1] towards -(d-1) * 4.5 and sigma = exp(y/2) underflows: the reference's
+#  own procedure ends in "Maximum number of iterations reached" there -- the oracle does too; d = 32 is stable)
+run("funnel(32) N=1024 SliceSampler (full log potential per proposal)", P.Inputs(target=P.Funnel(32), reference=P.ScaledPrecisionNormalLogPotential(1/9., 32), n_chains=1024, explorer=P.SliceSampler(), record=rec, n_rounds=20, show_report=False), 16, 4)
 run("C4 shard: toy_mvn(4096) N=1024 SliceSampler", P.Inputs(target=P.toy_mvn_target(4096), n_chains=1024, explorer=P.SliceSampler(), record=rec, n_rounds=20, show_report=False), 8, 2)
 run("C5 shard: Ising 256x256 N=512 IsingMetropolis", P.Inputs(target=P.IsingLogPotential(1.0, 256), n_chains=512, record=rec, n_rounds=20, show_report=False), 4, 1)
