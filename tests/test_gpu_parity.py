@@ -248,7 +248,9 @@ def test_errors_are_loud(P):
     bad = [dict(n_chains=0), dict(n_chains=4, dim=0), dict(n_chains=4, dim=8, explorer=99), dict(n_chains=5, world_size=2),
            dict(n_chains=4, n_chains_variational=4, world_size=2, rank=0),                         # two legs are single-engine
            dict(n_chains=4, dim=8, explorer=L.EXPLORER_SLICE, explorer2=L.EXPLORER_TOY),            # Compose set
-           dict(n_chains=4, dim=8, target=L.TARGET_FUNNEL, explorer=L.EXPLORER_SLICE),             # funnel: Langevin kernels only
+           dict(n_chains=4, dim=8, target=L.TARGET_FUNNEL, explorer=L.EXPLORER_TOY),               # funnel: AutoMALA / MALA / SliceSampler
+           dict(n_chains=4, dim=2000, target=L.TARGET_FUNNEL, explorer=L.EXPLORER_SLICE),          # ... register-resident: dim <= 1024
+           dict(n_chains=4, dim=8, target=L.TARGET_FUNNEL, explorer=L.EXPLORER_SLICE, debug_kernel=1),
            dict(n_chains=4, dim=2000, explorer=L.EXPLORER_AUTOMALA),                               # register-resident bound
            dict(n_chains=4, dim=49, target=L.TARGET_ISING, explorer=L.EXPLORER_SLICE),
            dict(n_chains=4, dim=8, record_flags=L.RECORD_TRACES_EXTENDED)]                         # extended needs traces
