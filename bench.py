@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (weak) / in total (strong)")
     ap.add_argument("--explorer", default="slice", choices=["slice", "toy"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timeout-s", type=float, default=1500.0,
+                    help="watchdog: a rank (or the launcher) that is still running after this many seconds reports it and exits "
+                         "non-zero instead of sitting in a collective for ever")
     ap.add_argument("--round-trip-rounds", type=int, default=15,
                     help="untimed leg after the timed region: rounds 1..R of the reference's round loop with schedule "
                          "adaptation; the round-trip rate is read off the last round (2^R scans).  0 = skip")
@@ -71,10 +74,18 @@ def launch(args):
                                       stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
     # wait for all; a rank that dies would leave its peers blocked in a collective, so the first failure ends the others
     rcs = [None] * len(procs)
+    t_start = time.time()
     while any(rc is None for rc in rcs):
         for i, p in enumerate(procs):
             if rcs[i] is None:
                 rcs[i] = p.poll()
+        if time.time() - t_start > args.timeout_s + 60.0:        # (the ranks' own watchdogs fire first)
+            sys.stderr.write("bench.py: ranks still running after %.0f s, ending them\n" % (time.time() - t_start))
+            for i, p in enumerate(procs):
+                if rcs[i] is None and p.poll() is None:
+                    p.kill()                                 # exactly the PIDs started above
+            rcs = [p.wait() or 124 for p in procs]
+            break
         if any(rc not in (None, 0) for rc in rcs):
             time.sleep(2.0)
             for i, p in enumerate(procs):
@@ -156,6 +167,15 @@ def main():
         sys.exit(launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(world_env or "1")
+
+    def _watchdog():
+        sys.stderr.write("bench.py rank %d: still running after %.0f s (a peer died or a collective hangs); giving up\n" % (rank, args.timeout_s))
+        sys.stderr.flush()
+        os._exit(124)
+    import threading
+    wd = threading.Timer(args.timeout_s, _watchdog)
+    wd.daemon = True
+    wd.start()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -192,7 +212,7 @@ def main():
         total_chains = n_chains * world
     explorer = P.SliceSampler() if args.explorer == "slice" else P.ToyExplorer()
     rt_rounds = max(args.round_trip_rounds, 0)
-    inputs = P.Inputs(target=P.toy_mvn_target(d), n_chains=total_chains, n_rounds=max(rt_rounds, 1), explorer=explorer, seed=1,
+    inputs = P.Inputs(target=P.toy_mvn_target(d), n_chains=total_chains, n_rounds=max(rt_rounds, 1), explorer=explorer, seed=1,     # (n_rounds only sizes buffers that this run does not record)
                       record=[P.round_trip, P.log_sum_ratio], show_report=False, device=local_rank)
     transport = "single GPU"
     if world > 1:
@@ -257,9 +277,13 @@ def main():
     # round-trip half of the metric (src/recorders/RoundTripRecorder.jl:23): untimed, the reference's own
     # round loop -- rounds 1..R with schedule adaptation after each -- the rate is n_round_trips(last round) / 2^R
     rt = None
+    if rt_rounds > 0:          # keep the untimed leg near 90 s whatever the workload: rounds 1..R run 2^(R+1) - 2 scans (same R on every rank: dt is the max over ranks)
+        import math
+        rt_rounds = max(1, min(rt_rounds, int(math.floor(math.log2(90.0 / max(dt / K, 1e-6)))) - 1))
     if rt_rounds > 0 and args.explorer == "slice":
         t1 = time.perf_counter()
         pt.shared.iterators.round = 0
+        pt.inputs.n_rounds = rt_rounds
         last = None
         while next_round(pt):
             last = run_one_round(pt)
@@ -327,6 +351,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    wd.cancel()
 
 
 if __name__ == "__main__":
