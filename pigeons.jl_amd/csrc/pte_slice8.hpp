@@ -38,12 +38,15 @@ namespace pte {
 #endif
 constexpr int S8_BD = PTE_S8_BD;                 // doubling budget of a speculative hypothesis (=> its acceptance check has <= 2 halvings); the shrinkage budget S8_BS is a template parameter
 
-#ifndef PTE_S8_WAVES                     // resident waves per SIMD the register allocation must allow (4 <=> 128 VGPRs)
+#ifndef PTE_S8_WAVES                     // occupancy hint to the register allocator (waves per SIMD)
 #define PTE_S8_WAVES 4
 #endif
 // The body is shared by two kernels that differ in the size of the LDS draw window: 512 draws convert fewer draws twice
-// (1.2 % faster), 256 draws keep the block at 10 KB of LDS, i.e. 16 resident replicas per CU (4 per SIMD) when a GPU holds
-// more than ~2800 replicas.
+// (1.2 % faster), 256 draws keep the block at 10 KB of LDS when a GPU holds more than ~2800 replicas.  Register use is
+// ~145 VGPRs whatever the hint says (the hand-scheduled shrinkage block pins v96-v113), i.e. 3 resident waves per SIMD,
+// 12 replicas per CU; forcing 128 VGPRs (amdgpu_num_vgpr: 4 waves per SIMD, 36 B of scratch per lane) was measured at
+// 3072 / 4096 / 8192 replicas and changes nothing (1.875 / 2.318 / 4.250 against 1.877 / 2.316 / 4.252 ms): three waves
+// already saturate a SIMD's issue slots.
 template <int NLU, int S8_BS, int WINDOW>
 __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
     using namespace s7;
