@@ -348,10 +348,20 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out))
         sys.stdout.flush()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     wd.cancel()
+    if dist is not None:
+        # orderly teardown, every rank at the same point: the engine's communicator first, then torch's; nothing in it can
+        # change the result any more, so a teardown hiccup must not turn a measured run into a failed one
+        try:
+            dist.barrier()
+            if hasattr(eng, "comm_destroy"):
+                eng.comm_destroy()
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as exc:
+            sys.stderr.write("bench.py rank %d: teardown: %r\n" % (rank, exc))
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
