@@ -46,6 +46,10 @@ def parse_args():
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (weak) / in total (strong)")
     ap.add_argument("--explorer", default="slice", choices=["slice", "toy"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--same-device", action="store_true",
+                    help="TEST ONLY: every rank uses HIP device 0 (the control plane then runs over gloo, and the data path needs an "
+                         "RCCL stand-in that accepts two ranks on one device: $PTE_RCCL_LIB=tests/fakerccl/libfakerccl.so); "
+                         "the line says so and is not a measurement")
     ap.add_argument("--timeout-s", type=float, default=1500.0,
                     help="watchdog: a rank (or the launcher) that is still running after this many seconds reports it and exits "
                          "non-zero instead of sitting in a collective for ever")
@@ -176,7 +180,7 @@ def main():
     wd = threading.Timer(args.timeout_s, _watchdog)
     wd.daemon = True
     wd.start()
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # the CPU baseline leg pins one OpenMP thread per physical core; libgomp reads this when it is first mapped
@@ -188,7 +192,7 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("PTE_BENCH_BACKEND", "nccl")          # nccl == RCCL on ROCm (control plane only)
+        backend = "gloo" if args.same_device else os.environ.get("PTE_BENCH_BACKEND", "nccl")   # nccl == RCCL on ROCm (control plane only)
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -322,7 +326,9 @@ def main():
         "config": {"workload": "toy_mvn_target(%d), n_chains=%d per GPU x %d GPU, %s, seed=1, DEO swaps every scan"
                                % (d, n_chains, world, "SliceSampler(w=10,p=20,n_passes=3)" if args.explorer == "slice" else "ToyExplorer"),
                    "sharding": ("chains sharded over %d GPUs, boundary replicas only; transport: %s" % (world, transport)) if world > 1 else "single GPU",
-                   "n_ranks_seen": ranks_seen, "boundary_swaps_per_rank": boundary, "ms_per_step_per_rank": per_rank_ms},
+                   "n_ranks_seen": ranks_seen, "boundary_swaps_per_rank": boundary, "ms_per_step_per_rank": per_rank_ms,
+                   **({"same_device_test_run": "every rank on HIP device 0 with an RCCL stand-in ($PTE_RCCL_LIB=%s): exercises the "
+                       "multi-rank code path, NOT a measurement" % os.environ.get("PTE_RCCL_LIB", "")} if args.same_device else {})},
         "round_trip_rate": rt["round_trip_rate"] if rt else None, "n_round_trips": rt["n_round_trips"] if rt else None,
         "n_tempered_restarts": rt["n_tempered_restarts"] if rt else None, "round_trip": rt,
         "lp_evals_per_replica_step": lp_evals,

@@ -22,6 +22,11 @@
 #include "pte_slice8.hpp"
 #include "pte_automala.hpp"
 #include "pte_ising.hpp"
+#ifdef PTE_PROFILE_WAVES                   // debug builds only (tools/prof_waves.py): per-wave start / end / placement of the explore kernel
+#define PTE_WAVE_PROFILE_WORDS 4
+#else
+#define PTE_WAVE_PROFILE_WORDS 0
+#endif
 #include "pte_comm.hpp"
 
 using namespace pte;
@@ -294,7 +299,7 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
         } else if (h->slice_impl == 8) {
             // shrinkage steps for every hypothesis: PTE_S8_BS = 9, re-measured after every change of the round's cost (tools/bench_variant.py)
             // 14 KB of LDS per replica (512-draw window) allow 11 replicas per CU; beyond 256 x 11 the 10 KB variant keeps 16
-            if (N <= 256 * 11) { DISPATCH_NLU_M(h->nlu, k_explore_slice8, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp); }
+            if (N <= PTE_S8_TWIN_FROM) { DISPATCH_NLU_M(h->nlu, k_explore_slice8, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp); }
             else { DISPATCH_NLU_M(h->nlu, k_explore_slice8_lds10k, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp); }
         }
 #ifdef PTE_TEST_KERNELS
@@ -524,7 +529,7 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.rt_trips, (size_t)K);
     rc |= dev_alloc(h, &e.expl_acc_sum, (size_t)K);   rc |= dev_alloc(h, &e.expl_acc_n, (size_t)K);
     rc |= dev_alloc(h, &e.expl_steps_sum, (size_t)K); rc |= dev_alloc(h, &e.expl_steps_n, (size_t)K);
-    rc |= dev_alloc(h, &e.on_mean, (size_t)(2 * (d + 1)));   rc |= dev_alloc(h, &e.on_m2, (size_t)(2 * (d + 1)));
+    rc |= dev_alloc(h, &e.on_mean, (size_t)(2 * (d + 1)));   rc |= dev_alloc(h, &e.on_m2, (size_t)(2 * (d + 1)) + PTE_WAVE_PROFILE_WORDS * (size_t)K);   // (+ 4 words per wave in -DPTE_PROFILE_WAVES builds)
     rc |= dev_alloc(h, &e.eac, (size_t)(5 * K)); rc |= dev_alloc(h, &e.eac_n, (size_t)K);
     rc |= dev_alloc(h, &e.lp_stash, (size_t)K);
     const int64_t trace_rows = (cfg->record_flags & PTE_RECORD_TRACES_EXTENDED) ? K : (cfg->n_chains_variational > 0 ? 2 : 1);   // chains traced per scan
@@ -1215,7 +1220,7 @@ const char *pte_kernel_name(const pte_engine *h) {
         switch (h->slice_impl) {
         case 1: return "k_explore_slice"; case 2: return "k_explore_slice2"; case 5: return "k_explore_slice5";
         case 7: return "k_explore_slice7";
-        default: return h->K <= 256 * 11 ? "k_explore_slice8" : "k_explore_slice8_lds10k";
+        default: return h->K <= PTE_S8_TWIN_FROM ? "k_explore_slice8" : "k_explore_slice8_lds10k";
         }
     case PTE_EXPLORER_AUTOMALA: case PTE_EXPLORER_MALA: return "k_explore_automala";
     case PTE_EXPLORER_ISING_METROPOLIS: {
@@ -1430,3 +1435,14 @@ int pte_test_sqr_norm(int32_t device, const double *x, int64_t rows, int64_t d, 
 }
 
 }  // extern "C"
+
+#ifdef PTE_PROFILE_WAVES
+// debug builds only: out[4K] = per local chain {start, end on the 100 MHz clock, HW_ID, XCC_ID} of the last explore launch
+extern "C" int pte_debug_wave_profile(pte_engine *h, double *out) {
+    if (!h || !out) return 1;
+    HIP_OK(h, hipSetDevice(h->cfg.device));
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    HIP_OK(h, hipMemcpy(out, h->dev.on_m2 + 2 * (h->d + 1), sizeof(double) * 4 * (size_t)h->K, hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif

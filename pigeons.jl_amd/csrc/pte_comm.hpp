@@ -34,8 +34,8 @@ struct RcclApi {
     std::string where;
 };
 
-// Returns nullptr and fills `err` when no RCCL can be mapped.  Search order: a copy already in the process
-// (RTLD_NOLOAD by SONAME), $PTE_RCCL_LIB, the loader's search path, /opt/rocm/lib.
+// Returns nullptr and fills `err` when no RCCL can be mapped.  Search order: $PTE_RCCL_LIB (explicit override), a copy
+// already in the process (RTLD_NOLOAD by SONAME), the loader's search path, /opt/rocm/lib.
 inline RcclApi *rccl_api(std::string &err) {
     static RcclApi api;
     static bool tried = false;
@@ -43,13 +43,25 @@ inline RcclApi *rccl_api(std::string &err) {
     if (api.lib) return &api;
     if (tried) { err = first_err; return nullptr; }
     tried = true;
-    void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
-    std::string where = "librccl.so.1 (already mapped)";
+    // an explicit $PTE_RCCL_LIB wins over everything (also over a copy the process has already mapped: tests hand in a
+    // stand-in this way, tests/fakerccl); an unloadable override is an error, not a reason to fall through to another library
+    void *lib = nullptr;
+    std::string where;
+    const char *env = std::getenv("PTE_RCCL_LIB");
+    if (env && *env) {
+        lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+        where = env;
+        if (!lib) {
+            const char *e = dlerror();
+            first_err = std::string("RCCL override $PTE_RCCL_LIB=") + env + " cannot be loaded (" + (e ? e : "?") + ")";
+            err = first_err;
+            return nullptr;
+        }
+    }
+    if (!lib) { lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD); where = "librccl.so.1 (already mapped)"; }
     if (!lib) {
-        const char *env = std::getenv("PTE_RCCL_LIB");
-        const char *cands[] = {env, "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+        const char *cands[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
         for (const char *c : cands) {
-            if (!c || !*c) continue;
             lib = dlopen(c, RTLD_NOW | RTLD_LOCAL);
             if (lib) { where = c; break; }
         }

@@ -61,6 +61,9 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
     constexpr int BLK = PTE_S8_BLK, CPB = BLK / 64;  // coordinates per block (rounds do not reach across a block end) = CPB 64-leaf chunks of the tree
     __shared__ double s_x[BLK];              // the current block: start-of-pass values, overwritten as coordinates retire
     const int lane = lane_id();
+#ifdef PTE_PROFILE_WAVES
+    const uint64_t wave_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int i = lane; i < 256; i += 64) { s_we[i] = ZIG_WE[i]; s_ke[i] = ZIG_KE[i]; }
     __syncthreads();
     const int64_t cl = blockIdx.x;
@@ -562,14 +565,27 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
 #endif
     }
     record_after_explore(e, cl, c, slot, lane, lp_before, S, 0.0);
+#ifdef PTE_PROFILE_WAVES
+    if (lane == 0) {
+        double *o = e.on_m2 + 2 * (e.d + 1) + 4 * cl;
+        o[0] = (double)wave_t0; o[1] = (double)__builtin_amdgcn_s_memrealtime();
+        o[2] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4); o[3] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
 }
 
 template <int NLU, int S8_BS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES, PTE_S8_WAVES))) void k_explore_slice8(EngineDev e, SliceParams sp) {
     slice8_body<NLU, S8_BS, PTE_S7_WIN>(e, sp);
 }
+#ifndef PTE_S8_TWIN_WAVES
+#define PTE_S8_TWIN_WAVES PTE_S8_WAVES
+#endif
+#ifndef PTE_S8_TWIN_FROM                 // more local replicas than this run the 10 KB-LDS twin
+#define PTE_S8_TWIN_FROM (256 * 11)
+#endif
 template <int NLU, int S8_BS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES, PTE_S8_WAVES))) void k_explore_slice8_lds10k(EngineDev e, SliceParams sp) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_TWIN_WAVES, PTE_S8_TWIN_WAVES))) void k_explore_slice8_lds10k(EngineDev e, SliceParams sp) {
     slice8_body<NLU, S8_BS, 256>(e, sp);
 }
 

@@ -486,7 +486,7 @@ def _mk_am(P, N, d, rounds, target="mvn", seed=1, precond=None):
     return P.PT(inp), ref
 
 
-def _check_am_round(P, pt, ref, rtol):
+def _check_am_round(P, pt, ref, rtol, acc_rtol=None):
     assert P.next_round(pt)
     red = P.run_one_round(pt)
     P.adapt(pt, red)
@@ -505,7 +505,7 @@ def _check_am_round(P, pt, ref, rtol):
     np.testing.assert_allclose(rm, rmr, rtol=1e-12)
     am, an = red.explorer_acceptance_pr
     assert np.array_equal(an, anr)
-    np.testing.assert_allclose(am, amr, rtol=rtol, atol=1e-300)
+    np.testing.assert_allclose(am, amr, rtol=acc_rtol or rtol, atol=1e-300)
     m, n = red.swap_acceptance_pr
     mr, nr = ref.swap_pr()
     assert np.array_equal(n, nr)
