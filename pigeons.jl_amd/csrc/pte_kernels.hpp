@@ -14,6 +14,7 @@
 // One wavefront per replica; mapping chain -> wave so that wave c works at beta_c.
 #pragma once
 #include "pte_device.hpp"
+#include "pte_normals.hpp"
 
 namespace pte {
 
@@ -83,7 +84,9 @@ __device__ __forceinline__ void set_error(const EngineDev &e, int code, int chai
 // ---------------------------------------------------------------------------------------------
 template <int NLU>
 __global__ __launch_bounds__(64) void k_init(EngineDev e, uint64_t master_seed, double init_sd) {
+    __shared__ NormalsLds L;
     const int lane = lane_id();
+    normals_lds_init(L, lane);
     const int64_t il = blockIdx.x;            // local slot
     if (il >= e.K) return;
     const int64_t i = e.c0 + il;              // global replica index == initial chain
@@ -92,17 +95,7 @@ __global__ __launch_bounds__(64) void k_init(EngineDev e, uint64_t master_seed, 
     r.seed = mix64(master_seed + (uint64_t)(2 * i + 1) * G);
     r.gamma = mix_gamma(master_seed + (uint64_t)(2 * i + 2) * G);
     if (e.d > 0) {
-        double *xrow = e.x + il * e.ld;
-        const int B = (int)((e.d + 63) >> 6);
-        double BS = 0.0;
-        for (int b = 0; b < B; ++b) {
-            int nl = (int)min((int64_t)64, e.d - 64 * (int64_t)b);
-            double v = wave_randn_block(r, lane, nl) / init_sd;
-            if (lane < nl) xrow[64 * b + lane] = v; else v = 0.0;
-            double s = wave_tree_sum64(v * v);
-            if (lane == b) BS = s;
-        }
-        double S = upper_tree_root<NLU>(BS);
+        const double S = upper_tree_root<NLU>(normals_row(L, r, e.x + il * e.ld, e.d, init_sd, lane));
         if (lane == 0) e.suff[il] = S;
     }
     if (lane == 0) {
@@ -228,16 +221,19 @@ __device__ __forceinline__ void iid_refresh_recorded(const EngineDev &e, int64_t
 // ---------------------------------------------------------------------------------------------
 template <int NLU>
 __global__ __launch_bounds__(64) void k_explore_toy(EngineDev e) {
-    __shared__ double s_wi[256];                          // ziggurat tables in LDS: the per-lane lookups are gathers
-    __shared__ unsigned long long s_ki[256];
+    __shared__ NormalsLds L;                              // ziggurat tables, the chunk's values by stream position, event list, block sums
     const int lane = lane_id();
-    for (int i = lane; i < 256; i += 64) { s_wi[i] = ZIG_WI[i]; s_ki[i] = ZIG_KI[i]; }
-    __syncthreads();
+    normals_lds_init(L, lane);
     const int64_t cl = blockIdx.x;
     if (cl >= e.K) return;
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];
-    iid_refresh_recorded<NLU>(e, cl, c, slot, e.sd[c], lane, s_wi, s_ki);
+    if (e.compose_phase == 2) return;                     // the first explorer's kernel already did
+    const double lp0 = lp_before_explore(e, c, slot);
+    SeqRng r{e.rng[2 * slot], e.rng[2 * slot + 1]};
+    const double S = upper_tree_root<NLU>(normals_row(L, r, e.x + (int64_t)slot * e.ld, e.d, e.sd[c], lane));
+    if (lane == 0) { e.suff[slot] = S; e.rng[2 * slot] = r.seed; }
+    record_after_explore_impl(e, cl, c, slot, lane, lp0, S, 0.0);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -486,7 +486,7 @@ def _mk_am(P, N, d, rounds, target="mvn", seed=1, precond=None):
     return P.PT(inp), ref
 
 
-def _check_am_round(P, pt, ref, rtol, acc_rtol=None):
+def _check_am_round(P, pt, ref, rtol, acc_rtol=None, state_atol=None):
     assert P.next_round(pt)
     red = P.run_one_round(pt)
     P.adapt(pt, red)
@@ -521,7 +521,7 @@ def _check_am_round(P, pt, ref, rtol, acc_rtol=None):
     x, chain, rng = pt.replicas.states()
     xr, cr, rr = ref.states()
     assert np.array_equal(chain, cr) and np.array_equal(rng, rr)
-    np.testing.assert_allclose(x, xr, rtol=rtol, atol=1e-9 * rtol / 1e-6)
+    np.testing.assert_allclose(x, xr, rtol=rtol, atol=state_atol or 1e-9 * rtol / 1e-6)
 
 
 @pytest.mark.parametrize("N,d,rounds,seed", [(6, 10, 7, 1), (5, 64, 5, 2), (8, 128, 5, 1), (4, 200, 4, 3), (3, 1000, 3, 1)])

@@ -3,7 +3,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pigeons.jl_amd")]
 import pigeons_amd as P
-for N, d in ((8192, 4096), (8192, 1024), (1024, 1024)):
+for N, d in ((8192, 4096), (8192, 1024), (1024, 1024))[:1 if os.environ.get('PTE_BENCH_TOY_ONLY_FIRST') else 3]:
     pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, record=[P.log_sum_ratio], n_rounds=20, show_report=False))
     e = pt.replicas
     e.run_scans(1, 8)
