@@ -268,7 +268,7 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
     case PTE_EXPLORER_NONE: return 0;
     case PTE_EXPLORER_TOY:
         time_begin(h, 0);
-        DISPATCH_NLU(h->nlu, k_explore_toy, dim3((unsigned)N), dim3(64), h->stream, h->dev);
+        DISPATCH_NLU(h->nlu, k_explore_toy, dim3((unsigned)((N + NRM_WPB - 1) / NRM_WPB)), dim3(64 * NRM_WPB), h->stream, h->dev);
         time_end(h);
         break;
     case PTE_EXPLORER_SLICE:
@@ -564,7 +564,7 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     if (upload_ladder(h)) return bail(1);
     if (reset_recorders(h)) return bail(1);
     const double init_sd = swapper ? 1.0 : std::sqrt(cfg->target_params[1]);   // toy_mvn_target.jl:10-11
-    if (!ising) { DISPATCH_NLU(h->nlu, k_init, dim3((unsigned)K), dim3(64), h->stream, e, (uint64_t)cfg->seed, init_sd); }
+    if (!ising) { DISPATCH_NLU(h->nlu, k_init, dim3((unsigned)((K + NRM_WPB - 1) / NRM_WPB)), dim3(64 * NRM_WPB), h->stream, e, (uint64_t)cfg->seed, init_sd); }
     else {
         std::vector<int32_t> ch((size_t)K), sl((size_t)K); std::vector<int64_t> rid((size_t)K);
         for (int64_t il = 0; il < K; ++il) { ch[il] = (int32_t)(h->c0 + il); sl[il] = (int32_t)il; rid[il] = h->c0 + il; }

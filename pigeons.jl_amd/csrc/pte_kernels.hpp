@@ -83,11 +83,11 @@ __device__ __forceinline__ void set_error(const EngineDev &e, int code, int chai
 // SplittableRandom(seed); the split is counter based, so every wave derives its own stream.
 // ---------------------------------------------------------------------------------------------
 template <int NLU>
-__global__ __launch_bounds__(64) void k_init(EngineDev e, uint64_t master_seed, double init_sd) {
+__global__ __launch_bounds__(64 * NRM_WPB) NRM_ATTR void k_init(EngineDev e, uint64_t master_seed, double init_sd) {
     __shared__ NormalsLds L;
     const int lane = lane_id();
     normals_lds_init(L, lane);
-    const int64_t il = blockIdx.x;            // local slot
+    const int64_t il = (int64_t)blockIdx.x * NRM_WPB + (NRM_WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0);   // local slot: one wave per replica (wave-uniform)
     if (il >= e.K) return;
     const int64_t i = e.c0 + il;              // global replica index == initial chain
     const uint64_t G = 0x9e3779b97f4a7c15ULL;
@@ -220,11 +220,11 @@ __device__ __forceinline__ void iid_refresh_recorded(const EngineDev &e, int64_t
 // HBM-write bound: 8d bytes stored per replica.
 // ---------------------------------------------------------------------------------------------
 template <int NLU>
-__global__ __launch_bounds__(64) void k_explore_toy(EngineDev e) {
+__global__ __launch_bounds__(64 * NRM_WPB) NRM_ATTR void k_explore_toy(EngineDev e) {
     __shared__ NormalsLds L;                              // ziggurat tables, the chunk's values by stream position, event list, block sums
     const int lane = lane_id();
     normals_lds_init(L, lane);
-    const int64_t cl = blockIdx.x;
+    const int64_t cl = (int64_t)blockIdx.x * NRM_WPB + (NRM_WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0);   // wave-uniform
     if (cl >= e.K) return;
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];

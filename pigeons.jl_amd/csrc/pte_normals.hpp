@@ -3,19 +3,23 @@
 // :10-11; ToyExplorer.jl:7-12) and returns the fixed-tree sum of squares.  Bit-identical to wave_randn_block + x / sd
 // (pte_device.hpp), organised for HBM-rate output (round 3).
 //
-// The stream is counter based (draw k = mix64(seed + k gamma)), but output i does not sit at stream position i: 1.2 % of the
+// The stream is counter based (draw k = mix64(seed + k gamma)), but output i does not sit at stream position i: 1.5 % of the
 // ziggurat draws leave the fast path and consume extra draws (wedge test: one uniform, then either the same value or a fresh
 // attempt; tail: a loop of pairs).  What the old kernel did per 64 draws -- resolve the first such event sequentially, re-draw
-// the lanes behind it, repeat (54 % of the blocks) -- is amortised here over a CHUNK of 512 outputs:
-//   1. every lane evaluates 9 stream positions (576 = 512 + 64 slack): value as if the fast path applied (the wedge's accepted
-//      value is the same expression), stored to LDS by POSITION; the non-fast positions are compacted into an event list;
-//   2. ONE divergent pass: event lane e re-derives its draw and the next one and runs the wedge test (exp); tails are rare
-//      (3e-4 of the draws) and resolved by the exact sequential code;
-//   3. a scalar walk over the (sorted) events yields the map output -> position: position = output + shift, the shift grows by
-//      1 at an accepted wedge (its uniform), by 2 at a rejected one (draw + uniform, the output restarts), by the tail's draws;
-//   4. outputs are gathered from LDS at output + shift, FOUR CONSECUTIVE OUTPUTS PER LANE (32-byte stores), divided by sd,
-//      squared and summed: the first two levels of the fixed tree are in-lane adds, four DPP steps finish four 64-leaf blocks
-//      at once (the old layout, one leaf per lane, paid six DPP steps per block: 4.2 SIMD cycles per v_mov_b32_dpp).
+// the lanes behind it, repeat (54 % of the blocks) -- becomes a STREAM COMPACTION over a chunk of 512 outputs:
+//   1. every lane evaluates 9 stream positions (576 = 512 + 64 slack) and keeps the values in registers: the value as if the
+//      fast path applied (the wedge's accepted value is the same expression); the non-fast positions go to an event list;
+//   2. ONE divergent pass: event lane e re-derives its draw and the next one and runs the wedge test (exp), or the tail's loop;
+//   3. lane-parallel over the (sorted) events: which of them start an attempt (an event whose position was consumed by the live
+//      event before it does not), a prefix sum of the consumed draws, and a bitmap of the CONSUMED positions (an accepted wedge
+//      consumes the uniform behind it; a rejected one its own draw and the uniform; a tail its trials);
+//   4. every position that was not consumed is an output: its index is a running count (ballot prefix, v_mbcnt) -- the values
+//      are written to LDS in OUTPUT order; a tail writes its value over the slot of its position;
+//   5. outputs are read back FOUR CONSECUTIVE PER LANE (two 16-byte LDS reads, 32-byte stores), divided by sd, squared and
+//      summed: the first two levels of the fixed tree are in-lane adds, four DPP steps finish four 64-leaf blocks at once (the
+//      old layout, one leaf per lane, paid six DPP steps per block at 4.2 SIMD cycles per v_mov_b32_dpp).
+// No loop over events anywhere, no scalar hop per event: a lone wave went from 9,900 cycles per chunk (scalar walk over the
+// events: 4,900 of them) to the issue time of its ~650 VALU instructions.
 // x / sd is q = x r, q' = fma(fma(-q, sd, x), r, q) with r = RN(1 / sd): correctly rounded (Markstein 1990, Thm: y = RN(1/b),
 // q = RN(a y), then RN(q + RN(a - b q) y) = RN(a / b) unless b's significand is all ones -- that case takes the IEEE division;
 // 4e8 random (x, sd) pairs against x / sd on the host: 0 mismatches; tests/test_gpu_normals.py holds the device to x / sd).
@@ -39,17 +43,54 @@ constexpr int NRM_MAX_EV = 64;              // events resolved lane-parallel per
 // array).  NRM_PAD = 1 puts element i at i + (i >> 5), which spreads the strided reads over all banks -- measured: no gain (the
 // kernel is not bound by the LDS), so the dense layout stays.
 __device__ __forceinline__ constexpr int nrm_pad(int i) { return NRM_PAD ? i + (i >> 5) : i; }
-struct NormalsLds {                         // one per wave (= per workgroup)
+#ifndef NRM_OCC
+#define NRM_OCC 4                           // > 0: waves per SIMD the register allocation must allow (measured 3 / 4 / 5: 2.59 / 2.71 / 0.94 TB/s at N = 32768 -- 5 spills 64 VGPRs)
+#endif
+#if NRM_OCC > 0
+#define NRM_ATTR __attribute__((amdgpu_waves_per_eu(NRM_OCC, NRM_OCC)))
+#else
+#define NRM_ATTR
+#endif
+#ifndef NRM_FI_LDS
+#define NRM_FI_LDS 1
+#endif
+#ifndef NRM_WPB
+#define NRM_WPB 4                           // waves (replicas) per workgroup; they share the ziggurat tables (6 KB)
+#endif
+struct NormalsLds {                         // one per workgroup
     double wi[256];
     unsigned long long ki[256];             // (directly behind wi: one ds_read2st64_b64 fetches both)
-    double val[NRM_CP + NRM_CP / 32 + 2];
-    int ev[NRM_MAX_EV];
-    double bs[64];
+#if NRM_FI_LDS
+    double fi[256];                         // wedge test of the event pass
+#endif
+    alignas(16) double out[NRM_WPB][NRM_CO];    // the chunk's values in OUTPUT order
+    unsigned long long del[NRM_WPB][NRM_SLOTS]; // bitmap of the consumed stream positions
+    int ev[NRM_WPB][NRM_MAX_EV];
+    double bs[NRM_WPB][64];
+#ifdef NRM_PROF                             // tools/ubench/normals_prof.hip only: cycles per phase
+    unsigned long long prof[8];
+#endif
 };
 
 __device__ __forceinline__ void normals_lds_init(NormalsLds &L, int lane) {
-    for (int i = lane; i < 256; i += 64) { L.wi[i] = ZIG_WI[i]; L.ki[i] = ZIG_KI[i]; }
+    for (int i = NRM_WPB > 1 ? (int)threadIdx.x : lane; i < 256; i += 64 * NRM_WPB) {
+        L.wi[i] = ZIG_WI[i]; L.ki[i] = ZIG_KI[i];
+#if NRM_FI_LDS
+        L.fi[i] = ZIG_FI[i];
+#endif
+    }
     __syncthreads();
+}
+
+// inclusive prefix sum over the 64 lanes (Kogge-Stone inside the rows of 16 by row_shr 1, 2, 4, 8; then the row totals)
+__device__ __forceinline__ int wave_iscan_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast31 -> rows 2, 3
+    return v;
 }
 
 __device__ __forceinline__ double dpp_row_step(double v, int which) {
@@ -65,6 +106,7 @@ __device__ __forceinline__ double dpp_row_step(double v, int which) {
 // Fills xrow[0 .. d) and returns lane b = sum of squares of block b (64 leaves), to be fed to upper_tree_root<NLU>.
 // `r` is advanced exactly as d sequential randn(rng) calls would advance it.  One wave per workgroup.
 __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *xrow, int64_t d, double sd, int lane) {
+    const int wv = NRM_WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;      // wave-uniform (kept in an SGPR)
     const double rinv = 1.0 / sd;
     const bool markstein = (__double_as_longlong(sd) & 0x000fffffffffffffLL) != 0x000fffffffffffffLL;      // uniform
     const uint64_t gamma = r.gamma;
@@ -72,100 +114,153 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
     int64_t done = 0;                                       // outputs written so far (a multiple of 256 until the last group)
     while (done < d) {
         // ---- 1. positions base + 1 .. base + NRM_CP of the stream
+#ifdef NRM_PROF
+        const unsigned long long pt0 = __builtin_readcyclecounter();
+#endif
         const uint64_t base = r.seed;
         uint64_t zc = base + (uint64_t)(lane + 1) * gamma;
         int n_ev = 0;                                       // uniform
+        double v[NRM_SLOTS];
+        if (lane < NRM_SLOTS) L.del[wv][lane] = 0ull;
         __builtin_amdgcn_wave_barrier();
-#pragma unroll NRM_UNROLL
+#pragma unroll
         for (int j = 0; j < NRM_SLOTS; ++j) {
             const uint64_t raw = mix64(zc) & MASK52;
             zc += g64;
             const uint64_t rabs = raw >> 1;
             const int idx = (int)(rabs & 0xFF);
-                        const double w = L.wi[idx];
+            const double w = L.wi[idx];
             const unsigned long long k = L.ki[idx];
             // (double)(u & 1 ? -rabs : rabs) * wi[idx]: rabs < 2^51 goes exactly into the significand of 2^52 + rabs; the sign is
             // applied to the product (round-to-nearest is symmetric).  rabs = 0 with the sign bit set would give -0.0 where the
             // reference has +0.0: the division step below returns +0.0 for it (fma(+0.0, r, -0.0) = +0.0).
             const double mag = __longlong_as_double((long long)(rabs | 0x4330000000000000ULL)) - 4503599627370496.0;
             const double prod = mag * w;
-            const double v = __longlong_as_double(__double_as_longlong(prod) ^ (long long)(raw << 63));
-            L.val[nrm_pad(64 * j) + nrm_pad(lane)] = v;            // = nrm_pad(64 j + lane)
+            v[j] = __longlong_as_double(__double_as_longlong(prod) ^ (long long)(raw << 63));
             const bool slow = !(rabs < k);
             const uint64_t m = ballot64(slow);
-            if (m) {                                        // uniform branch, 54 % of the slots
+            if (m) {                                        // uniform branch, 60 % of the slots
                 const int at = n_ev + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (slow && at < NRM_MAX_EV) L.ev[at] = 64 * j + lane;
+                if (slow && at < NRM_MAX_EV) L.ev[wv][at] = 64 * j + lane;
                 n_ev += __popcll(m);
             }
         }
         int pos_limit = NRM_CP;                             // positions below this one are resolved (events beyond the list are not)
         if (n_ev > NRM_MAX_EV) { n_ev = NRM_MAX_EV; }
         __builtin_amdgcn_wave_barrier();
-        if (n_ev == NRM_MAX_EV) pos_limit = L.ev[NRM_MAX_EV - 1] + 1;  // (essentially never: 7 events expected; later positions may hide unlisted events)
+        if (n_ev == NRM_MAX_EV) pos_limit = L.ev[wv][NRM_MAX_EV - 1] + 1;  // (essentially never: 9 events expected; later positions may hide unlisted events)
+#ifdef NRM_PROF
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long pt1 = __builtin_readcyclecounter();
+#endif
         // ---- 2. one divergent pass over the events: lane e < n_ev resolves event e
-        int e_pos = 0x7fffffff, e_kind = 0;                 // kind: 1 wedge accepted, 2 wedge rejected, 3 tail
-        if (lane < n_ev) {
-            e_pos = L.ev[lane];
+        //      kind 1: wedge accepted (the output takes the value at its position, one uniform consumed)
+        //      kind 2: wedge rejected (draw + uniform consumed, the output restarts behind them)
+        //      kind 3: tail (the output is +-(ZIG_NOR_R + xx), two draws per trial consumed)
+        const bool is_ev = lane < n_ev;
+        int e_pos = 0x3fffffff, e_kind = 0, e_delta = 0;    // e_delta: extra stream positions the event consumes
+        double e_tail = 0.0;
+        if (is_ev) {
+            e_pos = L.ev[wv][lane];
             const uint64_t z = base + (uint64_t)(e_pos + 1) * gamma;
             const uint64_t raw = mix64(z) & MASK52;
             const int64_t rabs = (int64_t)(raw >> 1);
             const int idx = (int)(rabs & 0xFF);
             if (idx == 0) {
-                e_kind = 3;
+                // tail of the normal ziggurat (Random/src/normal.jl randn_unlikely, idx == 0), exactly, at this stream position
+                SeqRng t{z, gamma};
+                int pairs = 0;
+                double xx, yy;
+                do {
+                    xx = ZIG_NOR_INV_R * zig_tail_neglog(t.rand());
+                    yy = zig_tail_neglog(t.rand());
+                    pairs += 1;
+                } while (!(yy + yy > xx * xx) && pairs < 4096);
+                e_kind = 3; e_delta = 2 * pairs;
+                e_tail = ((rabs >> 8) & 1) ? (-ZIG_NOR_R - xx) : (ZIG_NOR_R + xx);
             } else {
-                                const double x = (double)((raw & 1) ? -rabs : rabs) * ZIG_WI[idx];
+                const double x = (double)((raw & 1) ? -rabs : rabs) * L.wi[idx];
                 const double u1 = u52_to_unit(mix64(z + gamma));
-                                const double f1 = ZIG_FI[idx - 1], f0 = ZIG_FI[idx];
+#if NRM_FI_LDS
+                const double f1 = L.fi[idx - 1], f0 = L.fi[idx];
+#else
+                const double f1 = ZIG_FI[idx - 1], f0 = ZIG_FI[idx];
+#endif
                 e_kind = ((f1 - f0) * u1 + f0 < exp(-0.5 * x * x)) ? 1 : 2;
+                e_delta = e_kind;
             }
         }
-        // ---- 3 + 4. groups of 256 outputs; the scalar walk over the events runs alongside
-        int shift = 0, ev = 0, consumed_end = -1;           // uniform: positions <= consumed_end are extra draws of an earlier event
+#ifdef NRM_PROF
+        asm volatile("" :: "v"(e_kind), "v"(e_pos));
+        const unsigned long long pt2 = __builtin_readcyclecounter();
+#endif
+        // ---- 3. which events start an attempt (the events are sorted by position): an event does NOT iff the live event before it
+        // consumed its position -- a wedge consumes the position right behind it, a tail the 2 x trials behind it
+        const int e_cons = (e_kind == 3) ? e_delta : 1;
+        const int prev_end = __shfl_up(e_pos + e_cons, 1, 64);
+        const bool covered = is_ev && lane > 0 && e_pos <= prev_end;
+        bool live = is_ev;
+        if (ballot64(covered) != 0ull) {
+            // runs of adjacent events (13 % of the chunks have a pair): alternate along the run.  Three Jacobi steps settle runs of up
+            // to four; anything longer -- or a tail covering more than its neighbour -- is settled sequentially
+            for (int it = 0; it < 3; ++it) { const bool pl = __shfl_up((int)live, 1, 64) != 0; live = is_ev && !(covered && pl); }
+            const bool pl = __shfl_up((int)live, 1, 64) != 0;
+            const int prev2_end = __shfl_up(e_pos + e_cons, 2, 64);
+            const bool bad = (live != (is_ev && !(covered && pl))) || (is_ev && lane > 1 && e_pos <= prev2_end);
+            if (ballot64(bad) != 0ull) {
+                uint64_t lm = 0ull; int cend = -1;
+                for (int j = 0; j < n_ev; ++j) {
+                    const int p = __builtin_amdgcn_readlane(e_pos, j);
+                    if (p <= cend) continue;
+                    lm |= 1ull << j;
+                    cend = p + __builtin_amdgcn_readlane(e_cons, j);
+                }
+                live = __builtin_amdgcn_inverse_ballot_w64(lm);
+            }
+        }
+        {   // a live tail whose trials leave the chunk: nothing at or behind its position is emitted
+            const uint64_t cm = ballot64(live && e_kind == 3 && e_pos + e_delta >= NRM_CP);
+            if (cm != 0ull) pos_limit = min(pos_limit, __builtin_amdgcn_readlane(e_pos, (int)__builtin_ctzll(cm)));
+        }
+        const int e_d = live ? e_delta : 0;
+        const int e_incl = wave_iscan_i32(e_d);             // draws consumed by the events up to and including this one
+        const int e_kout = e_pos - (e_incl - e_d);          // the output the attempt belongs to
+        if (live) {
+            // consumed positions: accepted wedge p + 1; rejected wedge p, p + 1; tail p + 1 .. p + e_delta
+            const int first = e_pos + ((e_kind == 2) ? 0 : 1), last = min(e_pos + ((e_kind == 3) ? e_delta : 1), NRM_CP - 1);
+            for (int q = first; q <= last; ++q) atomicOr(&L.del[wv][q >> 6], 1ull << (q & 63));
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- 4. compaction: the positions that were not consumed, in order, are the outputs
+        {
+            int cum = 0;                                    // uniform: outputs before this slot
+#pragma unroll
+            for (int j = 0; j < NRM_SLOTS; ++j) {
+                const unsigned long long dj = L.del[wv][j];
+                const uint64_t keep = ~(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(dj >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)dj));
+                const int at = cum + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(keep >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)keep, 0u));
+                if (__builtin_amdgcn_inverse_ballot_w64(keep) && at < NRM_CO) L.out[wv][at] = v[j];
+                cum += __popcll(keep);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (live && e_kind == 3 && e_kout < NRM_CO) L.out[wv][e_kout] = e_tail;       // (its position holds the fast-path expression)
+        __builtin_amdgcn_wave_barrier();
+#ifdef NRM_PROF
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long walk_cyc = __builtin_readcyclecounter() - pt2;
+#endif
+        // ---- 5. groups of 256 outputs: divide, store, tree
         int emitted = 0, shift_emitted = 0;
         const int want = (int)min((int64_t)NRM_CO, d - done);
         for (int g0 = 0; g0 < want; g0 += 256) {
             const int gend = min(g0 + 256, want);
-            int k0 = g0 + 4 * lane;                         // this lane's outputs k0 .. k0 + 3 (relative to the chunk)
-            int s0 = shift, s1 = shift, s2 = shift, s3 = shift;
-            bool cut = false;
-            while (ev < n_ev) {
-                const int p = __builtin_amdgcn_readlane(e_pos, ev);
-                if (p <= consumed_end) { ev += 1; continue; }                   // not the start of an attempt
-                const int kout = p - shift;                 // the output this attempt belongs to
-                if (kout >= gend) break;
-                int kind = __builtin_amdgcn_readlane(e_kind, ev);
-                int delta, thr;
-                if (kind == 3) {
-                    // tail of the normal ziggurat (Random/src/normal.jl randn_unlikely, idx == 0): exact sequential code at this position
-                    SeqRng t{base + (uint64_t)(p + 1) * gamma, gamma};
-                    const uint64_t raw = mix64(t.seed) & MASK52;
-                    const int64_t rabs = (int64_t)(raw >> 1);
-                    int pairs = 0;
-                    double xx, yy;
-                    do {
-                        xx = ZIG_NOR_INV_R * zig_tail_neglog(t.rand());
-                        yy = zig_tail_neglog(t.rand());
-                        pairs += 1;
-                    } while (!(yy + yy > xx * xx) && pairs < 4096);
-                    const double tv = ((rabs >> 8) & 1) ? (-ZIG_NOR_R - xx) : (ZIG_NOR_R + xx);
-                    if (p + 2 * pairs >= NRM_CP) { cut = true; break; }          // (its draws leave the chunk: redo from here next chunk)
-                    if (lane == 0) L.val[nrm_pad(p)] = tv;
-                    __builtin_amdgcn_wave_barrier();
-                    delta = 2 * pairs; thr = kout + 1;
-                } else if (kind == 1) { delta = 1; thr = kout + 1; }
-                else { delta = 2; thr = kout; }
-                consumed_end = p + ((kind == 2) ? 1 : delta);
-                s0 += (k0 >= thr) ? delta : 0;
-                s1 += (k0 + 1 >= thr) ? delta : 0;
-                s2 += (k0 + 2 >= thr) ? delta : 0;
-                s3 += (k0 + 3 >= thr) ? delta : 0;
-                shift += delta;
-                ev += 1;
-            }
-            // every position this group reads must be resolved and inside the chunk
-            if (cut || gend - 1 + shift >= pos_limit) break;
-            const double a0 = L.val[nrm_pad(k0 + s0)], a1 = L.val[nrm_pad(k0 + 1 + s1)], a2 = L.val[nrm_pad(k0 + 2 + s2)], a3 = L.val[nrm_pad(k0 + 3 + s3)];
+            const int k0 = g0 + 4 * lane;                   // this lane's outputs k0 .. k0 + 3 (relative to the chunk)
+            // draws consumed by the attempts of the outputs below gend (uniform); every position the group takes must be resolved
+            const int shift = __builtin_amdgcn_readlane(wave_iscan_i32((is_ev && e_kout < gend) ? e_d : 0), 63);
+            if (gend - 1 + shift >= pos_limit) break;
+            const double2 a01 = *reinterpret_cast<const double2 *>(&L.out[wv][k0]), a23 = *reinterpret_cast<const double2 *>(&L.out[wv][k0 + 2]);
+            const double a0 = a01.x, a1 = a01.y, a2 = a23.x, a3 = a23.y;
             double q0, q1, q2, q3;
             if (markstein) {
                 q0 = a0 * rinv; q1 = a1 * rinv; q2 = a2 * rinv; q3 = a3 * rinv;
@@ -192,10 +287,10 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
             }
 #endif
             // fixed tree over 64-leaf blocks: two levels in the lane, four across the 16 lanes of a row (= one block)
-            double s = (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
-            s = dpp_row_step(s, 0); s = dpp_row_step(s, 1); s = dpp_row_step(s, 2); s = dpp_row_step(s, 3);
-            if ((lane & 15) == 0) L.bs[(int)((done + g0) >> 6) + (lane >> 4)] = s;
-            emitted = gend; shift_emitted = shift;          // (every event of an output below gend has been walked, none of a later one)
+            double sq = (q0 * q0 + q1 * q1) + (q2 * q2 + q3 * q3);
+            sq = dpp_row_step(sq, 0); sq = dpp_row_step(sq, 1); sq = dpp_row_step(sq, 2); sq = dpp_row_step(sq, 3);
+            if ((lane & 15) == 0) L.bs[wv][(int)((done + g0) >> 6) + (lane >> 4)] = sq;
+            emitted = gend; shift_emitted = shift;          // (the attempts of every output below gend, of none at or above it)
         }
         if (emitted == 0) {
             // Unreachable for the slack chosen unless a tail's draws leave the chunk right at its start or > 64 events crowd the first
@@ -206,17 +301,22 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
                 double v = wave_randn_block(r, lane, nl) / sd + 0.0;
                 if (lane < nl) xrow[done + b0 + lane] = v; else v = 0.0;
                 const double sq = wave_sum_dpp(v * v);
-                if (lane == 0) L.bs[(int)((done + b0) >> 6)] = sq;
+                if (lane == 0) L.bs[wv][(int)((done + b0) >> 6)] = sq;
             }
             done += gl;
             continue;
         }
         r.seed = base + (uint64_t)(emitted + shift_emitted) * gamma;     // stream position of the next output's first draw
+#ifdef NRM_PROF
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        { const unsigned long long pt3 = __builtin_readcyclecounter();
+          if (lane == 0) { L.prof[0] += pt1 - pt0; L.prof[1] += pt2 - pt1; L.prof[2] += walk_cyc; L.prof[3] += pt3 - pt2 - walk_cyc; L.prof[4] += 1; L.prof[5] += n_ev; } }
+#endif
         done += emitted;
     }
     __builtin_amdgcn_wave_barrier();
     const int B = (int)((d + 63) >> 6);
-    return (lane < B) ? L.bs[lane] : 0.0;
+    return (lane < B) ? L.bs[wv][lane] : 0.0;
 }
 
 }  // namespace pte
