@@ -194,7 +194,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 const int ex = (lane == 0) ? ex0 : 0;
                 const double Q = xold * xold - E * inv_nhp;
                 const double Bq = Sest + fabs(Q);
-                double dmin = INFINITY;
+                double dmin = fabs(E * inv_nhp);             // |x_old^2 - Q|: the old position is inside the slice by the margin too (see the acceptance check)
                 auto test = [&](double v) __attribute__((always_inline)) -> double {
                     const double d = v * v - Q;
                     dmin = fmin(dmin, fabs(d));
@@ -240,7 +240,6 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                     asm volatile("" : "+v"(dL), "+v"(dR), "+v"(kd));
                 }
                 const bool dbl_ok = !((kd < sp.p) && (fmin(dL, dR) < 0.0));     // ended by itself, not by a budget
-                const bool doubled = (RR - LL) > w11;
                 const double thr2 = 1e-6 * fmax(fabs(LL), fabs(RR));
 #ifdef PTE_PROFILE_SECTIONS
                 asm volatile("" :: "v"(LL), "v"(RR), "v"(kd), "v"(thr2));
@@ -341,56 +340,17 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 asm volatile("" :: "v"(xf), "v"(n), "v"(dmin));
 #endif
                 PROF_T(t2); PROF_ADD(1, t2 - t1);
-                // ---- acceptance check of the doubling scheme (:192-237) for the proposal found; a
-                //      proposal that fails it sends the hypothesis to the exact path
-                const bool chk = valid && doubled;
-                {
-                    // Only the doubled hypotheses work here (EXEC-masked region, <= 2 halvings for a budgeted hypothesis);
-                    // the flags leave the region as per-lane integers.
-                    double Lhat = LL, Rhat = RR, oL = dL, oR = dR;
-                    int Di = 0, oki = 1, unf = 0;
-                    if (chk) {
-                        auto halve = [&]() __attribute__((always_inline)) {
-                            const double Mid = (Lhat + Rhat) * 0.5;
-                            const bool right = xf < Mid;
-                            const double dm = test(Mid);
-                            Di |= ((xold < Mid) != right) ? 1 : 0;
-                            Rhat = right ? Mid : Rhat;
-                            Lhat = right ? Lhat : Mid;
-                            oR = right ? dm : oR;
-                            oL = right ? oL : dm;
-                            oki = (Di && !(oL < 0.0) && !(oR < 0.0)) ? 0 : 1;
-                        };
-                        halve();
-                        if (oki && (Rhat - Lhat > w11)) {
-                            halve();
-                            unf = (oki && (Rhat - Lhat > w11)) ? 1 : 0;
-                        }
-                    }
-                    asm volatile("" : "+v"(Di), "+v"(oki), "+v"(unf));
-                    bool D = Di != 0, ok = oki != 0;
-                    bool unfinished = unf != 0;
-                    if (__builtin_expect(ballot64(lane == 0 && unfinished) != 0ull, 0)) {
-                        bool go = (lane == 0);
-                        while (go) {
-                            const double Mid = (Lhat + Rhat) * 0.5;
-                            const bool right = xf < Mid;
-                            D = D || ((xold < Mid) != right);
-                            const double dm = test(Mid);
-                            Rhat = right ? Mid : Rhat;
-                            Lhat = right ? Lhat : Mid;
-                            oR = right ? dm : oR;
-                            oL = right ? oL : dm;
-                            ok = !(D && !(oL < 0.0) && !(oR < 0.0));
-                            go = ok && (Rhat - Lhat > w11);
-                        }
-                        int oki2 = ok ? 1 : 0;
-                        asm volatile("" : "+v"(oki2));
-                        ok = oki2 != 0;
-                        unfinished = unfinished && lane != 0;
-                    }
-                    valid = valid && (!chk || (ok && !unfinished));
-                }
+                // ---- acceptance check of the doubling scheme (:192-237): provably a no-op on this path, so it is not executed.
+                //      slice_accept rejects iff at some halving the old and the new position lie on different sides of the midpoint
+                //      (D) and BOTH ends of the halved interval are outside the slice.  Once D holds, the end on the old position's
+                //      side is a midpoint strictly between the new and the old position.  Here the slice { v : z < lp(v) } is
+                //      { v : v^2 < Q' } for the reference's own floating-point predicate too (the fixed-tree sum is monotone in
+                //      |v|: every rounding step is), an interval -- and both positions are inside it with the filter's margin to
+                //      spare (the new one by its own test, the old one because |x_old^2 - Q| = E / |nhp| was folded into dmin
+                //      above), so that end is inside and the test cannot fire.  Measured before the removal: 0 rejections in every
+                //      profile (profiles/r03_slice8_sections_by_chain.txt), while the region cost the hot chains (precision near 1,
+                //      where most intervals are doubled) ~8 % of their time -- they were the launch's slowest waves
+                //      (profiles/r03_slice8_per_wave.txt).  The exact sequential procedure below still runs the reference's test.
 #ifdef PTE_PROFILE_SECTIONS
                 {   // why the true path ends where it ends (slots 8..15: all 5 levels done, then the causes)
                     const bool mg = dmin > 2e-12 * Bq;
