@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (weak) / in total (strong)")
     ap.add_argument("--explorer", default="slice", choices=["slice", "toy"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed hbm_kernels / extra_configs blocks")
     ap.add_argument("--same-device", action="store_true",
                     help="TEST ONLY: every rank uses HIP device 0 (the control plane then runs over gloo, and the data path needs an "
                          "RCCL stand-in that accepts two ranks on one device: $PTE_RCCL_LIB=tests/fakerccl/libfakerccl.so); "
@@ -164,6 +165,56 @@ def cpu_baseline(d, target_seconds=12.0):
     }
 
 
+def hbm_kernels(P):
+    """The kernels the HBM roofline applies to, untimed for the headline: ToyExplorer at N = 8192, d = 4096 (256 MiB of
+    state).  Durations are HIP events on the engine's stream in THIS run (pte_timing_*; k_init is timed once, at pte_create);
+    bytes are algorithmic: k_explore_toy / k_init write 8 d + 32 B per replica, k_swap moves 96 B per replica."""
+    N, d = 8192, 4096
+    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=8, record=[P.round_trip, P.log_sum_ratio], show_report=False))
+    e = pt.replicas
+    init_ms, _ = e.timing(2)
+    e.run_scans(1, 4)
+    e.timing_reset(True)
+    e.run_scans(1, 16)
+    out = {"workload": "toy_mvn_target(%d), n_chains=%d, ToyExplorer (i.i.d. refresh of every chain)" % (d, N),
+           "source": "HIP events in this run", "hbm_achievable_GBps": HBM_ACHIEVABLE_GBS, "hbm_peak_GBps": HBM_PEAK_GBS}
+    for name, ms, nbytes in (("k_explore_toy", e.timing(0)[0] / max(e.timing(0)[1], 1), (8 * d + 32) * N),
+                             ("k_init", init_ms, (8 * d + 32) * N),
+                             ("k_swap", e.timing(1)[0] / max(e.timing(1)[1], 1), 96 * N)):
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out[name] = {"bytes_per_launch": nbytes, "avg_launch_us": ms * 1e3, "GBps": gbs,
+                     "frac_of_6.29TBps": gbs / HBM_ACHIEVABLE_GBS, "frac_of_8TBps": gbs / HBM_PEAK_GBS}
+    e.timing_reset(False)
+    return out
+
+
+def extra_configs(P):
+    """ms / scan (explore + swap, wall clock around pte_run_scans, states resident) of the other BASELINE configs at their per-GPU
+    shapes, and the 1-GPU anchor of the strong-scaling clause -- untimed for the headline, so that every config has a driver-visible
+    number.  A handful of scans each."""
+    import torch
+    rec = [P.round_trip, P.log_sum_ratio]
+    cfgs = [
+        ("C2 toy_mvn_target(1024), n_chains=256, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(1024), n_chains=256, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 4, 16),
+        ("C3 funnel d=128, n_chains=1024, AutoMALA", lambda: P.Inputs(target=P.Funnel(128), reference=P.ScaledPrecisionNormalLogPotential(1 / 9., 128), n_chains=1024, explorer=P.AutoMALA(), record=rec, n_rounds=8, show_report=False), 4, 32),
+        ("C4 shard: toy_mvn_target(4096), 1024 of 8192 chains, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(4096), n_chains=1024, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 2, 8),
+        ("C4 on ONE GPU (strong-scaling anchor): toy_mvn_target(4096), n_chains=8192, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(4096), n_chains=8192, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 1, 4),
+        ("C5 shard: Ising 256x256, 512 of 4096 chains, IsingMetropolis(3 sweeps)", lambda: P.Inputs(target=P.IsingLogPotential(1.0, 256), n_chains=512, record=rec, n_rounds=8, show_report=False), 1, 4),
+    ]
+    out = []
+    for name, mk, warm, scans in cfgs:
+        inp = mk()
+        pt = P.PT(inp)
+        e = pt.replicas
+        e.run_scans(1, warm)
+        torch.cuda.synchronize()
+        t = time.perf_counter(); e.run_scans(1, scans); torch.cuda.synchronize(); dt = time.perf_counter() - t
+        out.append({"config": name, "kernel": e.kernel_name(), "ms_per_scan": dt / scans * 1e3, "replica_steps_per_s": inp.n_chains * scans / dt,
+                    "chains_per_gpu": inp.n_chains, "waves_per_simd": inp.n_chains / 1024.0})
+        del pt, e
+    return out
+
+
 def main():
     args = parse_args()
     world_env = os.environ.get("WORLD_SIZE")
@@ -269,6 +320,17 @@ def main():
     ex_ms, ex_n = eng.timing(0)
     samples = np.sort(eng.timing_samples(0))
     eng.timing_reset(False)
+    # the same K scans once more WITHOUT HIP events in the stream (an event pair costs stream time per launch): the cross-check of
+    # what the instrumentation costs the timed region above; `value` stays the instrumented, contract-timed pass
+    sync()
+    t0 = time.perf_counter()
+    runner.run_scans(1, K)
+    sync()
+    dt_noev = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt_noev], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_noev = float(t.item())
     red = reduce_recorders(pt)
     ss_sum, ss_n = red.explorer_n_steps
     boundary = [int(getattr(runner, "n_boundary_swaps", 0))]
@@ -307,12 +369,21 @@ def main():
     ex_avg_ms = ex_ms / max(ex_n, 1)
     kernel_name = eng.kernel_name()                # reported by the library (pte_kernel_name), not guessed
     traffic = None
+    traffic_source = None
     issue = None
-    try:   # HBM bytes per launch from the committed rocprofv3 PMC passes of this kernel at this workload
+    try:   # HBM bytes per launch and the SQ instruction counters: STATIC, from the committed rocprofv3 PMC passes of this kernel at
+           # this workload (PMC passes cannot run inside an unprofiled bench; the line names the file they come from)
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(kernel_name)
         if tj and d == 1024 and n_chains == 1024:
             traffic = tj["fetch_bytes"] + tj["write_bytes"]
+            traffic_source = "static: " + tj.get("source", "profiles/traffic.json")
             issue = tj.get("issue")                   # what actually bounds the kernel: instruction issue of one wave per replica
+            if issue:
+                # issue roofline of ONE wave per SIMD: every instruction of a lone wave costs >= 4.44 cycles (tools/ubench/issue_floor.hip,
+                # profiles/r03_issue_floor.txt); frac = instructions x floor / wave cycles = the share of the wave's life that is issue
+                floor = 4.44
+                issue = dict(issue, source="static: " + tj.get("source", "profiles/traffic.json"), floor_cycles_per_instruction=floor,
+                             frac_of_issue_floor=issue["instructions_per_wave"] * floor / issue["wave_cycles"])
     except Exception:
         traffic = None
     achieved = alg_bytes / (ex_avg_ms * 1e-3) / 1e9 if ex_avg_ms > 0 else 0.0
@@ -321,12 +392,13 @@ def main():
     out = {
         "metric": "replica-steps/sec (explore+swap), toy_mvn d=%d, n_chains=%d; round-trip rate" % (d, total_chains),
         "value": value, "unit": "replica-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "ms_per_step": dt / K * 1e3, "ms_per_step_without_hip_events": dt_noev / K * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "toy_mvn_target(%d), n_chains=%d per GPU x %d GPU, %s, seed=1, DEO swaps every scan"
                                % (d, n_chains, world, "SliceSampler(w=10,p=20,n_passes=3)" if args.explorer == "slice" else "ToyExplorer"),
                    "sharding": ("chains sharded over %d GPUs, boundary replicas only; transport: %s" % (world, transport)) if world > 1 else "single GPU",
                    "n_ranks_seen": ranks_seen, "boundary_swaps_per_rank": boundary, "ms_per_step_per_rank": per_rank_ms,
+                   "chains_per_gpu": n_chains, "waves_per_simd": n_chains / 1024.0,      # one wave per replica, 1024 SIMDs per GPU
                    **({"same_device_test_run": "every rank on HIP device 0 with an RCCL stand-in ($PTE_RCCL_LIB=%s): exercises the "
                        "multi-rank code path, NOT a measurement" % os.environ.get("PTE_RCCL_LIB", "")} if args.same_device else {})},
         "round_trip_rate": rt["round_trip_rate"] if rt else None, "n_round_trips": rt["n_round_trips"] if rt else None,
@@ -334,7 +406,7 @@ def main():
         "lp_evals_per_replica_step": lp_evals,
         "roofline": {"bound": "hbm", "kernel": kernel_name,
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "avg_launch_ms": ex_avg_ms, "launches": ex_n,
+                     "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": ex_avg_ms, "launches": ex_n,
                      "launch_ms_min_median_max": [float(samples[0]), float(samples[len(samples) // 2]), float(samples[-1])] if len(samples) else None,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "swap_kernel_avg_launch_ms": sw_ms / max(sw_n, 1),
@@ -347,6 +419,10 @@ def main():
                      "note": "SliceSampler is bound by the instruction issue of ONE wave per replica walking a sequential "
                              "decision chain (3*d coordinate updates, ~6.5 draws each), not by HBM; see DESIGN.md sec. 5"},
     }
+    if rank == 0 and world == 1 and not args.no_extra:
+        del pt, runner, eng                              # (frees the metric engine's HBM before the 256 MiB one)
+        out["hbm_kernels"] = hbm_kernels(P)
+        out["extra_configs"] = extra_configs(P)
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.explorer == "slice":
             out["cpu_baseline"] = cpu_baseline(d)

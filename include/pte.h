@@ -257,7 +257,8 @@ int pte_get_index_process_shard(const pte_engine *h, int64_t *replica, int64_t *
 int pte_get_replica_ids(const pte_engine *h, int64_t *out /*K*/);
 
 /* Measurement hooks (bench.py): per-kernel HIP-event timing accumulated on the engine's stream
- * over pte_run_scans calls since the last reset.  kernel: 0 = explore, 1 = swap.
+ * over pte_run_scans calls since the last reset.  kernel: 0 = explore, 1 = swap; 2 = k_init (create_replicas), timed once
+ * at pte_create and not touched by pte_timing_reset.
  * enable: 0 off, 1 every kernel, 2 the explore kernels only (an event pair costs ~10 us of stream time per launch). */
 int pte_timing_reset(pte_engine *h, int enable);
 int pte_timing_get(const pte_engine *h, int kernel, double *total_ms, int64_t *launches);

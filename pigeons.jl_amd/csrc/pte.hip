@@ -89,6 +89,7 @@ struct pte_engine {
     struct Ev { hipEvent_t a, b; int kernel; };
     std::vector<Ev> events;
     std::vector<hipEvent_t> ev_pool;
+    double init_ms = -1.0;            // duration of k_init (create_replicas), -1: not launched (Ising, TestSwapper)
     double t_ms[2] = {0, 0};
     int64_t t_n[2] = {0, 0};
     std::vector<float> t_samples[2];  // per-launch durations since the last reset (spread of the timed region)
@@ -564,7 +565,13 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     if (upload_ladder(h)) return bail(1);
     if (reset_recorders(h)) return bail(1);
     const double init_sd = swapper ? 1.0 : std::sqrt(cfg->target_params[1]);   // toy_mvn_target.jl:10-11
-    if (!ising) { DISPATCH_NLU(h->nlu, k_init, dim3((unsigned)((K + NRM_WPB - 1) / NRM_WPB)), dim3(64 * NRM_WPB), h->stream, e, (uint64_t)cfg->seed, init_sd); }
+    hipEvent_t init_a = nullptr, init_b = nullptr;       // k_init's duration: pte_timing_get(kernel = 2), one event pair per engine
+    if (!ising) {
+        hipEventCreate(&init_a); hipEventCreate(&init_b);
+        hipEventRecord(init_a, h->stream);
+        DISPATCH_NLU(h->nlu, k_init, dim3((unsigned)((K + NRM_WPB - 1) / NRM_WPB)), dim3(64 * NRM_WPB), h->stream, e, (uint64_t)cfg->seed, init_sd);
+        hipEventRecord(init_b, h->stream);
+    }
     else {
         std::vector<int32_t> ch((size_t)K), sl((size_t)K); std::vector<int64_t> rid((size_t)K);
         for (int64_t il = 0; il < K; ++il) { ch[il] = (int32_t)(h->c0 + il); sl[il] = (int32_t)il; rid[il] = h->c0 + il; }
@@ -575,6 +582,11 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     }
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) {
         h->err = "k_init launch failed"; return bail(1);
+    }
+    if (init_a) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, init_a, init_b) == hipSuccess) h->init_ms = ms;
+        hipEventDestroy(init_a); hipEventDestroy(init_b);
     }
     if (funnel || ising) {
         // funnel: initialization(::LogDensity, rng, i) = zeros(dim); Ising: falses(L, L) (examples/ising.jl:85) (test/supporting/dimensional-analysis.jl:24): the streams
@@ -1382,7 +1394,12 @@ int pte_timing_get_samples(const pte_engine *hc, int kernel, double *out_ms, int
 }
 int pte_timing_get(const pte_engine *hc, int kernel, double *total_ms, int64_t *launches) {
     pte_engine *h = const_cast<pte_engine *>(hc);
-    if (!h || kernel < 0 || kernel > 1) return 1;
+    if (!h || kernel < 0 || kernel > 2) return 1;
+    if (kernel == 2) {                                  // k_init: timed once, at pte_create
+        if (total_ms) *total_ms = h->init_ms < 0 ? 0.0 : h->init_ms;
+        if (launches) *launches = h->init_ms < 0 ? 0 : 1;
+        return 0;
+    }
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
     time_collect(h);

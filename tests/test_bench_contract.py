@@ -51,3 +51,15 @@ def test_single_gpu_line_has_the_contract_fields():
     assert c["kind"] == "port" and c["unit"] == "replica-steps/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     rt = j["round_trip"]
     assert rt["rounds"] == 4 and rt["scans_in_last_round"] == 16 and rt["global_barrier"] > 0
+    # round 3: what is static says so, the instrumentation is cross-checked, the HBM-bound kernels and every BASELINE config are in the line
+    assert j["ms_per_step_without_hip_events"] > 0 and j["ms_per_step_without_hip_events"] <= j["ms_per_step"] * 1.10
+    assert r["traffic"] is None or str(r["traffic_source"]).startswith("static: profiles/")
+    assert r["instruction_issue"] is None or str(r["instruction_issue"]["source"]).startswith("static: profiles/")
+    h = j["hbm_kernels"]
+    for k in ("k_explore_toy", "k_init", "k_swap"):
+        assert h[k]["avg_launch_us"] > 0 and h[k]["bytes_per_launch"] > 0 and abs(h[k]["frac_of_8TBps"] - h[k]["GBps"] / 8000.0) < 1e-12
+    assert h["k_explore_toy"]["bytes_per_launch"] == (8 * 4096 + 32) * 8192
+    x = j["extra_configs"]
+    assert len(x) == 5 and all(c["ms_per_scan"] > 0 and c["kernel"] for c in x)
+    assert {c["kernel"] for c in x} >= {"k_explore_slice8", "k_explore_slice8_lds10k", "k_explore_automala", "k_explore_ising_spec"}
+    assert j["config"]["chains_per_gpu"] == 1024 and j["config"]["waves_per_simd"] == 1.0
