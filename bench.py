@@ -387,7 +387,7 @@ def main():
     except Exception:
         traffic = None
     achieved = alg_bytes / (ex_avg_ms * 1e-3) / 1e9 if ex_avg_ms > 0 else 0.0
-    lp_evals = float(np.sum(ss_sum) / max(K * (total_chains - 1), 1)) + 2.0 * 3 * d if args.explorer == "slice" else 0.0
+    lp_evals = float(np.sum(ss_sum) / max(2 * K * (total_chains - 1), 1)) + 2.0 * 3 * d if args.explorer == "slice" else 0.0   # (the recorders cover both K-scan passes)
     composite_bytes = (24 * d + 128) * value            # B/s over the whole job
     out = {
         "metric": "replica-steps/sec (explore+swap), toy_mvn d=%d, n_chains=%d; round-trip rate" % (d, total_chains),

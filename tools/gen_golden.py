@@ -103,8 +103,32 @@ def oracle_runs():
     return out
 
 
+def cabi_c1():
+    """BASELINE configs[0] (toy_mvn_target(2), n_chains=10, n_rounds=5, SliceSampler, seed 1) round by round, in a line format
+    a plain C program reads with fscanf (tests/test_cabi.c): the schedule IN FORCE during each round (so that the C side needs no
+    adaptation code), that round's swap acceptance and index process, and the final replicas."""
+    N, d, R = 10, 2, 5
+    pt = O.OraclePT(n_chains=N, dim=d, seed=1, explorer=O.EXPLORER_SLICE)
+    hx = lambda a: " ".join(float.hex(float(v)) for v in np.ravel(a))
+    it = lambda a: " ".join(str(int(v)) for v in np.ravel(a))
+    lines = ["config %d %d 1 %d" % (N, d, R)]
+    for r in range(1, R + 1):
+        lines.append("round %d" % r)
+        lines.append("schedule " + hx(pt.schedule()))
+        pt.run_round()
+        m, n = pt.swap_pr()
+        lines.append("swap_mean " + hx(m))
+        lines.append("swap_n " + it(n))
+        lines.append("index_process " + it(pt.index_process()))          # [replica][scan]
+    x, chain, rng = pt.states()
+    lines += ["final_chain " + it(chain), "final_rng " + it(rng), "final_state " + hx(x), "end"]
+    return "\n".join(lines) + "\n"
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    with open(os.path.join(GOLD, "cabi_c1.txt"), "w") as f:
+        f.write(cabi_c1())
     with open(os.path.join(GOLD, "kat_reference.json"), "w") as f:
         json.dump(kat_reference(), f, indent=1)
     with open(os.path.join(GOLD, "oracle_runs.json"), "w") as f:
