@@ -47,7 +47,7 @@ constexpr int S8_BD = PTE_S8_BD;                 // doubling budget of a specula
 // 12 replicas per CU; forcing 128 VGPRs (amdgpu_num_vgpr: 4 waves per SIMD, 36 B of scratch per lane) was measured at
 // 3072 / 4096 / 8192 replicas and changes nothing (1.875 / 2.318 / 4.250 against 1.877 / 2.316 / 4.252 ms): three waves
 // already saturate a SIMD's issue slots.
-template <int NLU, int S8_BS, int WINDOW>
+template <int NLU, int S8_BS, int WINDOW, bool DBL_EXEC>
 __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
     using namespace s7;
     constexpr int WIN = WINDOW, REFILL_AT = WINDOW - PTE_S7_MARGIN;
@@ -205,6 +205,54 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 double dL = test(LL), dR = test(RR);
                 // ---- doubling (:115-139): S8_BD predicated steps for every lane ...
                 int kd = 0;
+#if PTE_S8_BD >= 1 && PTE_S8_BD <= 4 && !defined(PTE_S8_DOUBLING_SELECTS)
+                if (DBL_EXEC && sp.p >= S8_BD) {         // (uniform; compile-time per kernel)
+                    // Hand-written: a step runs under EXEC = "this hypothesis still needs doubling", the left / right extension under
+                    // EXEC = need & left / need & ~left -- 13 VALU instructions per step where the select form below needs 28 (sixteen of
+                    // them v_cndmask halves).  Same operations in the same order per lane: L - (R - L) or R + (R - L)
+                    // (SliceSampler.jl:123-131), d = v * v - Q, |d| folded into dmin.  Which form is faster depends on what else the SIMD
+                    // has to do: each step of this form crosses twice from the vector to the scalar side (v_cmp -> s_and_saveexec), ~40
+                    // cycles each for a wave ALONE on its SIMD, nothing when other waves fill the gap -- measured at N = 1024 / 2048 /
+                    // 4096 / 8192 replicas per GPU: 0.868 / 1.141 / 1.853 / 3.395 ms per scan in this form against 0.851 / 1.167 / 1.950 /
+                    // 3.566 in the select form.  Choosing at RUN time inside one kernel costs more than either (0.897 at N = 1024: both bodies in the
+                    // loop), so the choice is per kernel: selects in k_explore_slice8 (up to 2816 replicas), EXEC masks in the many-replica twin.
+                    double t_, wd_;
+                    uint64_t sv_, sv2_;
+#define PTE_S8_DSTEP(V) \
+                    "v_min_f64 %[t], %[dL], %[dR]\n" \
+                    "v_cmp_gt_f64 vcc, 0, %[t]\n" \
+                    "s_and_saveexec_b64 %[sv], vcc\n" \
+                    "v_add_u32 %[kd], 1, %[kd]\n" \
+                    "v_add_f64 %[wd], %[RR], -%[LL]\n" \
+                    "v_cmp_ge_f64 vcc, 0.5, " V "\n" \
+                    "s_and_saveexec_b64 %[sv2], vcc\n" \
+                    "v_add_f64 %[LL], %[LL], -%[wd]\n" \
+                    "v_mul_f64 %[t], %[LL], %[LL]\n" \
+                    "v_add_f64 %[dL], %[t], -%[Q]\n" \
+                    "v_min_f64 %[dmin], %[dmin], |%[dL]|\n" \
+                    "s_andn2_b64 exec, %[sv2], exec\n" \
+                    "v_add_f64 %[RR], %[RR], %[wd]\n" \
+                    "v_mul_f64 %[t], %[RR], %[RR]\n" \
+                    "v_add_f64 %[dR], %[t], -%[Q]\n" \
+                    "v_min_f64 %[dmin], %[dmin], |%[dR]|\n" \
+                    "s_mov_b64 exec, %[sv]\n"
+                    asm volatile(PTE_S8_DSTEP("%[V0]")
+#if PTE_S8_BD >= 2
+                                 PTE_S8_DSTEP("%[V1]")
+#endif
+#if PTE_S8_BD >= 3
+                                 PTE_S8_DSTEP("%[V2]")
+#endif
+#if PTE_S8_BD >= 4
+                                 PTE_S8_DSTEP("%[V3]")
+#endif
+                                 : [LL] "+v"(LL), [RR] "+v"(RR), [dL] "+v"(dL), [dR] "+v"(dR), [dmin] "+v"(dmin), [kd] "+v"(kd),
+                                   [t] "=&v"(t_), [wd] "=&v"(wd_), [sv] "=&s"(sv_), [sv2] "=&s"(sv2_)
+                                 : [Q] "v"(Q), [V0] "v"(Vd[0]), [V1] "v"(Vd[S8_BD > 1 ? 1 : 0]), [V2] "v"(Vd[S8_BD > 2 ? 2 : 0]), [V3] "v"(Vd[S8_BD > 3 ? 3 : 0])
+                                 : "vcc");
+#undef PTE_S8_DSTEP
+                } else
+#endif
 #pragma unroll
                 for (int it = 0; it < S8_BD; ++it) {
                     const bool need = (fmin(dL, dR) < 0.0) && it < sp.p;
@@ -377,6 +425,40 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 const int kn = cnt + succ_off;
                 const bool inw = (unsigned)kn < (unsigned)succ_wd;
                 const uint64_t vmask = ballot64(valid);
+#ifdef PTE_S8_CHAINED_CHASE      // measured and dropped: 33 cycles per hop in isolation against 52 (tools/ubench/hop.hip), 2 % SLOWER in the kernel (0.913 against 0.897 ms at matched builds)
+                // word of a valid hypothesis: bits 0-5 its successor lane (0: none), bits 8-15 its draw count, bit 24 "one more
+                // coordinate done"; an invalid hypothesis has word 0.  The successor sits in the LOW bits because v_readlane takes its
+                // lane from bits 5:0 of the scalar operand: the word read at one level is the lane select of the next read as it
+                // stands, so the five reads are chained through ONE register each -- no scalar arithmetic between them (a wave alone
+                // on its SIMD pays ~50 cycles for every vector -> scalar ALU -> vector dependence, tools/ubench/lds_lat.hip: the chase
+                // used to cost ~340 cycles per round, 16 % of it).  The sums are taken afterwards, off the dependence chain.
+                const int word = valid ? (int)(0x1000000u | ((unsigned)cnt << 8) | (inw ? (unsigned)(kn + succ_base) : 0u)) : 0;
+                const int packed = (lane != 0) ? word : 0;      // a broken path falls back to lane 0, which contributes nothing
+#ifdef PTE_PROFILE_SECTIONS
+                asm volatile("" :: "v"(packed));
+#endif
+                PROF_T(t3); PROF_ADD(2, t3 - t2); PROF_ADD(3, 1);
+                int gdone;
+                {
+                    int wv[G];
+                    wv[0] = __builtin_amdgcn_readlane(word, 0);
+#pragma unroll
+                    for (int g = 1; g < G; ++g) wv[g] = __builtin_amdgcn_readlane(packed, wv[g - 1]);
+                    uint64_t tmask = 1ull;
+                    unsigned acc = (unsigned)wv[G - 1] >> 8;
+#pragma unroll
+                    for (int g = 0; g < G - 1; ++g) {
+                        tmask |= 1ull << (wv[g] & 63);
+                        acc += (unsigned)wv[g] >> 8;
+                    }
+                    tmask &= vmask;                           // (a path ends AT an invalid lane: its bit was set above)
+                    if (__builtin_amdgcn_inverse_ballot_w64(tmask)) s_x[(l + hg) & (BLK - 1)] = xf;
+                    __builtin_amdgcn_wave_barrier();
+                    p += (int)(acc & 0xFFFFu);
+                    gdone = (int)(acc >> 16);
+                    l += gdone;
+                }
+#else
                 // packed word of a valid hypothesis of level >= 1: bits 0-7 its draw count, bits 8-13 its successor lane (0: none),
                 // bit 16 "one more coordinate done" -- so that ONE masked add per level accumulates both the draws consumed (low
                 // half) and the coordinates retired (high half) of the true path
@@ -406,6 +488,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                     gdone += acc >> 16;
                     l += gdone;
                 }
+#endif
 #ifdef PTE_PROFILE_SECTIONS
                 asm volatile("" :: "s"(p), "s"(l));
 #endif
@@ -536,7 +619,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
 
 template <int NLU, int S8_BS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES, PTE_S8_WAVES))) void k_explore_slice8(EngineDev e, SliceParams sp) {
-    slice8_body<NLU, S8_BS, PTE_S7_WIN>(e, sp);
+    slice8_body<NLU, S8_BS, PTE_S7_WIN, false>(e, sp);
 }
 #ifndef PTE_S8_TWIN_WAVES
 #define PTE_S8_TWIN_WAVES PTE_S8_WAVES
@@ -546,7 +629,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES
 #endif
 template <int NLU, int S8_BS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_TWIN_WAVES, PTE_S8_TWIN_WAVES))) void k_explore_slice8_lds10k(EngineDev e, SliceParams sp) {
-    slice8_body<NLU, S8_BS, 256>(e, sp);
+    slice8_body<NLU, S8_BS, 256, true>(e, sp);
 }
 
 }  // namespace pte
