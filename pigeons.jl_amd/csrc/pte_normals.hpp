@@ -125,7 +125,11 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < NRM_SLOTS; ++j) {
+#ifdef NRM_MEASURE_NO_MIX          // measurement builds only (wrong samples): what the SplitMix64 finaliser costs
+            const uint64_t raw = (zc ^ (zc >> 29)) & MASK52;
+#else
             const uint64_t raw = mix64(zc) & MASK52;
+#endif
             zc += g64;
             const uint64_t rabs = raw >> 1;
             const int idx = (int)(rabs & 0xFF);
@@ -160,7 +164,12 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
         const bool is_ev = lane < n_ev;
         int e_pos = 0x3fffffff, e_kind = 0, e_delta = 0;    // e_delta: extra stream positions the event consumes
         double e_tail = 0.0;
+#ifdef NRM_MEASURE_NO_EVENTS       // measurement builds only (wrong samples): every event taken as an accepted wedge, no exp
+        if (is_ev) { e_pos = L.ev[wv][lane]; e_kind = 1; e_delta = 1; }
+        if (false) {
+#else
         if (is_ev) {
+#endif
             e_pos = L.ev[wv][lane];
             const uint64_t z = base + (uint64_t)(e_pos + 1) * gamma;
             const uint64_t raw = mix64(z) & MASK52;
@@ -186,7 +195,18 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
 #else
                 const double f1 = ZIG_FI[idx - 1], f0 = ZIG_FI[idx];
 #endif
-                e_kind = ((f1 - f0) * u1 + f0 < exp(-0.5 * x * x)) ? 1 : 2;
+                // wedge test  y < exp(-x^2 / 2)  (Random/src/normal.jl randn_unlikely).  The double-precision exp is a chain of ~60
+                // dependent FP64 instructions that a handful of lanes execute while the rest of the wave waits -- a fifth of the whole
+                // kernel's time when it ran for every chunk.  Decide with the hardware's single-precision exp2 instead and keep the
+                // exact evaluation for the band the approximation cannot decide: relative error of (float)t -> t * log2(e) -> v_exp_f32
+                // < 1e-6 for t in [-6.7, 0] (three roundings of <= 6e-8 relative on an exponent below 9.7, one ulp of the exp itself);
+                // the band is 8e-6 wide on either side, so the decision is the exact one outside it and the exact code runs inside
+                // it (probability 1.6e-5 per event).
+                const double t = -0.5 * x * x;
+                const double y = (f1 - f0) * u1 + f0;
+                const double ea = (double)__builtin_amdgcn_exp2f((float)t * 1.44269504088896341f);
+                e_kind = (y < ea * (1.0 - 8e-6)) ? 1 : ((y > ea * (1.0 + 8e-6)) ? 2 : 0);
+                if (e_kind == 0) e_kind = (y < exp(t)) ? 1 : 2;
                 e_delta = e_kind;
             }
         }
@@ -232,6 +252,10 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
         }
         __builtin_amdgcn_wave_barrier();
         // ---- 4. compaction: the positions that were not consumed, in order, are the outputs
+        // (A vector-only form -- the bitmap word as a broadcast, v_bcnt against the lane's own lanes-below mask, consumed positions
+        // stored into dump slots, no readfirstlane and no EXEC mask -- makes a lone wave 16 % faster per chunk and the kernel at
+        // full occupancy 17 % SLOWER (0.127 against 0.108 ms at N = 8192): with four waves per SIMD the trips to the scalar side
+        // overlap, the extra vector instructions do not.  Measured in round 3 and dropped.)
         {
             int cum = 0;                                    // uniform: outputs before this slot
 #pragma unroll
