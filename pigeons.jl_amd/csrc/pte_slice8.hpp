@@ -12,7 +12,8 @@
 // lane 0 is coordinate l at the known position; 14 / 16 / 17 / 16 lanes cover the positions at
 // which coordinates l+1 .. l+4 can start (their windows cover ~3 sigma of the consumed-draw
 // distribution).  Every lane runs the complete scalar procedure of the reference
-// (SliceSampler.jl:97-237: doubling, shrinkage, acceptance check of the doubling scheme) on its own
+// (SliceSampler.jl:97-237: doubling, shrinkage; the acceptance check of the doubling scheme cannot reject on this path and is
+// not executed since round 3 -- the proof is at its place in the round) on its own
 // hypothesis, reading pre-converted draws from a 512-draw LDS window of the stream.  Every lane also
 // names the lane that follows it on the true path (its draw count fixes where the next coordinate
 // starts), so the chase is one v_readlane per level, without branches; the true lanes then store

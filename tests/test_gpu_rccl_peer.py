@@ -151,3 +151,19 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     assert len(c["boundary_swaps_per_rank"]) == 2 and sum(c["boundary_swaps_per_rank"]) > 0, c
     assert len(c["ms_per_step_per_rank"]) == 2 and "same_device_test_run" in c
     assert line["value"] > 0 and line["roofline"]["kernel"] == "k_explore_slice8"
+
+
+def test_bench_strong_scaling_two_ranks_on_one_device():
+    """bench.py --scaling strong (BASELINE configs[3]'s partitioning: a fixed ladder cut over the ranks) through the same 2-rank path,
+    at a size that keeps the test short: 8192 chains of dimension 128 -> 4096 per rank = the many-replica kernel on every rank."""
+    fake = build_fakerccl()
+    env = dict(os.environ, PTE_RCCL_LIB=fake)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--scaling", "strong", "--chains", "8192",
+                        "--dim", "128", "--steps", "4", "--warmup", "2", "--round-trip-rounds", "0", "--no-cpu-baseline", "--timeout-s", "400"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    c = line["config"]
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2 and c["n_ranks_seen"] == 2 and c["chains_per_gpu"] == 4096
+    assert line["roofline"]["kernel"] == "k_explore_slice8_lds10k" and "FALLBACK" not in c["sharding"]
+    assert abs(line["value"] - 8192 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]

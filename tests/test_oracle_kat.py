@@ -267,3 +267,18 @@ def test_gaussian_reference_on_the_funnel():
     assert abs(v[0][0]) < 0.6 and abs(v[1][0] - 3.0) < 0.6                  # z[1] ~ Normal(0, 3)
     p = pt.stepping_stone_pair()
     assert abs(0.5 * (p[0] + p[1])) < 0.25
+
+
+@pytest.mark.parametrize("w,p,n_passes", [(10.0, 20, 3), (1.0, 20, 2), (0.2, 20, 2), (0.05, 8, 1), (100.0, 20, 2)])
+def test_slice_accept_never_rejects_on_the_mvn_path(w, p, n_passes):
+    """The device's speculative rounds do not execute the acceptance check of the doubling scheme (SliceSampler.jl:192-237):
+    on the scaled-precision MVN path the slice is an interval for the floating-point predicate too, so the check cannot reject
+    (pigeons.jl_amd/csrc/pte_slice8.hpp, DESIGN.md 5 round 3 c).  The oracle DOES execute it, records 1.0 / 0.0 per call as the
+    reference does (explorer_acceptance_pr) -- its mean must be exactly 1 on every chain, also where almost every interval is
+    doubled (w far below the slice width) and where the doubling budget p is hit."""
+    for N, d, seed in [(6, 40, 1), (12, 7, 2), (4, 300, 3)]:
+        pt = O.OraclePT(n_chains=N, dim=d, seed=seed, explorer=O.EXPLORER_SLICE, slice_w=w, slice_p=p, slice_n_passes=n_passes)
+        for _ in range(4):
+            pt.run_round()
+            am, an, ss, sn = pt.explorer_stats()
+            assert np.all(an[1:] > 0) and np.all(am[1:] == 1.0), (w, p, N, d, am)
