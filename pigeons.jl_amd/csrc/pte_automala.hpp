@@ -43,9 +43,38 @@ __device__ __forceinline__ double block_tree(double (&s)[E]) {
 template <int E>
 __device__ __forceinline__ double tree_sum_regs(const double (&t)[E]) {
     double s[E];
+    constexpr int M = E < 4 ? E : 4;                  // block sums taken M at a time, their tree levels interleaved
 #pragma unroll
-    for (int j = 0; j < E; ++j) s[j] = wave_sum_dpp(t[j]);
+    for (int j0 = 0; j0 < E; j0 += M) {
+        double v[M];
+#pragma unroll
+        for (int j = 0; j < M; ++j) v[j] = t[j0 + j];
+        wave_sum_dpp_multi<M>(v);
+#pragma unroll
+        for (int j = 0; j < M; ++j) s[j0 + j] = v[j];
+    }
     return block_tree<E>(s);
+}
+// K reductions at once: the block sums of all of them in lockstep, two blocks of each at a time (6 chains for K = 3)
+template <int E, int K>
+__device__ __forceinline__ void tree_sum_regs_multi(const double (&t)[K][E], double (&out)[K]) {
+    double s[K][E];
+    constexpr int G = E < 2 ? E : 2;
+#pragma unroll
+    for (int j0 = 0; j0 < E; j0 += G) {
+        double v[K * G];
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int j = 0; j < G; ++j) v[k * G + j] = t[k][j0 + j];
+        wave_sum_dpp_multi<K * G>(v);
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int j = 0; j < G; ++j) s[k][j0 + j] = v[k * G + j];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) out[k] = block_tree<E>(s[k]);
 }
 template <int E>
 __device__ __forceinline__ double sqr_norm_regs(const double (&v)[E]) {
@@ -118,6 +147,44 @@ struct AmTarget {
         }
         return lp;
     }
+    // the same, with S = sum x^2 taken alongside: the block sums of the two or three reductions (x^2, the log-density terms, the
+    // terms of d/dy) are independent and run in lockstep (wave_sum_dpp_multi) instead of one dependent DPP chain after the other
+    __device__ __forceinline__ double funnel_and_sqr_norm(const double (&x)[E], double (*g)[E], double &S) const {
+        const double y = readlane_f64(x[0], 0);
+        const double sigma = exp(y / 2.0);
+        const double logsigma = log(sigma);
+        const double LOG2PI = 1.8378770664093453;
+        double zi[E];
+        if (g) {
+            double t[3][E], out[3];
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                zi[j] = x[j] / sigma;
+                t[0][j] = x[j] * x[j];
+                t[1][j] = valid(j) ? (-(zi[j] * zi[j] + LOG2PI) / 2.0 - logsigma) : 0.0;
+                (*g)[j] = valid(j) ? -(zi[j] / sigma) : 0.0;
+                t[2][j] = valid(j) ? (zi[j] * zi[j] - 1.0) / 2.0 : 0.0;
+            }
+            const double zv = y / 3.0;
+            if (lane == 0) { t[1][0] = -(zv * zv + LOG2PI) / 2.0 - log3; t[2][0] = -(y / 9.0); }
+            tree_sum_regs_multi<E, 3>(t, out);
+            S = out[0];
+            if (lane == 0) (*g)[0] = out[2];
+            return out[1];
+        }
+        double t[2][E], out[2];
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            zi[j] = x[j] / sigma;
+            t[0][j] = x[j] * x[j];
+            t[1][j] = valid(j) ? (-(zi[j] * zi[j] + LOG2PI) / 2.0 - logsigma) : 0.0;
+        }
+        const double zv = y / 3.0;
+        if (lane == 0) t[1][0] = -(zv * zv + LOG2PI) / 2.0 - log3;
+        tree_sum_regs_multi<E, 2>(t, out);
+        S = out[0];
+        return out[1];
+    }
     // log_potentials[chain](x) as a plain callable: InterpolatedLogPotential(x) (src/paths/InterpolatedLogPotential.jl:9-16)
     // WITH its beta == 0 / beta == 1 short-circuits -- what SliceSampler evaluates (the AD form below has none)
     __device__ __forceinline__ double path_lp(const double (&x)[E]) const {
@@ -131,25 +198,29 @@ struct AmTarget {
     }
     // LogDensityProblems.logdensity
     __device__ __forceinline__ double logdensity(const double (&x)[E]) const {
-        const double S = sqr_norm_regs<E>(x);
-        if (TGT == TGT_MVN) return nhp * S;
+        if (TGT == TGT_MVN) return nhp * sqr_norm_regs<E>(x);
+        double S, l2;
+        if (E <= 4) l2 = funnel_and_sqr_norm(x, nullptr, S);
+        else { S = sqr_norm_regs<E>(x); l2 = funnel(x, nullptr); }
         const double l1 = ref_lp(x, S);
-        const double l2 = funnel(x, nullptr);
         return omb * l1 + beta * l2;
     }
     // LogDensityProblems.logdensity_and_gradient
     __device__ __forceinline__ double logdensity_and_gradient(const double (&x)[E], double (&g)[E]) const {
-        const double S = sqr_norm_regs<E>(x);
+        double S = 0.0;
         if (TGT == TGT_MVN) {
+            S = sqr_norm_regs<E>(x);
 #pragma unroll
             for (int j = 0; j < E; ++j) g[j] = nprec * x[j];
             return nhp * S;
         }
         double logdens = 0.0;
+        double g2[E];
+        double l2;
+        if (E <= 4) l2 = funnel_and_sqr_norm(x, &g2, S);
+        else { S = sqr_norm_regs<E>(x); l2 = funnel(x, &g2); }
         const double l1 = ref_lp(x, S);
         logdens += l1 * omb;
-        double g2[E];
-        const double l2 = funnel(x, &g2);
         logdens += l2 * beta;
         if (vr) {                                    // BufferedAD{GaussianReference}: -1/s^2 (x - m)
 #pragma unroll

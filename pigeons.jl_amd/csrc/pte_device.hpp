@@ -112,6 +112,27 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     v = dpp_add_step<0x143, 0xC>(v);    // row_bcast31 -> rows 2,3
     return readlane_f64(v, 63);
 }
+// M independent wave sums taken in lockstep: the same operations per sum as wave_sum_dpp (bit-identical), but every level of the tree
+// is issued for all M sums before the next level, so that the wait states of one chain (a DPP move reads what the add before it
+// wrote: s_nop, plus the dependent FP64 latency) are filled by the others.  One dependent sum costs a wave alone on its SIMD ~180
+// cycles (tools/ubench/wave_sum_all.hip); hipcc issues consecutive wave_sum_dpp calls one after the other.
+template <int M>
+__device__ __forceinline__ void wave_sum_dpp_multi(double (&v)[M]) {
+#pragma unroll
+    for (int j = 0; j < M; ++j) v[j] = dpp_add_step<0xB1, 0xF>(v[j]);
+#pragma unroll
+    for (int j = 0; j < M; ++j) v[j] = dpp_add_step<0x4E, 0xF>(v[j]);
+#pragma unroll
+    for (int j = 0; j < M; ++j) v[j] = dpp_add_step<0x141, 0xF>(v[j]);
+#pragma unroll
+    for (int j = 0; j < M; ++j) v[j] = dpp_add_step<0x140, 0xF>(v[j]);
+#pragma unroll
+    for (int j = 0; j < M; ++j) v[j] = dpp_add_step<0x142, 0xA>(v[j]);
+#pragma unroll
+    for (int j = 0; j < M; ++j) v[j] = dpp_add_step<0x143, 0xC>(v[j]);
+#pragma unroll
+    for (int j = 0; j < M; ++j) v[j] = readlane_f64(v[j], 63);
+}
 // ---- sequential (uniform) stream: used on slow paths and for single draws ---------------------
 struct SeqRng {
     uint64_t seed, gamma;   // uniform
