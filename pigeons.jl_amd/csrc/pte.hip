@@ -22,7 +22,9 @@
 #include "pte_slice8.hpp"
 #include "pte_automala.hpp"
 #include "pte_ising.hpp"
-#ifdef PTE_PROFILE_WAVES                   // debug builds only (tools/prof_waves.py): per-wave start / end / placement of the explore kernel
+#if defined(PTE_PROFILE_AM)               // debug builds only (tools/prof_automala.py): 12 words per wave, section times of k_explore_automala
+#define PTE_WAVE_PROFILE_WORDS 12
+#elif defined(PTE_PROFILE_WAVES)          // debug builds only (tools/prof_waves.py): per-wave start / end / placement of the explore kernel
 #define PTE_WAVE_PROFILE_WORDS 4
 #else
 #define PTE_WAVE_PROFILE_WORDS 0
@@ -1453,13 +1455,14 @@ int pte_test_sqr_norm(int32_t device, const double *x, int64_t rows, int64_t d, 
 
 }  // extern "C"
 
-#ifdef PTE_PROFILE_WAVES
+#if defined(PTE_PROFILE_WAVES) || defined(PTE_PROFILE_AM)
 // debug builds only: out[4K] = per local chain {start, end on the 100 MHz clock, HW_ID, XCC_ID} of the last explore launch
+// (PTE_PROFILE_AM: out[12K], see pte_automala.hpp)
 extern "C" int pte_debug_wave_profile(pte_engine *h, double *out) {
     if (!h || !out) return 1;
     HIP_OK(h, hipSetDevice(h->cfg.device));
     HIP_OK(h, hipStreamSynchronize(h->stream));
-    HIP_OK(h, hipMemcpy(out, h->dev.on_m2 + 2 * (h->d + 1), sizeof(double) * 4 * (size_t)h->K, hipMemcpyDeviceToHost));
+    HIP_OK(h, hipMemcpy(out, h->dev.on_m2 + 2 * (h->d + 1), sizeof(double) * PTE_WAVE_PROFILE_WORDS * (size_t)h->K, hipMemcpyDeviceToHost));
     return 0;
 }
 #endif

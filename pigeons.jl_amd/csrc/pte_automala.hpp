@@ -42,39 +42,60 @@ __device__ __forceinline__ double block_tree(double (&s)[E]) {
 }
 template <int E>
 __device__ __forceinline__ double tree_sum_regs(const double (&t)[E]) {
-    double s[E];
-    constexpr int M = E < 4 ? E : 4;                  // block sums taken M at a time, their tree levels interleaved
+    if constexpr (E >= 4) {                            // block sums four at a time, blocks 2i and 2i+1 added in the same pass
+        double s[E / 2];
 #pragma unroll
-    for (int j0 = 0; j0 < E; j0 += M) {
-        double v[M];
+        for (int j0 = 0; j0 < E; j0 += 4) {
+            double v[4], o[2];
 #pragma unroll
-        for (int j = 0; j < M; ++j) v[j] = t[j0 + j];
-        wave_sum_dpp_multi<M>(v);
+            for (int j = 0; j < 4; ++j) v[j] = t[j0 + j];
+            wave_sum_pairs<4>(v, o);
+            s[j0 / 2] = o[0]; s[j0 / 2 + 1] = o[1];
+        }
+        return block_tree<E / 2>(s);
+    } else {
+        double s[E];
 #pragma unroll
-        for (int j = 0; j < M; ++j) s[j0 + j] = v[j];
+        for (int j = 0; j < E; ++j) s[j] = t[j];
+        wave_sum_dpp_multi<E>(s);                      // their tree levels interleaved
+        return block_tree<E>(s);
     }
-    return block_tree<E>(s);
 }
-// K reductions at once: the block sums of all of them in lockstep, two blocks of each at a time (6 chains for K = 3)
+// K reductions at once (K = 2 or 4, E >= 2): the block sums of all of them in lockstep, blocks 2i and 2i+1 of each at a time
 template <int E, int K>
 __device__ __forceinline__ void tree_sum_regs_multi(const double (&t)[K][E], double (&out)[K]) {
-    double s[K][E];
-    constexpr int G = E < 2 ? E : 2;
+    if constexpr (E >= 2 && (K == 2 || K == 4)) {
+        double s[K][E / 2];
 #pragma unroll
-    for (int j0 = 0; j0 < E; j0 += G) {
-        double v[K * G];
+        for (int j0 = 0; j0 < E; j0 += 2) {
+            double v[2 * K], o[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k)
+            for (int k = 0; k < K; ++k) { v[2 * k] = t[k][j0]; v[2 * k + 1] = t[k][j0 + 1]; }
+            wave_sum_pairs<2 * K>(v, o);
 #pragma unroll
-            for (int j = 0; j < G; ++j) v[k * G + j] = t[k][j0 + j];
-        wave_sum_dpp_multi<K * G>(v);
+            for (int k = 0; k < K; ++k) s[k][j0 / 2] = o[k];
+        }
 #pragma unroll
-        for (int k = 0; k < K; ++k)
+        for (int k = 0; k < K; ++k) out[k] = block_tree<E / 2>(s[k]);
+    } else {
+        double s[K][E];
+        constexpr int G = E < 2 ? E : 2;
 #pragma unroll
-            for (int j = 0; j < G; ++j) s[k][j0 + j] = v[k * G + j];
+        for (int j0 = 0; j0 < E; j0 += G) {
+            double v[K * G];
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int j = 0; j < G; ++j) v[k * G + j] = t[k][j0 + j];
+            wave_sum_dpp_multi<K * G>(v);
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int j = 0; j < G; ++j) s[k][j0 + j] = v[k * G + j];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[k] = block_tree<E>(s[k]);
     }
-#pragma unroll
-    for (int k = 0; k < K; ++k) out[k] = block_tree<E>(s[k]);
 }
 template <int E>
 __device__ __forceinline__ double sqr_norm_regs(const double (&v)[E]) {
@@ -147,42 +168,34 @@ struct AmTarget {
         }
         return lp;
     }
-    // the same, with S = sum x^2 taken alongside: the block sums of the two or three reductions (x^2, the log-density terms, the
-    // terms of d/dy) are independent and run in lockstep (wave_sum_dpp_multi) instead of one dependent DPP chain after the other
-    __device__ __forceinline__ double funnel_and_sqr_norm(const double (&x)[E], double (*g)[E], double &S) const {
+    // the same, with S = sum x^2 (and, when q is given, Q = sum q^2: the kinetic energy the caller needs next) taken alongside:
+    // the block sums of the two to four reductions are independent and run in lockstep (wave_sum_dpp_multi) instead of one
+    // dependent DPP chain after the other
+    template <bool GRAD, bool WITH_Q>
+    __device__ __forceinline__ double funnel_and_sqr_norm(const double (&x)[E], double (&g)[E], double &S, const double (&q)[E], double &Q) const {
         const double y = readlane_f64(x[0], 0);
         const double sigma = exp(y / 2.0);
         const double logsigma = log(sigma);
         const double LOG2PI = 1.8378770664093453;
-        double zi[E];
-        if (g) {
-            double t[3][E], out[3];
-#pragma unroll
-            for (int j = 0; j < E; ++j) {
-                zi[j] = x[j] / sigma;
-                t[0][j] = x[j] * x[j];
-                t[1][j] = valid(j) ? (-(zi[j] * zi[j] + LOG2PI) / 2.0 - logsigma) : 0.0;
-                (*g)[j] = valid(j) ? -(zi[j] / sigma) : 0.0;
-                t[2][j] = valid(j) ? (zi[j] * zi[j] - 1.0) / 2.0 : 0.0;
-            }
-            const double zv = y / 3.0;
-            if (lane == 0) { t[1][0] = -(zv * zv + LOG2PI) / 2.0 - log3; t[2][0] = -(y / 9.0); }
-            tree_sum_regs_multi<E, 3>(t, out);
-            S = out[0];
-            if (lane == 0) (*g)[0] = out[2];
-            return out[1];
-        }
-        double t[2][E], out[2];
+        constexpr int K = 2 + (GRAD ? 1 : 0) + (WITH_Q ? 1 : 0), KG = 2, KQ = GRAD ? 3 : 2;
+        double t[K][E], out[K];
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            zi[j] = x[j] / sigma;
+            const double zi = x[j] / sigma;
             t[0][j] = x[j] * x[j];
-            t[1][j] = valid(j) ? (-(zi[j] * zi[j] + LOG2PI) / 2.0 - logsigma) : 0.0;
+            t[1][j] = valid(j) ? (-(zi * zi + LOG2PI) / 2.0 - logsigma) : 0.0;
+            if (GRAD) {
+                g[j] = valid(j) ? -(zi / sigma) : 0.0;
+                t[KG % K][j] = valid(j) ? (zi * zi - 1.0) / 2.0 : 0.0;
+            }
+            if (WITH_Q) t[KQ % K][j] = q[j] * q[j];
         }
         const double zv = y / 3.0;
-        if (lane == 0) t[1][0] = -(zv * zv + LOG2PI) / 2.0 - log3;
-        tree_sum_regs_multi<E, 2>(t, out);
+        if (lane == 0) { t[1][0] = -(zv * zv + LOG2PI) / 2.0 - log3; if (GRAD) t[KG % K][0] = -(y / 9.0); }
+        tree_sum_regs_multi<E, K>(t, out);
         S = out[0];
+        if (GRAD) { if (lane == 0) g[0] = out[KG % K]; }
+        if (WITH_Q) Q = out[KQ % K];
         return out[1];
     }
     // log_potentials[chain](x) as a plain callable: InterpolatedLogPotential(x) (src/paths/InterpolatedLogPotential.jl:9-16)
@@ -199,17 +212,24 @@ struct AmTarget {
     // LogDensityProblems.logdensity
     __device__ __forceinline__ double logdensity(const double (&x)[E]) const {
         if (TGT == TGT_MVN) return nhp * sqr_norm_regs<E>(x);
-        double S, l2;
-        if (E <= 4) l2 = funnel_and_sqr_norm(x, nullptr, S);
+        double S, l2, dummy[E], dq;
+        if (E <= 4) l2 = funnel_and_sqr_norm<false, false>(x, dummy, S, x, dq);
         else { S = sqr_norm_regs<E>(x); l2 = funnel(x, nullptr); }
         const double l1 = ref_lp(x, S);
         return omb * l1 + beta * l2;
     }
-    // LogDensityProblems.logdensity_and_gradient
-    __device__ __forceinline__ double logdensity_and_gradient(const double (&x)[E], double (&g)[E]) const {
+    // LogDensityProblems.logdensity_and_gradient; WITH_Q: also Q = sum q^2 (fixed tree), reduced in lockstep with the sums of the density
+    template <bool WITH_Q>
+    __device__ __forceinline__ double logdensity_and_gradient_q(const double (&x)[E], double (&g)[E], const double (&q)[E], double &Q) const {
         double S = 0.0;
         if (TGT == TGT_MVN) {
-            S = sqr_norm_regs<E>(x);
+            if (WITH_Q) {
+                double t[2][E], out[2];
+#pragma unroll
+                for (int j = 0; j < E; ++j) { t[0][j] = x[j] * x[j]; t[1][j] = q[j] * q[j]; }
+                tree_sum_regs_multi<E, 2>(t, out);
+                S = out[0]; Q = out[1];
+            } else S = sqr_norm_regs<E>(x);
 #pragma unroll
             for (int j = 0; j < E; ++j) g[j] = nprec * x[j];
             return nhp * S;
@@ -217,8 +237,8 @@ struct AmTarget {
         double logdens = 0.0;
         double g2[E];
         double l2;
-        if (E <= 4) l2 = funnel_and_sqr_norm(x, &g2, S);
-        else { S = sqr_norm_regs<E>(x); l2 = funnel(x, &g2); }
+        if (E <= 4) l2 = funnel_and_sqr_norm<true, WITH_Q>(x, g2, S, q, Q);
+        else { S = sqr_norm_regs<E>(x); l2 = funnel(x, &g2); if (WITH_Q) Q = sqr_norm_regs<E>(q); }
         const double l1 = ref_lp(x, S);
         logdens += l1 * omb;
         logdens += l2 * beta;
@@ -231,6 +251,10 @@ struct AmTarget {
         }
         return logdens;
     }
+    __device__ __forceinline__ double logdensity_and_gradient(const double (&x)[E], double (&g)[E]) const {
+        double dq;
+        return logdensity_and_gradient_q<false>(x, g, x, dq);
+    }
 };
 
 // SLICE = true instantiates the same prologue (reference-chain refresh, state load) and epilogue (swap statistics, recorders)
@@ -239,6 +263,13 @@ template <int E, int TGT, bool SLICE = false>
 __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams ap) {
     constexpr int NLU = (E == 1 ? 0 : E == 2 ? 1 : E == 4 ? 2 : E == 8 ? 3 : 4);
     const int lane = lane_id();
+    // the ziggurat tables of the momentum draws, staged once: a global gather per block of draws costs a memory round trip each time
+    __shared__ double s_wi[256];
+    __shared__ unsigned long long s_ki[256];
+    if (!SLICE) {
+        for (int i = lane; i < 256; i += 64) { s_wi[i] = ZIG_WI[i]; s_ki[i] = ZIG_KI[i]; }
+        __syncthreads();
+    }
     const int64_t cl = blockIdx.x;
     if (cl >= e.K) return;
     const int64_t c = e.c0 + cl;
@@ -319,6 +350,14 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         }
     }
 
+#ifdef PTE_PROFILE_AM                      // debug builds only (tools/prof_automala.py): shader-clock time per section of the refresh loop
+    uint64_t am_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t am_tlast = __builtin_amdgcn_s_memtime();
+    const uint64_t am_rt0 = __builtin_amdgcn_s_memrealtime();
+#define AM_STAMP(k) do { asm volatile("" ::: "memory"); const uint64_t t_ = __builtin_amdgcn_s_memtime(); am_prof[k] += t_ - am_tlast; am_tlast = t_; asm volatile("" ::: "memory"); } while (0)
+#else
+#define AM_STAMP(k) do { } while (0)
+#endif
     double p[E], g[E], xs[E], xb[E], pb[E];
     long long steps_sum = 0; int steps_n = 0;
     double fac_sum = 0.0; int fac_n = 0;
@@ -332,8 +371,9 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
     // evaluations per auto_step_size call.
     double g0[E];            // conditioned gradient at the current x (valid after grad_at_start, until x moves for good)
     double lp0 = 0.0;        // log density at the current x
+    double pp0 = 0.0;        // |p|^2 of the fresh momentum, reduced alongside the sums of the density
     auto grad_at_start = [&]() {
-        lp0 = T.logdensity_and_gradient(x, g0);
+        lp0 = T.template logdensity_and_gradient_q<true>(x, g0, p, pp0);
 #pragma unroll
         for (int j = 0; j < E; ++j) g0[j] = g0[j] / M[j];
     };
@@ -347,11 +387,12 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         for (int j = 0; j < E; ++j) p[j] = p[j] + half * g0[j];
 #pragma unroll
         for (int j = 0; j < E; ++j) x[j] = x[j] + eps * (p[j] / M[j]);
-        const double logp = T.logdensity_and_gradient(x, g);
+        double pp_mid;                                    // |p|^2 after the first half step: independent of the gradient, reduced with it
+        const double logp = T.template logdensity_and_gradient_q<true>(x, g, p, pp_mid);
         logp_out = logp;
 #pragma unroll
         for (int j = 0; j < E; ++j) g[j] = g[j] / M[j];
-        const double ke_mid = 0.5 * sqr_norm_regs<E>(p);
+        const double ke_mid = 0.5 * pp_mid;
         ke_out = ke_mid;
         const double cur = logp - ke_mid;
         if (!isfinite(cur)) return false;
@@ -473,15 +514,18 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         r.seed = dr.final_seed();
     } else
     for (int it = 0; it < ap.n_refresh && !err; ++it) {
+        AM_STAMP(7);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             xs[j] = x[j];
             const int nl = (int)max((int64_t)0, min((int64_t)64, d - 64 * (int64_t)j));
             p[j] = 0.0;
-            if (nl > 0) { const double v = wave_randn_block(r, lane, nl); p[j] = lane < nl ? v : 0.0; }
+            if (nl > 0) { const double v = wave_randn_block(r, lane, nl, s_wi, s_ki); p[j] = lane < nl ? v : 0.0; }
         }
+        AM_STAMP(0);
         grad_at_start();
-        const double init_joint = lp0 - kinetic();
+        const double init_joint = lp0 - 0.5 * pp0;
+        AM_STAMP(1);
         if (!isfinite(init_joint)) { err = ERR_AM_DENSITY; break; }
         if (ap.mala) {                                   // mala! (MALA.jl:79-96)
             double lpn, ken;
@@ -500,10 +544,13 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         }
         const double ua = r.rand(), ub = r.rand();
         const double lower = log(ua < ub ? ua : ub), upper = log(ua < ub ? ub : ua);
+        AM_STAMP(2);
         const int proposed = auto_step_size(lower, upper, init_joint);
         if (err) break;
+        AM_STAMP(3);
         double lp_moved, ke_moved;
         const bool moved_ok = leap_frog(ap.step_size * ldexp(1.0, proposed), lp_moved, ke_moved);
+        AM_STAMP(4);
         if (ap.use_mh) {
 #pragma unroll
             for (int j = 0; j < E; ++j) p[j] = p[j] * -1.0;
@@ -514,6 +561,7 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
             const double h_rev = lp0 - (moved_ok ? ke_moved : kinetic());
             const int reversed = auto_step_size(lower, upper, h_rev);
             if (err) break;
+            AM_STAMP(5);
             const bool passed = reversed == proposed;
             rev_sum += passed ? 1 : 0; rev_n += 1;
             double probability = 0.0;
@@ -526,8 +574,16 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
 #pragma unroll
                 for (int j = 0; j < E; ++j) x[j] = xs[j];
             }
+            AM_STAMP(6);
         }
     }
+#ifdef PTE_PROFILE_AM
+    if (lane == 0) {
+        double *o = e.on_m2 + 2 * (d + 1) + 12 * cl;
+        for (int k = 0; k < 8; ++k) o[k] = (double)am_prof[k];
+        o[8] = (double)(__builtin_amdgcn_s_memrealtime() - am_rt0); o[9] = (double)steps_sum; o[10] = (double)steps_n; o[11] = (double)ap.n_refresh;
+    }
+#endif
     if (err) { if (lane == 0) set_error(e, err, (int)c, -1); return; }
 #pragma unroll
     for (int j = 0; j < E; ++j) if (T.valid(j)) xrow[64 * j + lane] = x[j];

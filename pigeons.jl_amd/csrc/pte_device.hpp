@@ -133,6 +133,56 @@ __device__ __forceinline__ void wave_sum_dpp_multi(double (&v)[M]) {
 #pragma unroll
     for (int j = 0; j < M; ++j) v[j] = readlane_f64(v[j], 63);
 }
+// gfx950 row / half exchanges between two registers:
+//   permlane16_swap(a, b): a' = [a.r0, b.r0, a.r2, b.r2], b' = [a.r1, b.r1, a.r3, b.r3]   (r = rows of 16 lanes)
+//   permlane32_swap(a, b): a' = [a.lo, b.lo],             b' = [a.hi, b.hi]               (halves of 32 lanes)
+// so that a' + b' is the next level of the fixed tree for BOTH operands at once, packed into one register.
+__device__ __forceinline__ void permlane16_swap_f64(double &a, double &b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]); b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void permlane32_swap_f64(double &a, double &b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]); b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// M = 4 or 8 wave sums, v[2i] and v[2i+1] being two 64-blocks whose totals the tree adds next: out[i] = sum(v[2i]) + sum(v[2i+1]).
+// Every addition is one the fixed tree makes (same operand pairs as wave_sum_dpp, then the block pair), but from the rows upwards the
+// partial sums of two chains share a register: 15.6 instructions per chain instead of 20.5.
+//   levels 1-4 (inside a row of 16): per chain, as in wave_sum_dpp
+//   level 5 (rows 0+1, 2+3):  pairs of chains through permlane16_swap  -> M/2 registers  [A01, B01, A23, B23]
+//   level 6 (halves):         pairs of those through permlane32_swap   -> M/4 registers  [A, B, C, D]  (one total per row)
+//   block pair A+B, C+D:      permlane16_swap again                    -> row 0 / row 2 (and rows 1 / 3 for the second register)
+template <int M>
+__device__ __forceinline__ void wave_sum_pairs(double (&v)[M], double (&out)[M / 2]) {
+    static_assert(M == 4 || M == 8, "wave_sum_pairs: 4 or 8 chains");
+#pragma unroll
+    for (int j = 0; j < M; ++j) v[j] = dpp_add_step<0xB1, 0xF>(v[j]);
+#pragma unroll
+    for (int j = 0; j < M; ++j) v[j] = dpp_add_step<0x4E, 0xF>(v[j]);
+#pragma unroll
+    for (int j = 0; j < M; ++j) v[j] = dpp_add_step<0x141, 0xF>(v[j]);
+#pragma unroll
+    for (int j = 0; j < M; ++j) v[j] = dpp_add_step<0x140, 0xF>(v[j]);
+    double w[M / 2];
+#pragma unroll
+    for (int i = 0; i < M / 2; ++i) { permlane16_swap_f64(v[2 * i], v[2 * i + 1]); w[i] = v[2 * i] + v[2 * i + 1]; }
+    double u[M / 4];
+#pragma unroll
+    for (int i = 0; i < M / 4; ++i) { permlane32_swap_f64(w[2 * i], w[2 * i + 1]); u[i] = w[2 * i] + w[2 * i + 1]; }
+    if constexpr (M == 8) {
+        permlane16_swap_f64(u[0], u[1]);               // u0' = [A, E, C, G], u1' = [B, F, D, H]   (A..D = chains 0..3 of u0, E..H = 4..7)
+        const double z = u[0] + u[1];                  // rows: pair 0, pair 2, pair 1, pair 3
+        out[0] = readlane_f64(z, 0); out[2] = readlane_f64(z, 16);
+        out[1] = readlane_f64(z, 32); out[3] = readlane_f64(z, 48);
+    } else {
+        double t = u[0];
+        permlane16_swap_f64(u[0], t);                  // u0' = [A, A, C, C], t' = [B, B, D, D]
+        const double z = u[0] + t;
+        out[0] = readlane_f64(z, 0); out[1] = readlane_f64(z, 32);
+    }
+}
 // ---- sequential (uniform) stream: used on slow paths and for single draws ---------------------
 struct SeqRng {
     uint64_t seed, gamma;   // uniform
