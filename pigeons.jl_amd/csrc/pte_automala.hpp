@@ -266,8 +266,9 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
     // the ziggurat tables of the momentum draws, staged once: a global gather per block of draws costs a memory round trip each time
     __shared__ double s_wi[256];
     __shared__ unsigned long long s_ki[256];
+    __shared__ double s_fi[256];
     if (!SLICE) {
-        for (int i = lane; i < 256; i += 64) { s_wi[i] = ZIG_WI[i]; s_ki[i] = ZIG_KI[i]; }
+        for (int i = lane; i < 256; i += 64) { s_wi[i] = ZIG_WI[i]; s_ki[i] = ZIG_KI[i]; s_fi[i] = ZIG_FI[i]; }
         __syncthreads();
     }
     const int64_t cl = blockIdx.x;
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
             xs[j] = x[j];
             const int nl = (int)max((int64_t)0, min((int64_t)64, d - 64 * (int64_t)j));
             p[j] = 0.0;
-            if (nl > 0) { const double v = wave_randn_block(r, lane, nl, s_wi, s_ki); p[j] = lane < nl ? v : 0.0; }
+            if (nl > 0) { const double v = wave_randn_block(r, lane, nl, s_wi, s_ki, s_fi); p[j] = lane < nl ? v : 0.0; }
         }
         AM_STAMP(0);
         grad_at_start();

@@ -191,33 +191,35 @@ struct SeqRng {
 };
 
 // randn slow path (Julia Random/src/normal.jl `randn_unlikely`), given the failed first draw.
-__device__ inline double randn_seq(SeqRng &r);
-__device__ inline double randn_unlikely(SeqRng &r, int idx, int64_t rabs, double x) {
+// (tables: global by default; a caller that staged them in LDS passes its copies -- a global gather is a memory round trip per event)
+__device__ inline double randn_seq(SeqRng &r, const double *wi = ZIG_WI, const unsigned long long *ki = ZIG_KI, const double *fi = ZIG_FI);
+__device__ inline double randn_unlikely(SeqRng &r, int idx, int64_t rabs, double x,
+                                        const double *wi = ZIG_WI, const unsigned long long *ki = ZIG_KI, const double *fi = ZIG_FI) {
     if (idx == 0) {
         for (;;) {
             double xx = ZIG_NOR_INV_R * zig_tail_neglog(r.rand());
             double yy = zig_tail_neglog(r.rand());
             if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? (-ZIG_NOR_R - xx) : (ZIG_NOR_R + xx);
         }
-    } else if ((ZIG_FI[idx - 1] - ZIG_FI[idx]) * r.rand() + ZIG_FI[idx] < exp(-0.5 * x * x)) {
+    } else if ((fi[idx - 1] - fi[idx]) * r.rand() + fi[idx] < exp(-0.5 * x * x)) {
         return x;
     }
-    return randn_seq(r);
+    return randn_seq(r, wi, ki, fi);
 }
-__device__ inline double randn_seq(SeqRng &r) {
+__device__ inline double randn_seq(SeqRng &r, const double *wi, const unsigned long long *ki, const double *fi) {
     for (;;) {
         uint64_t u = r.next() & MASK52;
         int64_t rabs = (int64_t)(u >> 1);
         int idx = (int)(rabs & 0xFF);
-        double x = (double)((u & 1) ? -rabs : rabs) * ZIG_WI[idx];
-        if ((uint64_t)rabs < ZIG_KI[idx]) return x;
+        double x = (double)((u & 1) ? -rabs : rabs) * wi[idx];
+        if ((uint64_t)rabs < ki[idx]) return x;
         if (idx == 0) {
             for (;;) {
                 double xx = ZIG_NOR_INV_R * zig_tail_neglog(r.rand());
                 double yy = zig_tail_neglog(r.rand());
                 if (yy + yy > xx * xx) return ((rabs >> 8) & 1) ? (-ZIG_NOR_R - xx) : (ZIG_NOR_R + xx);
             }
-        } else if ((ZIG_FI[idx - 1] - ZIG_FI[idx]) * r.rand() + ZIG_FI[idx] < exp(-0.5 * x * x)) {
+        } else if ((fi[idx - 1] - fi[idx]) * r.rand() + fi[idx] < exp(-0.5 * x * x)) {
             return x;
         }
     }
@@ -242,7 +244,7 @@ __device__ inline double randexp_seq(SeqRng &r) { return randexp_from_raw(r, r.n
 // lanes draw speculatively at consecutive counters; the first lane that needs the slow path is
 // resolved sequentially (it may consume extra draws) and the lanes after it are re-drawn.
 __device__ inline double wave_randn_block(SeqRng &r, int lane, int n_valid /*uniform, <= 64*/,
-                                          const double *wi = ZIG_WI, const unsigned long long *ki = ZIG_KI) {
+                                          const double *wi = ZIG_WI, const unsigned long long *ki = ZIG_KI, const double *fi = ZIG_FI) {
     double out = 0.0;
     int start = 0;
     while (start < n_valid) {
@@ -266,7 +268,7 @@ __device__ inline double wave_randn_block(SeqRng &r, int lane, int n_valid /*uni
         int idx_f = __builtin_amdgcn_readlane(idx, f);
         int64_t rabs_f = (int64_t)readlane_u64((uint64_t)rabs, f);
         double x_f = readlane_f64(x, f);
-        double xf = randn_unlikely(r, idx_f, rabs_f, x_f);
+        double xf = randn_unlikely(r, idx_f, rabs_f, x_f, wi, ki, fi);
         if (lane == f) out = xf;
         start = f + 1;
     }
