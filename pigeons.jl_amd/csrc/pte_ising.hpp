@@ -274,7 +274,6 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingParams ip) {
     extern __shared__ unsigned words[];
-    __shared__ unsigned s_uh[72];            // high words of the 64 buffered uniforms (+ padding read only by dead hypotheses)
     const int lane = lane_id();
     const int64_t cl = blockIdx.x;
     if (cl >= e.K) return;
@@ -327,9 +326,18 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
         const int lc = lidx >> 1;
         const unsigned lb = (unsigned)(lidx & 1);
         double unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma));
-        if (lane < 8) s_uh[64 + lane] = 0u;
-        s_uh[lane] = (unsigned)__double2hiint(unit);
-        __builtin_amdgcn_wave_barrier();
+        // The 64 buffered uniforms enter the vector pass only through four comparisons of their high words with the guard-banded
+        // thresholds: taken once per refill for the whole buffer (four ballots, bit i = uniform i), a hypothesis that has consumed
+        // lc uniforms reads bit (p + lc + its own count) of the mask its delta selects -- no LDS copy of the buffer, no load on the
+        // chain p -> pass -> chase -> p.   R = certainly rejected (u above the band), A = inside the band (or no valid filter).
+        unsigned long long mR4, mA4, mR8, mA8;
+        auto classify = [&]() {
+            const unsigned uh = (unsigned)__double2hiint(unit);
+            mR4 = ballot64(uh > r4hi_h); mR8 = ballot64(uh > r8hi_h);
+            mA4 = filter_ok ? ballot64(!(uh > r4hi_h) && !(uh < r4lo_h)) : ~0ull;
+            mA8 = filter_ok ? ballot64(!(uh > r8hi_h) && !(uh < r8lo_h)) : ~0ull;
+        };
+        classify();
         int p = 0;
         for (int k = 0; k < ip.n_steps; ++k) {
             for (int i = 0; i < L; ++i) {
@@ -345,34 +353,34 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                     for (int T0 = 0; T0 < 32; T0 += 16) {
                         if (p + 16 > 64) {
                             seed += (uint64_t)p * gamma; unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma)); p = 0;
-                            __builtin_amdgcn_wave_barrier();
-                            s_uh[lane] = (unsigned)__double2hiint(unit);
-                            __builtin_amdgcn_wave_barrier();
+                            classify();
                         }
                         const unsigned rt31 = (W == 1) ? (cur & 1u) : rightbit;
                         // ---- vector pass: every (quad, consumed, left) hypothesis of the chunk walks its four sites
-                        // (its uniforms are the next <= 4 of the buffer from position p + lc: loaded at once, picked by the count so far)
-                        const unsigned *uhp = &s_uh[p + lc];
-                        const unsigned uh0 = uhp[0], uh1 = uhp[1], uh2 = uhp[2], uh3 = uhp[3];
+                        // (its uniforms are the next <= 4 of the buffer from position p + lc: bits p + lc .. of the masks)
+                        const int sh = p + lc;                                   // <= 48 + 12
+                        const unsigned wR4 = (unsigned)(mR4 >> sh), wA4 = (unsigned)(mA4 >> sh), wR8 = (unsigned)(mR8 >> sh), wA8 = (unsigned)(mA8 >> sh);
                         int dc = 0, accbits = 0;
                         unsigned left = lb;
-                        bool amb = false;
+                        unsigned ambu = 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int t = (T0 + 4 * lk + j) & 31;
                             const unsigned sg = (cur >> t) & 1u;
                             const unsigned rt = (t == 31) ? rt31 : ((cur >> ((t + 1) & 31)) & 1u);
-                            const int nb = 2 * (int)(((up >> t) & 1u) + ((dn >> t) & 1u) + left + rt) - 4;
-                            const int delta = (1 - 2 * (int)sg) * 2 * nb;
-                            const bool need = delta < 0;
-                            const unsigned uhi = (j == 0 || dc == 0) ? uh0 : (j == 1 || dc == 1) ? uh1 : (j == 2 || dc == 2) ? uh2 : uh3;
-                            const unsigned hi_h = delta == -4 ? r4hi_h : r8hi_h, lo_h = delta == -4 ? r4lo_h : r8lo_h;
-                            const bool rej = need && (uhi > hi_h);
-                            amb = amb || (need && ((!rej && !(uhi < lo_h)) || !filter_ok));
-                            left = sg ^ (rej ? 0u : 1u);
-                            accbits |= (rej ? 0 : 1) << j;
+                            // delta = (1 - 2 sg) * 2 * (2 cnt - 4) with cnt = neighbours that are 1  ==  4 k - 8 with k = neighbours EQUAL
+                            // ... to the flipped spin's opposite, i.e. k = sg ? 4 - cnt : cnt: a draw is needed iff k < 2, delta == -4 iff k == 1
+                            const unsigned cnt = ((up >> t) & 1u) + ((dn >> t) & 1u) + left + rt;
+                            const unsigned kk = sg ? 4u - cnt : cnt;
+                            const bool need = kk < 2u;
+                            const unsigned mr = kk == 1u ? wR4 : wR8, ma = kk == 1u ? wA4 : wA8;
+                            const unsigned rej = need ? ((mr >> dc) & 1u) : 0u;
+                            ambu |= need ? ((ma >> dc) & 1u) : 0u;
+                            left = sg ^ rej ^ 1u;
+                            accbits |= (int)(rej ^ 1u) << j;
                             dc += need ? 1 : 0;
                         }
+                        const bool amb = ambu != 0;
                         const int c_run = lc + dc;
                         // packed: bit 0 = ambiguous somewhere in the quad, bits 1-4 = accepts, bits 5.. = NEXT chase state 2 c + spin
                         const int pk = (amb ? 1 : 0) | (accbits << 1) | ((2 * c_run + (int)left) << 5);
