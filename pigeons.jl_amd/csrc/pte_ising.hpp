@@ -359,7 +359,8 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                         // ---- vector pass: every (quad, consumed, left) hypothesis of the chunk walks its four sites
                         // (its uniforms are the next <= 4 of the buffer from position p + lc: bits p + lc .. of the masks)
                         const int sh = p + lc;                                   // <= 48 + 12
-                        const unsigned wR4 = (unsigned)(mR4 >> sh), wA4 = (unsigned)(mA4 >> sh), wR8 = (unsigned)(mR8 >> sh), wA8 = (unsigned)(mA8 >> sh);
+                        unsigned wR4 = (unsigned)(mR4 >> sh), wA4 = (unsigned)(mA4 >> sh), wR8 = (unsigned)(mR8 >> sh), wA8 = (unsigned)(mA8 >> sh);
+                        asm volatile("" : "+v"(wR4), "+v"(wA4), "+v"(wR8), "+v"(wA8));   // (keep the four 64-bit shifts here: hipcc sinks them below the per-site selects, 8 per pass)
                         int dc = 0, accbits = 0;
                         unsigned left = lb;
                         unsigned ambu = 0;
