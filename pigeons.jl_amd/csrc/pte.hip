@@ -331,8 +331,11 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
         const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
         const bool fun = h->cfg.target == PTE_TARGET_FUNNEL;
         time_begin(h, 0);
+        const bool full = h->d == 64 * (int64_t)E;       // no ragged last block: the instantiation without per-lane validity masks
 #define AM_LAUNCH(EE)                                                                                         \
-        if (fun) hipLaunchKernelGGL((k_explore_automala<EE, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
+        if (fun && full) hipLaunchKernelGGL((k_explore_automala<EE, TGT_FUNNEL, false, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
+        else if (fun) hipLaunchKernelGGL((k_explore_automala<EE, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
+        else if (full) hipLaunchKernelGGL((k_explore_automala<EE, TGT_MVN, false, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
         else hipLaunchKernelGGL((k_explore_automala<EE, TGT_MVN>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap);
         switch (E) { case 1: AM_LAUNCH(1) break; case 2: AM_LAUNCH(2) break; case 4: AM_LAUNCH(4) break;
                      case 8: AM_LAUNCH(8) break; default: AM_LAUNCH(16) break; }

@@ -105,7 +105,9 @@ __device__ __forceinline__ double sqr_norm_regs(const double (&v)[E]) {
     return tree_sum_regs<E>(t);
 }
 
-template <int E, int TGT>
+// FULL: d == 64 E, every lane of every block holds an element -- the masks, selects and EXEC-guarded divisions of a ragged last
+// block vanish (25 instructions of ~600 per leapfrog at E = 2)
+template <int E, int TGT, bool FULL = false>
 struct AmTarget {
     int64_t d; int lane;
     double nhp, nprec;          // MVN: -0.5*prec, -prec of this chain
@@ -139,7 +141,7 @@ struct AmTarget {
         return tree_sum_regs<E>(t);
     }
     __device__ __forceinline__ double ref_lp(const double (&x)[E], double S) const { return vr ? variational_lp(x) : ref_nhp * S; }
-    __device__ __forceinline__ bool valid(int j) const { return 64 * (int64_t)j + lane < d; }
+    __device__ __forceinline__ bool valid(int j) const { return FULL || 64 * (int64_t)j + lane < d; }
 
     // funnel: log density and (optionally) gradient; S = sum x^2 supplied by the caller
     __device__ __forceinline__ double funnel(const double (&x)[E], double (*g)[E]) const {
@@ -259,7 +261,7 @@ struct AmTarget {
 
 // SLICE = true instantiates the same prologue (reference-chain refresh, state load) and epilogue (swap statistics, recorders)
 // around the SliceSampler sweep instead of the Langevin refreshes: a separate kernel, so that neither pays for the other's registers.
-template <int E, int TGT, bool SLICE = false>
+template <int E, int TGT, bool SLICE = false, bool FULL = false>
 __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams ap) {
     constexpr int NLU = (E == 1 ? 0 : E == 2 ? 1 : E == 4 ? 2 : E == 8 ? 3 : 4);
     const int lane = lane_id();
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
     const int slot = e.slot_of_chain[cl];
     const int64_t d = e.d;
     double *xrow = e.x + (int64_t)slot * e.ld;
-    AmTarget<E, TGT> T;
+    AmTarget<E, TGT, FULL> T;
     T.d = d; T.lane = lane;
     T.nhp = e.nhp[c]; T.nprec = e.nprec[c];
     T.beta = e.beta[c]; T.omb = 1.0 - T.beta;
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             xs[j] = x[j];
-            const int nl = (int)max((int64_t)0, min((int64_t)64, d - 64 * (int64_t)j));
+            const int nl = FULL ? 64 : (int)max((int64_t)0, min((int64_t)64, d - 64 * (int64_t)j));
             p[j] = 0.0;
             if (nl > 0) { const double v = wave_randn_block(r, lane, nl, s_wi, s_ki, s_fi); p[j] = lane < nl ? v : 0.0; }
         }
