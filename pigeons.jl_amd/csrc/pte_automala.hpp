@@ -406,33 +406,53 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         if (!isfinite(sq)) return false;
         return true;
     };
-    // auto_step_size (:184-214): returns the exponent; h_before = log_joint at the start point (g0 / lp0 valid there)
-    auto auto_step_size = [&](double lower, double upper, double h_before) -> int {
+    // auto_step_size (:184-214): returns the exponent; h_before = log_joint at the start point (g0 / lp0 valid there).
+    // keep: the forward search.  The reference follows it with leap_frog!(start point, step_size * 2^exponent) -- a leapfrog the search
+    // has ALREADY made from the same point with the same step: its last trial when it shrank (exponent = -n) or did not move
+    // (exponent = 0), its last but one when it grew (exponent = n - 1).  That trial's outcome (state, momentum, conditioned gradient,
+    // log density, kinetic energy, return value) is kept instead of being thrown away and recomputed: the same bits, one gradient
+    // evaluation per refresh less.
+    double xk[E], pk[E], gk[E], lpk = 0.0, kek = 0.0; bool okk = true;
+    auto auto_step_size = [&](double lower, double upper, double h_before, bool keep) -> int {
 #pragma unroll
         for (int j = 0; j < E; ++j) { xb[j] = x[j]; pb[j] = p[j]; }
         double eps = ap.step_size;
-        auto diff_at = [&](double ee) -> double {
-            double lpn, ken;
-            leap_frog(ee, lpn, ken);
-            const double h_after = lpn - ken;
+        // one trial; save = this trial is (so far) the one the proposal would repeat
+        double t_lp = 0.0, t_ke = 0.0; bool t_ok = true;
+        auto trial = [&](double ee) -> double {
+            t_ok = leap_frog(ee, t_lp, t_ke);
+            return (t_lp - t_ke) - h_before;
+        };
+        auto save_trial = [&]() {
+#pragma unroll
+            for (int j = 0; j < E; ++j) { xk[j] = x[j]; pk[j] = p[j]; gk[j] = g[j]; }
+            lpk = t_lp; kek = t_ke; okk = t_ok;
+        };
+        auto restore = [&]() {
 #pragma unroll
             for (int j = 0; j < E; ++j) { x[j] = xb[j]; p[j] = pb[j]; }
-            return h_after - h_before;
         };
-        double diff = diff_at(eps);
+        double diff = trial(eps);
+        if (keep) save_trial();
+        restore();
         int n_steps = 0, exponent = 0;
         if (!isfinite(diff) || diff < lower) {
             for (int n = 1;; ++n) {
                 eps /= 2.0;
-                diff = diff_at(eps);
+                diff = trial(eps);
+                if (keep) save_trial();                       // shrinking: the last trial is the one
+                restore();
                 if (eps == 0.0) { err = ERR_AM_STEP; break; }
                 if (diff > lower) { n_steps = n; exponent = -n; break; }
             }
         } else if (diff > upper) {
             for (int n = 1;; ++n) {
                 eps *= 2.0;
-                diff = diff_at(eps);
-                if (!isfinite(diff) || diff < upper) { n_steps = n; exponent = n - 1; break; }
+                diff = trial(eps);
+                const bool stop = !isfinite(diff) || diff < upper;
+                if (keep && !stop) save_trial();              // growing: the last trial BEFORE the one that went too far
+                restore();
+                if (stop) { n_steps = n; exponent = n - 1; break; }
             }
         }
         steps_sum += 1 + n_steps; steps_n += 1;
@@ -561,11 +581,14 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         const double ua = r.rand(), ub = r.rand();
         const double lower = log(ua < ub ? ua : ub), upper = log(ua < ub ? ub : ua);
         AM_STAMP(2);
-        const int proposed = auto_step_size(lower, upper, init_joint);
+        const int proposed = auto_step_size(lower, upper, init_joint, true);
         if (err) break;
         AM_STAMP(3);
-        double lp_moved, ke_moved;
-        const bool moved_ok = leap_frog(ap.step_size * ldexp(1.0, proposed), lp_moved, ke_moved);
+        // leap_frog!(..., step_size * 2^proposed) from the start point == the trial the search kept
+#pragma unroll
+        for (int j = 0; j < E; ++j) { x[j] = xk[j]; p[j] = pk[j]; g[j] = gk[j]; }
+        const double lp_moved = lpk, ke_moved = kek;
+        const bool moved_ok = okk;
         AM_STAMP(4);
         if (ap.use_mh) {
 #pragma unroll
@@ -575,7 +598,7 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
 #pragma unroll
             for (int j = 0; j < E; ++j) g0[j] = g[j];
             const double h_rev = lp0 - (moved_ok ? ke_moved : kinetic());
-            const int reversed = auto_step_size(lower, upper, h_rev);
+            const int reversed = auto_step_size(lower, upper, h_rev, false);
             if (err) break;
             AM_STAMP(5);
             const bool passed = reversed == proposed;
