@@ -546,6 +546,19 @@ def test_automala_funnel_parity(P, N, d, rounds, seed):
         _check_am_round(P, pt, ref, rtol=1e-6)
 
 
+@pytest.mark.parametrize("path,N,d,rounds,seed", [("mvn", 4, 256, 4, 1), ("mvn", 3, 512, 3, 2), ("mvn", 3, 1024, 3, 1),
+                                                  ("funnel", 5, 64, 5, 3), ("funnel", 4, 256, 4, 1), ("funnel", 3, 300, 3, 2),
+                                                  ("funnel", 3, 512, 3, 1), ("funnel", 3, 700, 3, 2), ("funnel", 3, 1024, 3, 1)])
+def test_automala_every_register_layout_against_the_oracle(P, path, N, d, rounds, seed):
+    """Every instantiation of k_explore_automala: E = 1 .. 16 blocks of 64 coordinates per replica, with and without a ragged last
+    block (d = 64 E takes the mask-free instantiation), on both paths -- incl. d = 1024 (E = 16), the largest the Langevin kernels take.
+    The reductions differ by layout (one lockstep pass of eight packed chains at E <= 4 on the funnel, four at a time beyond), the
+    reuse of evaluations (start-point gradient carried, proposal = the search's kept trial) does not."""
+    pt, ref = _mk_am(P, N, d, rounds, path, seed)
+    for _ in range(rounds):
+        _check_am_round(P, pt, ref, rtol=1e-9 if path == "mvn" else 1e-6)
+
+
 def test_automala_stepping_stone_kat(P):
     """reference test/test_stepping_stone.jl:15-27 with AutoMALA(): |logZ error| < 0.2 at d=10, N=6, 12 rounds."""
     pt = P.pigeons(target=P.toy_mvn_target(10), explorer=P.AutoMALA(), n_chains=6, n_rounds=12, show_report=False)
