@@ -23,3 +23,9 @@ run("C3 funnel(128) N=1024 AutoMALA", P.Inputs(target=P.Funnel(128), reference=P
 run("funnel(32) N=1024 SliceSampler (full log potential per proposal)", P.Inputs(target=P.Funnel(32), reference=P.ScaledPrecisionNormalLogPotential(1/9., 32), n_chains=1024, explorer=P.SliceSampler(), record=rec, n_rounds=20, show_report=False), 16, 4)
 run("C4 shard: toy_mvn(4096) N=1024 SliceSampler", P.Inputs(target=P.toy_mvn_target(4096), n_chains=1024, explorer=P.SliceSampler(), record=rec, n_rounds=20, show_report=False), 8, 2)
 run("C5 shard: Ising 256x256 N=512 IsingMetropolis", P.Inputs(target=P.IsingLogPotential(1.0, 256), n_chains=512, record=rec, n_rounds=20, show_report=False), 4, 1)
+if os.environ.get("BC_LANGEVIN_LARGE", "1") != "0":
+    # the largest register layouts of the Langevin kernel (E = 8 / 16 blocks per replica; the funnel instantiation at E = 16 keeps part of its state in scratch)
+    run("toy_mvn(512) N=1024 AutoMALA", P.Inputs(target=P.toy_mvn_target(512), n_chains=1024, explorer=P.AutoMALA(), record=rec, n_rounds=20, show_report=False), 16, 4)
+    run("toy_mvn(1024) N=1024 AutoMALA", P.Inputs(target=P.toy_mvn_target(1024), n_chains=1024, explorer=P.AutoMALA(), record=rec, n_rounds=20, show_report=False), 16, 4)
+    run("funnel(512) N=1024 AutoMALA", P.Inputs(target=P.Funnel(512), reference=P.ScaledPrecisionNormalLogPotential(1/9., 512), n_chains=1024, explorer=P.AutoMALA(), record=rec, n_rounds=20, show_report=False), 16, 4)
+    run("funnel(1024) N=1024 AutoMALA", P.Inputs(target=P.Funnel(1024), reference=P.ScaledPrecisionNormalLogPotential(1/9., 1024), n_chains=1024, explorer=P.AutoMALA(), record=rec, n_rounds=20, show_report=False), 16, 4)
