@@ -28,7 +28,10 @@
 
 namespace pte {
 
-constexpr int NRM_CO = 512;                 // outputs per chunk (two groups of 256)
+#ifndef NRM_CHUNK
+#define NRM_CHUNK 512                       // measured at 1024 (round 3): 17 positions per lane in registers = 214 VGPRs, 2 waves per SIMD -- 2.08 against
+#endif                                      // 2.47 TB/s at N = 8192, d = 4096 (a lone wave gains 13 %: one event pass per 1024 outputs)
+constexpr int NRM_CO = NRM_CHUNK;           // outputs per chunk (groups of 256)
 constexpr int NRM_CP = NRM_CO + 64;         // stream positions evaluated per chunk
 constexpr int NRM_SLOTS = NRM_CP / 64;      // positions per lane
 constexpr int NRM_MAX_EV = 64;              // events resolved lane-parallel per chunk (more: the chunk is cut short)
