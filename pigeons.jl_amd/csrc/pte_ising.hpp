@@ -361,26 +361,36 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                         const int sh = p + lc;                                   // <= 48 + 12
                         unsigned wR4 = (unsigned)(mR4 >> sh), wA4 = (unsigned)(mA4 >> sh), wR8 = (unsigned)(mR8 >> sh), wA8 = (unsigned)(mA8 >> sh);
                         asm volatile("" : "+v"(wR4), "+v"(wA4), "+v"(wR8), "+v"(wA8));   // (keep the four 64-bit shifts here: hipcc sinks them below the per-site selects, 8 per pass)
-                        int dc = 0, accbits = 0;
-                        unsigned left = lb;
-                        unsigned ambu = 0;
+                        // What a site needs from its surroundings does not depend on the walk except through its NEW left neighbour: for
+                        // the quad's four sites at once (bit j = site j), from the nibbles of the word above, below, to the right (old
+                        // values) and of the spins themselves -- cnt = neighbours that are 1 = (U + D + R) + left, delta = (1 - 2 s) 2 (2 cnt - 4):
+                        //   a draw is needed iff  s ? cnt > 2 : cnt < 2,   delta == -4 iff  s ? cnt == 3 : cnt == 1
+                        // as boolean functions of (b1 b0 = U + D + R, s), once for left = 0 and once for left = 1; the walk then only
+                        // picks bits: 12 instead of 19 instructions per site.
+                        const int t0 = T0 + 4 * lk;
+                        const unsigned cur_r = (cur >> 1) | (rt31 << 31);        // right neighbours, site 31's from the next word (scalar)
+                        const unsigned U = (up >> t0) & 15u, D = (dn >> t0) & 15u, R = (cur_r >> t0) & 15u, S = (cur >> t0) & 15u;
+                        const unsigned b0 = U ^ D ^ R, b1 = (U & D) | (R & (U ^ D));
+                        const unsigned N0 = (S & b1 & b0) | (~S & ~b1),       I0 = (S & b1 & b0) | (~S & ~b1 & b0);
+                        const unsigned N1 = (S & b1) | (~S & ~b1 & ~b0),      I1 = (S & b1 & ~b0) | (~S & ~b1 & ~b0);
+                        const unsigned NN = (N0 & 15u) | ((N1 & 15u) << 4), II = (I0 & 15u) | ((I1 & 15u) << 4);   // bit j + 4 left
+                        const unsigned WR = (wR8 & 15u) | ((wR4 & 15u) << 4), WA = (wA8 & 15u) | ((wA4 & 15u) << 4);   // bit dc + 4 [delta == -4]
+                        const unsigned SN = ~S;
+                        int dc = 0;
+                        unsigned left = lb, ambu = 0, rejn = 0;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const int t = (T0 + 4 * lk + j) & 31;
-                            const unsigned sg = (cur >> t) & 1u;
-                            const unsigned rt = (t == 31) ? rt31 : ((cur >> ((t + 1) & 31)) & 1u);
-                            // delta = (1 - 2 sg) * 2 * (2 cnt - 4) with cnt = neighbours that are 1  ==  4 k - 8 with k = neighbours EQUAL
-                            // ... to the flipped spin's opposite, i.e. k = sg ? 4 - cnt : cnt: a draw is needed iff k < 2, delta == -4 iff k == 1
-                            const unsigned cnt = ((up >> t) & 1u) + ((dn >> t) & 1u) + left + rt;
-                            const unsigned kk = sg ? 4u - cnt : cnt;
-                            const bool need = kk < 2u;
-                            const unsigned mr = kk == 1u ? wR4 : wR8, ma = kk == 1u ? wA4 : wA8;
-                            const unsigned rej = need ? ((mr >> dc) & 1u) : 0u;
-                            ambu |= need ? ((ma >> dc) & 1u) : 0u;
-                            left = sg ^ rej ^ 1u;
-                            accbits |= (int)(rej ^ 1u) << j;
-                            dc += need ? 1 : 0;
+                            const unsigned shj = (left << 2) + (unsigned)j;
+                            const unsigned need = (NN >> shj) & 1u, is4 = (II >> shj) & 1u;
+                            const unsigned idx = (is4 << 2) + (unsigned)dc;
+                            const unsigned rej = need & (WR >> idx);             // (bit 0; the bits above are dropped where it is used)
+                            ambu |= need & (WA >> idx);
+                            left = ((SN >> j) ^ rej) & 1u;                       // the site's new spin: flipped unless rejected
+                            rejn |= (rej & 1u) << j;
+                            dc += (int)need;
                         }
+                        const int accbits = (int)(rejn ^ 15u);
+                        ambu &= 1u;
                         const bool amb = ambu != 0;
                         const int c_run = lc + dc;
                         // packed: bit 0 = ambiguous somewhere in the quad, bits 1-4 = accepts, bits 5.. = NEXT chase state 2 c + spin
