@@ -39,7 +39,7 @@ def case(kind, d, nf, nv, seed, rounds=5):
 
 bad = 0; n = 0
 for kind, (d, nf, nv), seed in itertools.product(["automala_mvn", "mala_mvn", "compose_mvn", "automala_funnel", "variational_funnel"],
-                                                 [(3, 6, 0), (40, 5, 4), (130, 4, 0), (300, 3, 3)], range(1, 5)):
+                                                 [(3, 6, 0), (40, 5, 4), (130, 4, 0), (300, 3, 3)] + ([(64, 5, 0), (128, 4, 2), (256, 3, 0), (512, 3, 2), (1024, 3, 0)] if os.environ.get('STRESS_WHOLE_BLOCKS', '1') != '0' else []), range(1, 1 + int(os.environ.get('STRESS_NSEEDS', '4')))):
     r = case(kind, d, nf, nv, seed)
     n += 1
     if r:
