@@ -47,7 +47,8 @@ constexpr int NRM_MAX_EV = 64;              // events resolved lane-parallel per
 // kernel is not bound by the LDS), so the dense layout stays.
 __device__ __forceinline__ constexpr int nrm_pad(int i) { return NRM_PAD ? i + (i >> 5) : i; }
 #ifndef NRM_OCC
-#define NRM_OCC 4                           // > 0: waves per SIMD the register allocation must allow (measured 3 / 4 / 5: 2.59 / 2.71 / 0.94 TB/s at N = 32768 -- 5 spills 64 VGPRs)
+#define NRM_OCC 5                           // > 0: waves per SIMD the register allocation must allow.  Positions in registers: 3 / 4 / 5 waves = 2.59 / 2.71 / 0.94 TB/s at
+                                            // N = 32768 (5 spilled 64 VGPRs); positions in LDS: 4 / 5 waves = 2.83 / 2.95 (95 VGPRs, 2 spilled; 6 does not fit)
 #endif
 #if NRM_OCC > 0
 #define NRM_ATTR __attribute__((amdgpu_waves_per_eu(NRM_OCC, NRM_OCC)))
@@ -56,6 +57,13 @@ __device__ __forceinline__ constexpr int nrm_pad(int i) { return NRM_PAD ? i + (
 #endif
 #ifndef NRM_FI_LDS
 #define NRM_FI_LDS 1
+#endif
+#ifndef NRM_EV_AFTER
+#define NRM_EV_AFTER 0
+#endif
+#ifndef NRM_POS_LDS
+#define NRM_POS_LDS 1                       // 1: the positions' values go to LDS as they are computed and are compacted IN PLACE (output k <= position k), not kept in
+                                            // registers: 105 instead of 143 VGPRs (the 128-register build spilled 15), which is what lets a fifth wave onto the SIMD
 #endif
 #ifndef NRM_WPB
 #define NRM_WPB 4                           // waves (replicas) per workgroup; they share the ziggurat tables (6 KB)
@@ -66,7 +74,7 @@ struct NormalsLds {                         // one per workgroup
 #if NRM_FI_LDS
     double fi[256];                         // wedge test of the event pass
 #endif
-    alignas(16) double out[NRM_WPB][NRM_CO];    // the chunk's values in OUTPUT order
+    alignas(16) double out[NRM_WPB][NRM_POS_LDS ? NRM_CP : NRM_CO];    // the chunk's values in OUTPUT order (NRM_POS_LDS: first by position, then compacted in place)
     unsigned long long del[NRM_WPB][NRM_SLOTS]; // bitmap of the consumed stream positions
     int ev[NRM_WPB][NRM_MAX_EV];
     double bs[NRM_WPB][64];
@@ -123,7 +131,10 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
         const uint64_t base = r.seed;
         uint64_t zc = base + (uint64_t)(lane + 1) * gamma;
         int n_ev = 0;                                       // uniform
-        double v[NRM_SLOTS];
+        double v[NRM_POS_LDS ? 1 : NRM_SLOTS];
+#if NRM_EV_AFTER
+        uint64_t mslow[NRM_SLOTS];                          // uniform: ballots of the non-fast positions, slot by slot
+#endif
         if (lane < NRM_SLOTS) L.del[wv][lane] = 0ull;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -143,15 +154,31 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
             // reference has +0.0: the division step below returns +0.0 for it (fma(+0.0, r, -0.0) = +0.0).
             const double mag = __longlong_as_double((long long)(rabs | 0x4330000000000000ULL)) - 4503599627370496.0;
             const double prod = mag * w;
-            v[j] = __longlong_as_double(__double_as_longlong(prod) ^ (long long)(raw << 63));
+            v[NRM_POS_LDS ? 0 : j] = __longlong_as_double(__double_as_longlong(prod) ^ (long long)(raw << 63));
+            if (NRM_POS_LDS) L.out[wv][64 * j + lane] = v[0];
             const bool slow = !(rabs < k);
             const uint64_t m = ballot64(slow);
+#if NRM_EV_AFTER
+            mslow[j] = m;                                   // (listed after the loop: no branch between the slots, so that the table reads of one overlap the arithmetic of the others)
+#else
             if (m) {                                        // uniform branch, 60 % of the slots
                 const int at = n_ev + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
                 if (slow && at < NRM_MAX_EV) L.ev[wv][at] = 64 * j + lane;
                 n_ev += __popcll(m);
             }
+#endif
         }
+#if NRM_EV_AFTER
+#pragma unroll
+        for (int j = 0; j < NRM_SLOTS; ++j) {
+            const uint64_t m = mslow[j];
+            if (m) {
+                const int at = n_ev + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (__builtin_amdgcn_inverse_ballot_w64(m) && at < NRM_MAX_EV) L.ev[wv][at] = 64 * j + lane;
+                n_ev += __popcll(m);
+            }
+        }
+#endif
         int pos_limit = NRM_CP;                             // positions below this one are resolved (events beyond the list are not)
         if (n_ev > NRM_MAX_EV) { n_ev = NRM_MAX_EV; }
         __builtin_amdgcn_wave_barrier();
@@ -266,7 +293,8 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
                 const unsigned long long dj = L.del[wv][j];
                 const uint64_t keep = ~(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(dj >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)dj));
                 const int at = cum + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(keep >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)keep, 0u));
-                if (__builtin_amdgcn_inverse_ballot_w64(keep) && at < NRM_CO) L.out[wv][at] = v[j];
+                const double vj = NRM_POS_LDS ? L.out[wv][64 * j + lane] : v[NRM_POS_LDS ? 0 : j];   // (in place: slot j's outputs land at or below its own positions, all read by now)
+                if (__builtin_amdgcn_inverse_ballot_w64(keep) && at < NRM_CO) L.out[wv][at] = vj;
                 cum += __popcll(keep);
             }
         }
