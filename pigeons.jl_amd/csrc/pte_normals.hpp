@@ -58,6 +58,9 @@ __device__ __forceinline__ constexpr int nrm_pad(int i) { return NRM_PAD ? i + (
 #ifndef NRM_FI_LDS
 #define NRM_FI_LDS 1
 #endif
+#ifndef NRM_SPLIT_TABLE_READS
+#define NRM_SPLIT_TABLE_READS 1
+#endif
 #ifndef NRM_EV_AFTER
 #define NRM_EV_AFTER 0
 #endif
@@ -70,7 +73,10 @@ __device__ __forceinline__ constexpr int nrm_pad(int i) { return NRM_PAD ? i + (
 #endif
 struct NormalsLds {                         // one per workgroup
     double wi[256];
-    unsigned long long ki[256];             // (directly behind wi: one ds_read2st64_b64 fetches both)
+#if NRM_SPLIT_TABLE_READS
+    double pad_[1];                         // (ki NOT at a multiple of 512 B behind wi: two ds_read_b64 -- 2 LDS cycles each, 64 banks -- instead of one ds_read2st64_b64: 8 cycles, 32 banks)
+#endif
+    unsigned long long ki[256];
 #if NRM_FI_LDS
     double fi[256];                         // wedge test of the event pass
 #endif
