@@ -285,6 +285,9 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
     const uint64_t gamma = e.rng[2 * slot + 1];
     const double lp_before = lp_before_explore(e, c, slot);
     const bool refresh = is_ref_chain(e, c);
+#ifdef PTE_PROFILE_WAVES
+    const uint64_t wave_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     for (int wd = lane; wd < NW; wd += 64) {
         unsigned v = 0;
@@ -468,6 +471,13 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
     for (int wd = lane; wd < NW; wd += 64) wrow[wd] = words[wd];
     if (lane == 0) { e.suff[slot] = (double)spp; e.rng[2 * slot] = seed; }
     record_after_explore(e, cl, c, slot, lane, lp_before, (double)spp, 0.0);
+#ifdef PTE_PROFILE_WAVES                   // debug builds only: per-wave start / end on the 100 MHz clock, placement
+    if (lane == 0) {
+        double *o = e.on_m2 + 2 * (e.d + 1) + 4 * cl;
+        o[0] = (double)wave_t0; o[1] = (double)__builtin_amdgcn_s_memrealtime();
+        o[2] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4); o[3] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+#endif
 }
 
 }  // namespace pte
