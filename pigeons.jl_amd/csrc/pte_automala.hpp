@@ -273,7 +273,14 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         for (int i = lane; i < 256; i += 64) { s_wi[i] = ZIG_WI[i]; s_ki[i] = ZIG_KI[i]; s_fi[i] = ZIG_FI[i]; }
         __syncthreads();
     }
-    const int64_t cl = blockIdx.x;
+    // Neighbouring chains do similar work (the slow ones -- most step-size trials -- sit next to the reference) and neighbouring
+    // workgroups share a CU, whose FP64 pipe the four SIMDs contend for: a stride permutation of workgroup -> chain spreads the slow
+    // chains over the chip.  Measured at C3, interleaved on one box: 0.231 -> 0.227 ms / scan (the same permutation makes the slice
+    // kernel 2.5 % SLOWER -- it is not applied there).
+#ifndef PTE_AM_PERMUTE
+#define PTE_AM_PERMUTE 97                  // (a prime: coprime to every chain count it does not divide)
+#endif
+    const int64_t cl = (e.K % PTE_AM_PERMUTE) ? ((int64_t)blockIdx.x * PTE_AM_PERMUTE) % e.K : (int64_t)blockIdx.x;
     if (cl >= e.K) return;
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];
