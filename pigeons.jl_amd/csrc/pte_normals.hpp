@@ -7,14 +7,15 @@
 // ziggurat draws leave the fast path and consume extra draws (wedge test: one uniform, then either the same value or a fresh
 // attempt; tail: a loop of pairs).  What the old kernel did per 64 draws -- resolve the first such event sequentially, re-draw
 // the lanes behind it, repeat (54 % of the blocks) -- becomes a STREAM COMPACTION over a chunk of 512 outputs:
-//   1. every lane evaluates 9 stream positions (576 = 512 + 64 slack) and keeps the values in registers: the value as if the
+//   1. every lane evaluates 9 stream positions (576 = 512 + 64 slack) and writes each value to LDS at its position (NRM_POS_LDS; the
+//      first version kept them in registers: 143 VGPRs, one wave per SIMD less): the value as if the
 //      fast path applied (the wedge's accepted value is the same expression); the non-fast positions go to an event list;
 //   2. ONE divergent pass: event lane e re-derives its draw and the next one and runs the wedge test (exp), or the tail's loop;
 //   3. lane-parallel over the (sorted) events: which of them start an attempt (an event whose position was consumed by the live
 //      event before it does not), a prefix sum of the consumed draws, and a bitmap of the CONSUMED positions (an accepted wedge
 //      consumes the uniform behind it; a rejected one its own draw and the uniform; a tail its trials);
 //   4. every position that was not consumed is an output: its index is a running count (ballot prefix, v_mbcnt) -- the values
-//      are written to LDS in OUTPUT order; a tail writes its value over the slot of its position;
+//      are moved to OUTPUT order IN PLACE (output k never lies above position k; a slot's 64 values are read before its outputs are written); a tail writes its value over the slot of its position;
 //   5. outputs are read back FOUR CONSECUTIVE PER LANE (two 16-byte LDS reads, 32-byte stores), divided by sd, squared and
 //      summed: the first two levels of the fixed tree are in-lane adds, four DPP steps finish four 64-leaf blocks at once (the
 //      old layout, one leaf per lane, paid six DPP steps per block at 4.2 SIMD cycles per v_mov_b32_dpp).
