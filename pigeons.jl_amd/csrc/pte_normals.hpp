@@ -30,63 +30,40 @@
 namespace pte {
 
 #ifndef NRM_CHUNK
-#define NRM_CHUNK 512                       // measured at 1024 (round 3): 17 positions per lane in registers = 214 VGPRs, 2 waves per SIMD -- 2.08 against
-#endif                                      // 2.47 TB/s at N = 8192, d = 4096 (a lone wave gains 13 %: one event pass per 1024 outputs)
+#define NRM_CHUNK 512                       // measured at 1024 (round 3): LDS then allows 3 waves per SIMD -- the same within 2 %
+#endif
 constexpr int NRM_CO = NRM_CHUNK;           // outputs per chunk (groups of 256)
 constexpr int NRM_CP = NRM_CO + 64;         // stream positions evaluated per chunk
 constexpr int NRM_SLOTS = NRM_CP / 64;      // positions per lane
-constexpr int NRM_MAX_EV = 64;              // events resolved lane-parallel per chunk (more: the chunk is cut short)
+#ifndef NRM_MAX_EV_
+#define NRM_MAX_EV_ 32                       // (test builds force the cut-short / fallback paths with a small value)
+#endif
+constexpr int NRM_MAX_EV = NRM_MAX_EV_;              // events resolved lane-parallel per chunk, two lanes each (more: the chunk is cut short)
+constexpr int NRM_EV_CAP = 128;             // entries of the event list (the list itself never overflows: the index is clamped)
 
-#ifndef NRM_PAD
-#define NRM_PAD 0
-#endif
-#ifndef NRM_UNROLL
-#define NRM_UNROLL 9
-#endif
-// val[] is read back four consecutive outputs per lane (a stride of 4 doubles across the lanes: 4-way bank conflicts on a dense
-// array).  NRM_PAD = 1 puts element i at i + (i >> 5), which spreads the strided reads over all banks -- measured: no gain (the
-// kernel is not bound by the LDS), so the dense layout stays.
-__device__ __forceinline__ constexpr int nrm_pad(int i) { return NRM_PAD ? i + (i >> 5) : i; }
 #ifndef NRM_OCC
-#define NRM_OCC 5                           // > 0: waves per SIMD the register allocation must allow.  Positions in registers: 3 / 4 / 5 waves = 2.59 / 2.71 / 0.94 TB/s at
-                                            // N = 32768 (5 spilled 64 VGPRs); positions in LDS: 4 / 5 waves = 2.83 / 2.95 (95 VGPRs, 2 spilled; 6 does not fit)
+#define NRM_OCC 5                           // > 0: waves per SIMD the register allocation must allow (4 / 5 waves = 2.83 / 2.95 TB/s at N = 32768 in round 3; 6 does not fit the LDS)
 #endif
 #if NRM_OCC > 0
 #define NRM_ATTR __attribute__((amdgpu_waves_per_eu(NRM_OCC, NRM_OCC)))
 #else
 #define NRM_ATTR
 #endif
-#ifndef NRM_FI_LDS
-#define NRM_FI_LDS 1
-#endif
-#ifndef NRM_SPLIT_TABLE_READS
-#define NRM_SPLIT_TABLE_READS 1
-#endif
-#ifndef NRM_PIPE
-#define NRM_PIPE 0                          // 1: table reads of slot j + 1 issued before slot j's branch -- measured +0.7 % at N = 32768, nothing at N = 8192 (tools/ab_toy.sh): off
-#endif
-#ifndef NRM_EV_AFTER
-#define NRM_EV_AFTER 0
-#endif
-#ifndef NRM_POS_LDS
-#define NRM_POS_LDS 1                       // 1: the positions' values go to LDS as they are computed and are compacted IN PLACE (output k <= position k), not kept in
-                                            // registers: 105 instead of 143 VGPRs (the 128-register build spilled 15), which is what lets a fifth wave onto the SIMD
-#endif
 #ifndef NRM_WPB
-#define NRM_WPB 4                           // waves (replicas) per workgroup; they share the ziggurat tables (6 KB)
+#define NRM_WPB 4                           // waves (replicas) per workgroup; they share the ziggurat tables (10 KB)
 #endif
+// Table entry of the fast path, indexed by the low NINE bits of the draw (bit 0 = sign, bits 1..8 = ziggurat layer), one ds_read_b128:
+//   w = +-wi[layer] / 2  -- the draw's 52 bits with bit 0 cleared are 2 rabs, and (2 rabs)(w / 2) is the same product as rabs w bit for
+//                           bit (scaling by 2 is exact); the sign rides on the table instead of being xor-ed into the product;
+//   k = 2 ki[layer] | 0x433 << 52  -- "rabs < ki" as ONE unsigned compare of the bit pattern of 2^52 + 2 rabs, which the conversion
+//                           builds anyway (same register pair: no copy).
+// Per 64 positions this drops a 64-bit shift, the 52-bit mask, a register move and the two sign instructions (29 -> 25 VALU).
+struct alignas(16) NrmWK { double w; unsigned long long k; };
 struct NormalsLds {                         // one per workgroup
-    double wi[256];
-#if NRM_SPLIT_TABLE_READS
-    double pad_[1];                         // (ki NOT at a multiple of 512 B behind wi: two ds_read_b64 -- 2 LDS cycles each, 64 banks -- instead of one ds_read2st64_b64: 8 cycles, 32 banks)
-#endif
-    unsigned long long ki[256];
-#if NRM_FI_LDS
+    NrmWK wk[512];
     double fi[256];                         // wedge test of the event pass
-#endif
-    alignas(16) double out[NRM_WPB][NRM_POS_LDS ? NRM_CP : NRM_CO];    // the chunk's values in OUTPUT order (NRM_POS_LDS: first by position, then compacted in place)
-    unsigned long long del[NRM_WPB][NRM_SLOTS]; // bitmap of the consumed stream positions
-    int ev[NRM_WPB][NRM_MAX_EV];
+    alignas(16) double out[NRM_WPB][NRM_CP];   // the chunk's values by stream position, then compacted in place to OUTPUT order
+    unsigned short ev[NRM_WPB][NRM_EV_CAP]; // positions that left the fast path, in stream order
     double bs[NRM_WPB][64];
 #ifdef NRM_PROF                             // tools/ubench/normals_prof.hip only: cycles per phase
     unsigned long long prof[8];
@@ -94,11 +71,11 @@ struct NormalsLds {                         // one per workgroup
 };
 
 __device__ __forceinline__ void normals_lds_init(NormalsLds &L, int lane) {
-    for (int i = NRM_WPB > 1 ? (int)threadIdx.x : lane; i < 256; i += 64 * NRM_WPB) {
-        L.wi[i] = ZIG_WI[i]; L.ki[i] = ZIG_KI[i];
-#if NRM_FI_LDS
-        L.fi[i] = ZIG_FI[i];
-#endif
+    for (int i = NRM_WPB > 1 ? (int)threadIdx.x : lane; i < 512; i += 64 * NRM_WPB) {
+        const double w = 0.5 * ZIG_WI[i >> 1];
+        L.wk[i].w = (i & 1) ? -w : w;
+        L.wk[i].k = (ZIG_KI[i >> 1] << 1) | 0x4330000000000000ull;
+        if (i < 256) L.fi[i] = ZIG_FI[i];
     }
     __syncthreads();
 }
@@ -125,13 +102,15 @@ __device__ __forceinline__ double dpp_row_step(double v, int which) {
 }
 
 // Fills xrow[0 .. d) and returns lane b = sum of squares of block b (64 leaves), to be fed to upper_tree_root<NLU>.
-// `r` is advanced exactly as d sequential randn(rng) calls would advance it.  One wave per workgroup.
+// `r` is advanced exactly as d sequential randn(rng) calls would advance it.  One wave per replica.
 __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *xrow, int64_t d, double sd, int lane) {
     const int wv = NRM_WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;      // wave-uniform (kept in an SGPR)
     const double rinv = 1.0 / sd;
     const bool markstein = (__double_as_longlong(sd) & 0x000fffffffffffffLL) != 0x000fffffffffffffLL;      // uniform
     const uint64_t gamma = r.gamma;
     const uint64_t g64 = gamma << 6;
+    const double NRM_DEAD = __longlong_as_double(0x7ff8dead00000000LL);     // a consumed stream position (no fast-path value is a NaN)
+    double *const out = L.out[wv];
     int64_t done = 0;                                       // outputs written so far (a multiple of 256 until the last group)
     while (done < d) {
         // ---- 1. positions base + 1 .. base + NRM_CP of the stream
@@ -141,119 +120,81 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
         const uint64_t base = r.seed;
         uint64_t zc = base + (uint64_t)(lane + 1) * gamma;
         int n_ev = 0;                                       // uniform
-        double v[NRM_POS_LDS ? 1 : NRM_SLOTS];
-#if NRM_EV_AFTER
-        uint64_t mslow[NRM_SLOTS];                          // uniform: ballots of the non-fast positions, slot by slot
-#endif
-        if (lane < NRM_SLOTS) L.del[wv][lane] = 0ull;
-        __builtin_amdgcn_wave_barrier();
-#if NRM_PIPE                                 // the table reads of slot j + 1 are issued before slot j is finished (and before its branch)
-        uint64_t raw_n = mix64(zc) & MASK52;
-        zc += g64;
-        double w_n = L.wi[(int)((raw_n >> 1) & 0xFF)];
-        unsigned long long k_n = L.ki[(int)((raw_n >> 1) & 0xFF)];
-#endif
 #pragma unroll
         for (int j = 0; j < NRM_SLOTS; ++j) {
-#if NRM_PIPE
-            const uint64_t raw = raw_n;
-            const double w = w_n;
-            const unsigned long long k = k_n;
-            const uint64_t rabs = raw >> 1;
-            if (j + 1 < NRM_SLOTS) {
-                raw_n = mix64(zc) & MASK52;
-                zc += g64;
-                w_n = L.wi[(int)((raw_n >> 1) & 0xFF)];
-                k_n = L.ki[(int)((raw_n >> 1) & 0xFF)];
-            }
-#else
 #ifdef NRM_MEASURE_NO_MIX          // measurement builds only (wrong samples): what the SplitMix64 finaliser costs
-            const uint64_t raw = (zc ^ (zc >> 29)) & MASK52;
+            const uint64_t raw = zc ^ (zc >> 29);
 #else
-            const uint64_t raw = mix64(zc) & MASK52;
+            const uint64_t raw = mix64(zc);
 #endif
             zc += g64;
-            const uint64_t rabs = raw >> 1;
-            const int idx = (int)(rabs & 0xFF);
-            const double w = L.wi[idx];
-            const unsigned long long k = L.ki[idx];
-#endif
-            // (double)(u & 1 ? -rabs : rabs) * wi[idx]: rabs < 2^51 goes exactly into the significand of 2^52 + rabs; the sign is
-            // applied to the product (round-to-nearest is symmetric).  rabs = 0 with the sign bit set would give -0.0 where the
-            // reference has +0.0: the division step below returns +0.0 for it (fma(+0.0, r, -0.0) = +0.0).
-            const double mag = __longlong_as_double((long long)(rabs | 0x4330000000000000ULL)) - 4503599627370496.0;
-            const double prod = mag * w;
-            v[NRM_POS_LDS ? 0 : j] = __longlong_as_double(__double_as_longlong(prod) ^ (long long)(raw << 63));
-            if (NRM_POS_LDS) L.out[wv][64 * j + lane] = v[0];
-            const bool slow = !(rabs < k);
+            const uint32_t lo = (uint32_t)raw, hi = (uint32_t)(raw >> 32);
+            const NrmWK t = L.wk[lo & 0x1FFu];
+            // 2^52 + (2 rabs + sign) as a bit pattern; with bit 0 cleared and 2^52 subtracted: 2 rabs, exactly
+            const uint64_t mb = ((uint64_t)((hi & 0x000FFFFFu) | 0x43300000u) << 32) | (lo & ~1u);
+            // rabs = 0 with the sign bit set gives -0.0 where the reference has +0.0: the division step below returns +0.0 for it
+            // (fma(+0.0, r, -0.0) = +0.0).
+            out[64 * j + lane] = (__longlong_as_double((long long)mb) - 4503599627370496.0) * t.w;
+            const bool slow = !(mb < t.k);                  // 2 rabs < 2 ki, on the bit patterns
             const uint64_t m = ballot64(slow);
-#if NRM_EV_AFTER
-            mslow[j] = m;                                   // (listed after the loop: no branch between the slots, so that the table reads of one overlap the arithmetic of the others)
-#else
             if (m) {                                        // uniform branch, 60 % of the slots
-                const int at = n_ev + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (slow && at < NRM_MAX_EV) L.ev[wv][at] = 64 * j + lane;
-                n_ev += __popcll(m);
-            }
-#endif
-        }
-#if NRM_EV_AFTER
-#pragma unroll
-        for (int j = 0; j < NRM_SLOTS; ++j) {
-            const uint64_t m = mslow[j];
-            if (m) {
-                const int at = n_ev + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (__builtin_amdgcn_inverse_ballot_w64(m) && at < NRM_MAX_EV) L.ev[wv][at] = 64 * j + lane;
+                const int at = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)n_ev));
+                if (slow) L.ev[wv][min(at, NRM_EV_CAP - 1)] = (unsigned short)(64 * j + lane);
                 n_ev += __popcll(m);
             }
         }
-#endif
         int pos_limit = NRM_CP;                             // positions below this one are resolved (events beyond the list are not)
-        if (n_ev > NRM_MAX_EV) { n_ev = NRM_MAX_EV; }
         __builtin_amdgcn_wave_barrier();
-        if (n_ev == NRM_MAX_EV) pos_limit = L.ev[wv][NRM_MAX_EV - 1] + 1;  // (essentially never: 9 events expected; later positions may hide unlisted events)
+        if (n_ev >= NRM_MAX_EV) { n_ev = NRM_MAX_EV; pos_limit = L.ev[wv][NRM_MAX_EV - 1] + 1; }  // (essentially never: 9 events expected; later positions may hide unlisted events)
 #ifdef NRM_PROF
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long pt1 = __builtin_readcyclecounter();
 #endif
-        // ---- 2. one divergent pass over the events: lane e < n_ev resolves event e
+        // ---- 2. one divergent pass over the events: lanes 2e and 2e + 1 resolve event e < n_ev together -- the wave pays per instruction
+        // ISSUED, not per lane, so the event's own draw and the uniform behind it are ONE SplitMix64 evaluation (exchanged inside the
+        // pair by DPP), and a tail's two logarithms per trial are one (a fifth of the kernel's time went here with one lane per event)
         //      kind 1: wedge accepted (the output takes the value at its position, one uniform consumed)
         //      kind 2: wedge rejected (draw + uniform consumed, the output restarts behind them)
         //      kind 3: tail (the output is +-(ZIG_NOR_R + xx), two draws per trial consumed)
-        const bool is_ev = lane < n_ev;
+        const int role = lane & 1;
+        const bool in_pass = (lane >> 1) < n_ev;
+        const bool is_ev = in_pass && role == 0;            // the even lane of a pair carries the event from here on
         int e_pos = 0x3fffffff, e_kind = 0, e_delta = 0;    // e_delta: extra stream positions the event consumes
         double e_tail = 0.0;
 #ifdef NRM_MEASURE_NO_EVENTS       // measurement builds only (wrong samples): every event taken as an accepted wedge, no exp
-        if (is_ev) { e_pos = L.ev[wv][lane]; e_kind = 1; e_delta = 1; }
+        if (in_pass) { e_pos = L.ev[wv][lane >> 1]; e_kind = 1; e_delta = 1; }
         if (false) {
 #else
-        if (is_ev) {
+        if (in_pass) {
 #endif
-            e_pos = L.ev[wv][lane];
-            const uint64_t z = base + (uint64_t)(e_pos + 1) * gamma;
-            const uint64_t raw = mix64(z) & MASK52;
-            const int64_t rabs = (int64_t)(raw >> 1);
-            const int idx = (int)(rabs & 0xFF);
+            e_pos = L.ev[wv][lane >> 1];
+            const double x = out[e_pos];                    // the value the fast path would have returned: (+-rabs) wi[idx], the wedge's candidate
+            const uint64_t zr = base + (uint64_t)(e_pos + 1 + role) * gamma;      // even lane: the event's own draw, odd lane: the draw behind it
+            const uint64_t mine = mix64(zr);
+            const uint64_t theirs = ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(mine >> 32), 0xB1, 0xF, 0xF, true) << 32)
+                                    | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)mine, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+            const uint64_t raw = role ? theirs : mine, nxt = role ? mine : theirs;     // both lanes of the pair hold both draws
+            const int idx = (int)((raw >> 1) & 0xFF);
             if (idx == 0) {
-                // tail of the normal ziggurat (Random/src/normal.jl randn_unlikely, idx == 0), exactly, at this stream position
-                SeqRng t{z, gamma};
+                // tail of the normal ziggurat (Random/src/normal.jl randn_unlikely, idx == 0), exactly, at this stream position: trial k
+                // takes the draws 2k - 1 (-> xx) and 2k (-> yy) behind the event; the even lane evaluates the first, the odd lane the second
+                uint64_t zt = zr + gamma;
                 int pairs = 0;
                 double xx, yy;
                 do {
-                    xx = ZIG_NOR_INV_R * zig_tail_neglog(t.rand());
-                    yy = zig_tail_neglog(t.rand());
+                    const double v = zig_tail_neglog(u52_to_unit(mix64(zt)));
+                    zt += gamma + gamma;
+                    const double pv = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, true),
+                                                       __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, true));
+                    xx = ZIG_NOR_INV_R * (role ? pv : v);
+                    yy = role ? v : pv;
                     pairs += 1;
-                } while (!(yy + yy > xx * xx) && pairs < 4096);
+                } while (!(yy + yy > xx * xx) && pairs < NRM_CP);         // (a tail that runs past the chunk is cut by pos_limit and redone by the next chunk)
                 e_kind = 3; e_delta = 2 * pairs;
-                e_tail = ((rabs >> 8) & 1) ? (-ZIG_NOR_R - xx) : (ZIG_NOR_R + xx);
+                e_tail = ((raw >> 9) & 1) ? (-ZIG_NOR_R - xx) : (ZIG_NOR_R + xx);
             } else {
-                const double x = (double)((raw & 1) ? -rabs : rabs) * L.wi[idx];
-                const double u1 = u52_to_unit(mix64(z + gamma));
-#if NRM_FI_LDS
+                const double u1 = u52_to_unit(nxt);
                 const double f1 = L.fi[idx - 1], f0 = L.fi[idx];
-#else
-                const double f1 = ZIG_FI[idx - 1], f0 = ZIG_FI[idx];
-#endif
                 // wedge test  y < exp(-x^2 / 2)  (Random/src/normal.jl randn_unlikely).  The double-precision exp is a chain of ~60
                 // dependent FP64 instructions that a handful of lanes execute while the rest of the wave waits -- a fifth of the whole
                 // kernel's time when it ran for every chunk.  Decide with the hardware's single-precision exp2 instead and keep the
@@ -276,19 +217,19 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
         // ---- 3. which events start an attempt (the events are sorted by position): an event does NOT iff the live event before it
         // consumed its position -- a wedge consumes the position right behind it, a tail the 2 x trials behind it
         const int e_cons = (e_kind == 3) ? e_delta : 1;
-        const int prev_end = __shfl_up(e_pos + e_cons, 1, 64);
-        const bool covered = is_ev && lane > 0 && e_pos <= prev_end;
+        const int prev_end = __shfl_up(e_pos + e_cons, 2, 64);       // (the event before this one sits two lanes down)
+        const bool covered = is_ev && lane > 1 && e_pos <= prev_end;
         bool live = is_ev;
         if (ballot64(covered) != 0ull) {
             // runs of adjacent events (13 % of the chunks have a pair): alternate along the run.  Three Jacobi steps settle runs of up
             // to four; anything longer -- or a tail covering more than its neighbour -- is settled sequentially
-            for (int it = 0; it < 3; ++it) { const bool pl = __shfl_up((int)live, 1, 64) != 0; live = is_ev && !(covered && pl); }
-            const bool pl = __shfl_up((int)live, 1, 64) != 0;
-            const int prev2_end = __shfl_up(e_pos + e_cons, 2, 64);
-            const bool bad = (live != (is_ev && !(covered && pl))) || (is_ev && lane > 1 && e_pos <= prev2_end);
+            for (int it = 0; it < 3; ++it) { const bool pl = __shfl_up((int)live, 2, 64) != 0; live = is_ev && !(covered && pl); }
+            const bool pl = __shfl_up((int)live, 2, 64) != 0;
+            const int prev2_end = __shfl_up(e_pos + e_cons, 4, 64);
+            const bool bad = (live != (is_ev && !(covered && pl))) || (is_ev && lane > 3 && e_pos <= prev2_end);
             if (ballot64(bad) != 0ull) {
                 uint64_t lm = 0ull; int cend = -1;
-                for (int j = 0; j < n_ev; ++j) {
+                for (int j = 0; j < 2 * n_ev; j += 2) {
                     const int p = __builtin_amdgcn_readlane(e_pos, j);
                     if (p <= cend) continue;
                     lm |= 1ull << j;
@@ -305,30 +246,28 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
         const int e_incl = wave_iscan_i32(e_d);             // draws consumed by the events up to and including this one
         const int e_kout = e_pos - (e_incl - e_d);          // the output the attempt belongs to
         if (live) {
-            // consumed positions: accepted wedge p + 1; rejected wedge p, p + 1; tail p + 1 .. p + e_delta
+            // consumed positions: accepted wedge p + 1; rejected wedge p, p + 1; tail p + 1 .. p + e_delta (its own slot takes the tail's value)
             const int first = e_pos + ((e_kind == 2) ? 0 : 1), last = min(e_pos + ((e_kind == 3) ? e_delta : 1), NRM_CP - 1);
-            for (int q = first; q <= last; ++q) atomicOr(&L.del[wv][q >> 6], 1ull << (q & 63));
+            for (int q = first; q <= last; ++q) out[q] = NRM_DEAD;
+            if (e_kind == 3) out[e_pos] = e_tail;
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- 4. compaction: the positions that were not consumed, in order, are the outputs
-        // (A vector-only form -- the bitmap word as a broadcast, v_bcnt against the lane's own lanes-below mask, consumed positions
-        // stored into dump slots, no readfirstlane and no EXEC mask -- makes a lone wave 16 % faster per chunk and the kernel at
-        // full occupancy 17 % SLOWER (0.127 against 0.108 ms at N = 8192): with four waves per SIMD the trips to the scalar side
-        // overlap, the extra vector instructions do not.  Measured in round 3 and dropped.)
+        // ---- 4. compaction in place: the positions that were not consumed, in order, are the outputs.  A slot's keep mask is the
+        // compare of its own values (ordered <=> not NRM_DEAD) -- straight into a scalar pair, no bitmap to build, clear or read back.
+        // Output k never lies above position k and a slot's 64 values are read before its outputs are written.
+        // (A vector-only form -- v_bcnt against the lane's own lanes-below mask, consumed positions stored into dump slots, no EXEC
+        // mask -- makes a lone wave 16 % faster per chunk and the kernel at full occupancy 17 % SLOWER: measured in round 3 and dropped.)
         {
             int cum = 0;                                    // uniform: outputs before this slot
 #pragma unroll
             for (int j = 0; j < NRM_SLOTS; ++j) {
-                const unsigned long long dj = L.del[wv][j];
-                const uint64_t keep = ~(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(dj >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)dj));
-                const int at = cum + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(keep >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)keep, 0u));
-                const double vj = NRM_POS_LDS ? L.out[wv][64 * j + lane] : v[NRM_POS_LDS ? 0 : j];   // (in place: slot j's outputs land at or below its own positions, all read by now)
-                if (__builtin_amdgcn_inverse_ballot_w64(keep) && at < NRM_CO) L.out[wv][at] = vj;
+                const double vj = out[64 * j + lane];
+                const uint64_t keep = ballot64(vj == vj);
+                const int at = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(keep >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)keep, (unsigned)cum));
+                if (vj == vj) out[at] = vj;
                 cum += __popcll(keep);
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        if (live && e_kind == 3 && e_kout < NRM_CO) L.out[wv][e_kout] = e_tail;       // (its position holds the fast-path expression)
         __builtin_amdgcn_wave_barrier();
 #ifdef NRM_PROF
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -337,13 +276,53 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
         // ---- 5. groups of 256 outputs: divide, store, tree
         int emitted = 0, shift_emitted = 0;
         const int want = (int)min((int64_t)NRM_CO, d - done);
+        // draws consumed by the attempts of the outputs below `gend` (uniform): the live events are sorted by output, so it is the
+        // running total at the last of them below gend
+        auto consumed_below = [&](int gend) -> int {
+            const uint64_t below = ballot64(live && e_kout < gend);
+            return below ? __builtin_amdgcn_readlane(e_incl, 63 - (int)__builtin_clzll(below)) : 0;
+        };
+        const int shift_all = consumed_below(NRM_CO);
+        if (want == NRM_CO && markstein && NRM_CO - 1 + shift_all < pos_limit) {
+            // the whole chunk (all but the last chunk of a row, and every position it takes is resolved): straight-line code, the
+            // groups' dependent chains (Markstein steps, DPP tree levels) issued level by level
+            constexpr int NG = NRM_CO / 256;
+            double q[NG][4];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const double2 a01 = *reinterpret_cast<const double2 *>(&out[256 * g + 4 * lane]), a23 = *reinterpret_cast<const double2 *>(&out[256 * g + 4 * lane + 2]);
+                q[g][0] = a01.x; q[g][1] = a01.y; q[g][2] = a23.x; q[g][3] = a23.y;
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const double a = q[g][i], t = a * rinv; q[g][i] = __builtin_fma(__builtin_fma(-t, sd, a), rinv, t); }
+            double sq[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+#ifndef NRM_NO_STORE
+                double2 *dst = reinterpret_cast<double2 *>(xrow + done + 256 * g + 4 * lane);
+                dst[0] = make_double2(q[g][0], q[g][1]); dst[1] = make_double2(q[g][2], q[g][3]);
+#endif
+                sq[g] = (q[g][0] * q[g][0] + q[g][1] * q[g][1]) + (q[g][2] * q[g][2] + q[g][3] * q[g][3]);
+            }
+#pragma unroll
+            for (int lv = 0; lv < 4; ++lv)
+#pragma unroll
+                for (int g = 0; g < NG; ++g) sq[g] = dpp_row_step(sq[g], lv);
+            // every lane of a row holds the row's (= one block's) sum: lane 16 r + g writes block 4 g + r of the chunk
+            double sel = sq[0];
+#pragma unroll
+            for (int g = 1; g < NG; ++g) sel = ((lane & 15) == g) ? sq[g] : sel;
+            if ((lane & 15) < NG) L.bs[wv][(int)(done >> 6) + 4 * (lane & 15) + (lane >> 4)] = sel;
+            emitted = NRM_CO; shift_emitted = shift_all;
+        } else
         for (int g0 = 0; g0 < want; g0 += 256) {
             const int gend = min(g0 + 256, want);
             const int k0 = g0 + 4 * lane;                   // this lane's outputs k0 .. k0 + 3 (relative to the chunk)
-            // draws consumed by the attempts of the outputs below gend (uniform); every position the group takes must be resolved
-            const int shift = __builtin_amdgcn_readlane(wave_iscan_i32((is_ev && e_kout < gend) ? e_d : 0), 63);
-            if (gend - 1 + shift >= pos_limit) break;
-            const double2 a01 = *reinterpret_cast<const double2 *>(&L.out[wv][k0]), a23 = *reinterpret_cast<const double2 *>(&L.out[wv][k0 + 2]);
+            const int shift = consumed_below(gend);
+            if (gend - 1 + shift >= pos_limit) break;        // every position the group takes must be resolved
+            const double2 a01 = *reinterpret_cast<const double2 *>(&out[k0]), a23 = *reinterpret_cast<const double2 *>(&out[k0 + 2]);
             const double a0 = a01.x, a1 = a01.y, a2 = a23.x, a3 = a23.y;
             double q0, q1, q2, q3;
             if (markstein) {
