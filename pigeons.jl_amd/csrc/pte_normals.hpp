@@ -58,6 +58,7 @@ constexpr int NRM_EV_CAP = 128;             // entries of the event list (the li
 //   k = 2 ki[layer] | 0x433 << 52  -- "rabs < ki" as ONE unsigned compare of the bit pattern of 2^52 + 2 rabs, which the conversion
 //                           builds anyway (same register pair: no copy).
 // Per 64 positions this drops a 64-bit shift, the 52-bit mask, a register move and the two sign instructions (29 -> 25 VALU).
+static_assert(NRM_EV_CAP > NRM_MAX_EV, "the clamped index must lie behind the events the pass reads");
 struct alignas(16) NrmWK { double w; unsigned long long k; };
 struct NormalsLds {                         // one per workgroup
     NrmWK wk[512];
@@ -110,6 +111,7 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
     const uint64_t gamma = r.gamma;
     const uint64_t g64 = gamma << 6;
     const double NRM_DEAD = __longlong_as_double(0x7ff8dead00000000LL);     // a consumed stream position (no fast-path value is a NaN)
+    const bool tail_log1p = (g_rng_policy & PTE_RNG_TAIL_LOG1P) != 0;       // (read once: zig_tail_neglog reloads the policy word at every call)
     double *const out = L.out[wv];
     int64_t done = 0;                                       // outputs written so far (a multiple of 256 until the last group)
     while (done < d) {
@@ -118,10 +120,16 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
         const unsigned long long pt0 = __builtin_readcyclecounter();
 #endif
         const uint64_t base = r.seed;
+#ifdef NRM_MEASURE_EXTRA_SALU      // measurement builds only: what N more scalar / vector instructions per chunk cost at full occupancy
+        { int t_ = (int)base; for (int i_ = 0; i_ < NRM_MEASURE_EXTRA_SALU; ++i_) asm volatile("s_add_u32 %0, %0, 1" : "+s"(t_)); asm volatile("" :: "s"(t_)); }
+#endif
+#ifdef NRM_MEASURE_EXTRA_VALU
+        { int t_ = lane; for (int i_ = 0; i_ < NRM_MEASURE_EXTRA_VALU; ++i_) asm volatile("v_add_u32 %0, 1, %0" : "+v"(t_)); asm volatile("" :: "v"(t_)); }
+#endif
         uint64_t zc = base + (uint64_t)(lane + 1) * gamma;
         int n_ev = 0;                                       // uniform
 #pragma unroll
-        for (int j = 0; j < NRM_SLOTS; ++j) {
+        for (int j = 0; j < NRM_SLOTS; ++j) {              // (three slots issued together, no branch between them: the same, measured)
 #ifdef NRM_MEASURE_NO_MIX          // measurement builds only (wrong samples): what the SplitMix64 finaliser costs
             const uint64_t raw = zc ^ (zc >> 29);
 #else
@@ -130,7 +138,7 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
             zc += g64;
             const uint32_t lo = (uint32_t)raw, hi = (uint32_t)(raw >> 32);
             const NrmWK t = L.wk[lo & 0x1FFu];
-            // 2^52 + (2 rabs + sign) as a bit pattern; with bit 0 cleared and 2^52 subtracted: 2 rabs, exactly
+            // the bit pattern of 2^52 + 2 rabs; minus 2^52: 2 rabs, exactly      (v_bfi_b32 for the and + or: the same pipe time, measured)
             const uint64_t mb = ((uint64_t)((hi & 0x000FFFFFu) | 0x43300000u) << 32) | (lo & ~1u);
             // rabs = 0 with the sign bit set gives -0.0 where the reference has +0.0: the division step below returns +0.0 for it
             // (fma(+0.0, r, -0.0) = +0.0).
@@ -138,6 +146,8 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
             const bool slow = !(mb < t.k);                  // 2 rabs < 2 ki, on the bit patterns
             const uint64_t m = ballot64(slow);
             if (m) {                                        // uniform branch, 60 % of the slots
+                // (the index is clamped: a list that stops growing at NRM_MAX_EV instead -- one scalar compare more in the branch condition, no
+                // v_min -- measured 1.8 % SLOWER at N = 8192)
                 const int at = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)n_ev));
                 if (slow) L.ev[wv][min(at, NRM_EV_CAP - 1)] = (unsigned short)(64 * j + lane);
                 n_ev += __popcll(m);
@@ -182,7 +192,8 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
                 int pairs = 0;
                 double xx, yy;
                 do {
-                    const double v = zig_tail_neglog(u52_to_unit(mix64(zt)));
+                    const double ut = u52_to_unit(mix64(zt));
+                    const double v = tail_log1p ? -log1p(-ut) : -log(ut);
                     zt += gamma + gamma;
                     const double pv = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, true),
                                                        __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, true));
