@@ -122,6 +122,20 @@ int dev_alloc(pte_engine *h, T **p, size_t n, bool zero = true) {
 
 int next_pow2_log(int64_t n) { int l = 0; while (((int64_t)1 << l) < n) ++l; return l; }
 
+#ifdef PTE_DEV_FEW_NLU   // development builds only (tools/build_variant.sh): the tree depths of d = 1024 and d = 4096, a fifth of the compile time
+#define DISPATCH_NLU_M(nlu, KERNEL, MM, grid, block, stream, ...)                                 \
+    switch (nlu) {                                                                               \
+    case 4: hipLaunchKernelGGL((KERNEL<4, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    case 6: hipLaunchKernelGGL((KERNEL<6, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    default: fprintf(stderr, "PTE_DEV_FEW_NLU build: d must be 1024 or 4096\n"); abort();        \
+    }
+#define DISPATCH_NLU(nlu, KERNEL, grid, block, stream, ...)                                      \
+    switch (nlu) {                                                                               \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    case 6: hipLaunchKernelGGL(KERNEL<6>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    default: fprintf(stderr, "PTE_DEV_FEW_NLU build: d must be 1024 or 4096\n"); abort();        \
+    }
+#else
 #define DISPATCH_NLU_M(nlu, KERNEL, MM, grid, block, stream, ...)                                 \
     switch (nlu) {                                                                               \
     case 0: hipLaunchKernelGGL((KERNEL<0, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
@@ -143,6 +157,8 @@ int next_pow2_log(int64_t n) { int l = 0; while (((int64_t)1 << l) < n) ++l; ret
     case 5: hipLaunchKernelGGL(KERNEL<5>, grid, block, 0, stream, __VA_ARGS__); break;           \
     default: hipLaunchKernelGGL(KERNEL<6>, grid, block, 0, stream, __VA_ARGS__); break;          \
     }
+
+#endif
 
 // discretize(path, schedule): per-chain constants of ScaledPrecisionNormalLogPotential
 // (reference src/paths/ScaledPrecisionNormalPath.jl:45-48, src/schedules/discretize.jl:6-7).
@@ -284,6 +300,9 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
             ap.ref_prec = h->cfg.target_params[0]; ap.log3 = std::log(3.0);
             const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
             time_begin(h, 0);
+#ifdef PTE_DEV_NO_LANGEVIN
+            return fail(h, "PTE_DEV_NO_LANGEVIN build");
+#else
             switch (E) {
             case 1: hipLaunchKernelGGL((k_explore_automala<1, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
             case 2: hipLaunchKernelGGL((k_explore_automala<2, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
@@ -291,6 +310,7 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
             case 8: hipLaunchKernelGGL((k_explore_automala<8, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
             default: hipLaunchKernelGGL((k_explore_automala<16, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
             }
+#endif
             time_end(h);
             break;
         }
@@ -302,7 +322,8 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
         } else if (h->slice_impl == 8) {
             // shrinkage steps for every hypothesis: PTE_S8_BS = 9, re-measured after every change of the round's cost (tools/bench_variant.py)
             // 14 KB of LDS per replica (512-draw window) allow 11 replicas per CU; beyond 256 x 11 the 10 KB variant keeps 16
-            if (N <= PTE_S8_TWIN_FROM) { DISPATCH_NLU_M(h->nlu, k_explore_slice8, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp); }
+            if (N <= PTE_S8_TWIN_FROM && sp.p >= PTE_S8_BD) { DISPATCH_NLU_M(h->nlu, k_explore_slice8, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp); }
+            else if (N <= PTE_S8_TWIN_FROM) { DISPATCH_NLU_M(h->nlu, k_explore_slice8_smallp, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp); }
             else { DISPATCH_NLU_M(h->nlu, k_explore_slice8_lds10k, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp); }
         }
 #ifdef PTE_TEST_KERNELS
@@ -337,8 +358,12 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
         else if (fun) hipLaunchKernelGGL((k_explore_automala<EE, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
         else if (full) hipLaunchKernelGGL((k_explore_automala<EE, TGT_MVN, false, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
         else hipLaunchKernelGGL((k_explore_automala<EE, TGT_MVN>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap);
+#ifdef PTE_DEV_NO_LANGEVIN      // development builds only (tools/build_variant.sh): three quarters of the compile time are these instantiations
+        (void)fun; (void)full; return fail(h, "PTE_DEV_NO_LANGEVIN build");
+#else
         switch (E) { case 1: AM_LAUNCH(1) break; case 2: AM_LAUNCH(2) break; case 4: AM_LAUNCH(4) break;
                      case 8: AM_LAUNCH(8) break; default: AM_LAUNCH(16) break; }
+#endif
 #undef AM_LAUNCH
         time_end(h);
         break;

@@ -48,7 +48,7 @@ constexpr int S8_BD = PTE_S8_BD;                 // doubling budget of a specula
 // 12 replicas per CU; forcing 128 VGPRs (amdgpu_num_vgpr: 4 waves per SIMD, 36 B of scratch per lane) was measured at
 // 3072 / 4096 / 8192 replicas and changes nothing (1.875 / 2.318 / 4.250 against 1.877 / 2.316 / 4.252 ms): three waves
 // already saturate a SIMD's issue slots.
-template <int NLU, int S8_BS, int WINDOW, bool DBL_EXEC>
+template <int NLU, int S8_BS, int WINDOW, int DBL_MODE>      // DBL_MODE: form of the budgeted doubling steps (0 selects, 1 EXEC masks, 2 v_cmpx + selects)
 __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
     using namespace s7;
     constexpr int WIN = WINDOW, REFILL_AT = WINDOW - PTE_S7_MARGIN;
@@ -206,8 +206,63 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 double dL = test(LL), dR = test(RR);
                 // ---- doubling (:115-139): S8_BD predicated steps for every lane ...
                 int kd = 0;
+                double dmin_lr = 0.0;                    // min(dL, dR) after the budgeted steps (DBL_MODE 2: left by the hand-written block)
 #if PTE_S8_BD >= 1 && PTE_S8_BD <= 4 && !defined(PTE_S8_DOUBLING_SELECTS)
-                if (DBL_EXEC && sp.p >= S8_BD) {         // (uniform; compile-time per kernel)
+                if constexpr (DBL_MODE == 2) {           // (the launcher picks this instantiation only for sp.p >= S8_BD: no second body in the loop)
+                    // Round 4, the one-wave-per-SIMD kernel: a hypothesis that needs no (further) doubling drops out of EXEC by v_cmpx --
+                    // written by the VECTOR side, no trip to the scalar side (what made the EXEC-mask form below 2 % slower for a lone
+                    // wave) -- which freezes its interval, end values, step count and dmin without a select; only the side (left / right,
+                    // per lane) is selected: 20 VALU instructions per step, none scalar, where the pure select form needs 28.  "Needs
+                    // doubling" is monotone (a lane that stops never resumes: its values do not change), so EXEC only narrows and is
+                    // restored once.  Same operations in the same order per lane: L - (R - L) or R + (R - L) (SliceSampler.jl:123-131),
+                    // d = v * v - Q, |d| folded into dmin.  (>= 4 instructions between a VALU write of VCC and its use as a lane mask.)
+                    // Fixed registers because the 64-bit selects address register halves; LL / RR / dmin / Q sit where the shrinkage block
+                    // below wants Lbar / Rbar / dmin / Q.
+                    double t_, wd_, cl_, cr_, cd_, dc_;
+                    uint64_t sv_;
+#define PTE_S8_CSTEP(V) \
+                    "v_min_f64 v[102:103], v[114:115], v[116:117]\n" \
+                    "v_cmpx_gt_f64 vcc, 0, v[102:103]\n" \
+                    "v_cmp_ge_f64 vcc, 0.5, " V "\n" \
+                    "v_add_f64 v[112:113], v[98:99], -v[96:97]\n" \
+                    "v_add_u32 %[kd], 1, %[kd]\n" \
+                    "v_add_f64 v[118:119], v[96:97], -v[112:113]\n" \
+                    "v_add_f64 v[120:121], v[98:99], v[112:113]\n" \
+                    "v_cndmask_b32 v100, v120, v118, vcc\n" \
+                    "v_cndmask_b32 v101, v121, v119, vcc\n" \
+                    "v_cndmask_b32 v96, v96, v118, vcc\n" \
+                    "v_cndmask_b32 v97, v97, v119, vcc\n" \
+                    "v_mul_f64 v[102:103], v[100:101], v[100:101]\n" \
+                    "v_cndmask_b32 v98, v120, v98, vcc\n" \
+                    "v_cndmask_b32 v99, v121, v99, vcc\n" \
+                    "v_add_f64 v[122:123], v[102:103], -v[110:111]\n" \
+                    "v_cndmask_b32 v114, v114, v122, vcc\n" \
+                    "v_cndmask_b32 v115, v115, v123, vcc\n" \
+                    "v_cndmask_b32 v116, v122, v116, vcc\n" \
+                    "v_cndmask_b32 v117, v123, v117, vcc\n" \
+                    "v_min_f64 v[104:105], v[104:105], |v[122:123]|\n"
+                    asm volatile("s_mov_b64 %[sv], exec\n"
+                                 PTE_S8_CSTEP("%[V0]")
+#if PTE_S8_BD >= 2
+                                 PTE_S8_CSTEP("%[V1]")
+#endif
+#if PTE_S8_BD >= 3
+                                 PTE_S8_CSTEP("%[V2]")
+#endif
+#if PTE_S8_BD >= 4
+                                 PTE_S8_CSTEP("%[V3]")
+#endif
+                                 "s_mov_b64 exec, %[sv]\n"
+                                 "v_min_f64 v[102:103], v[114:115], v[116:117]\n"      // (all lanes: what "still needs doubling" is decided on below)
+                                 : "+{v[96:97]}"(LL), "+{v[98:99]}"(RR), "+{v[114:115]}"(dL), "+{v[116:117]}"(dR), "+{v[104:105]}"(dmin), [kd] "+v"(kd),
+                                   "=&{v[102:103]}"(t_), "=&{v[112:113]}"(wd_), "=&{v[118:119]}"(cl_), "=&{v[120:121]}"(cr_), "=&{v[100:101]}"(cd_),
+                                   "=&{v[122:123]}"(dc_), [sv] "=&s"(sv_)
+                                 : "{v[110:111]}"(Q), [V0] "v"(Vd[0]), [V1] "v"(Vd[S8_BD > 1 ? 1 : 0]), [V2] "v"(Vd[S8_BD > 2 ? 2 : 0]), [V3] "v"(Vd[S8_BD > 3 ? 3 : 0])
+                                 : "vcc", "scc");
+#undef PTE_S8_CSTEP
+                    dmin_lr = t_;
+                } else
+                if (DBL_MODE == 1 && sp.p >= S8_BD) {    // (uniform; compile-time per kernel)
                     // Hand-written: a step runs under EXEC = "this hypothesis still needs doubling", the left / right extension under
                     // EXEC = need & left / need & ~left -- 13 VALU instructions per step where the select form below needs 28 (sixteen of
                     // them v_cndmask halves).  Same operations in the same order per lane: L - (R - L) or R + (R - L)
@@ -250,7 +305,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                                  : [LL] "+v"(LL), [RR] "+v"(RR), [dL] "+v"(dL), [dR] "+v"(dR), [dmin] "+v"(dmin), [kd] "+v"(kd),
                                    [t] "=&v"(t_), [wd] "=&v"(wd_), [sv] "=&s"(sv_), [sv2] "=&s"(sv2_)
                                  : [Q] "v"(Q), [V0] "v"(Vd[0]), [V1] "v"(Vd[S8_BD > 1 ? 1 : 0]), [V2] "v"(Vd[S8_BD > 2 ? 2 : 0]), [V3] "v"(Vd[S8_BD > 3 ? 3 : 0])
-                                 : "vcc");
+                                 : "vcc", "scc");        // (s_and_saveexec / s_andn2 write SCC)
 #undef PTE_S8_DSTEP
                 } else
 #endif
@@ -270,8 +325,9 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                     dL = nl_ ? dc : dL;
                     dR = nr_ ? dc : dR;
                 }
+                if constexpr (DBL_MODE != 2) dmin_lr = fmin(dL, dR);
                 // ... and the rest for the certain hypothesis only
-                if (__builtin_expect(ballot64(lane == 0 && (fmin(dL, dR) < 0.0) && kd < kcap) != 0ull, 0)) {
+                if (__builtin_expect(ballot64(lane == 0 && (dmin_lr < 0.0) && kd < kcap) != 0ull, 0)) {
                     bool need = (lane == 0);
                     while (need) {
                         const double V = s_u[idx0 + 2 + kd];
@@ -287,9 +343,11 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                         need = (kd < kcap) && (fmin(dL, dR) < 0.0);
                     }
                     asm volatile("" : "+v"(dL), "+v"(dR), "+v"(kd));
+                    dmin_lr = fmin(dL, dR);
                 }
-                const bool dbl_ok = !((kd < sp.p) && (fmin(dL, dR) < 0.0));     // ended by itself, not by a budget
-                const double thr2 = 1e-6 * fmax(fabs(LL), fabs(RR));
+                const bool dbl_ok = !((kd < sp.p) && (dmin_lr < 0.0));          // ended by itself, not by a budget
+                double thr2 = 1e-6 * fmax(fabs(LL), fabs(RR));
+                if constexpr (DBL_MODE == 2) asm volatile("" : "+v"(thr2));       // (taken here: LL / RR then live on only as the shrinkage block's bracket, in place)
 #ifdef PTE_PROFILE_SECTIONS
                 asm volatile("" :: "v"(LL), "v"(RR), "v"(kd), "v"(thr2));
 #endif
@@ -348,7 +406,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                                  : "{v[108:109]}"(xold), "{v[110:111]}"(Q), [u0] "v"(u[0]), [u1] "v"(u[1]), [u2] "v"(u[2]), [u3] "v"(u[3]),
                                    [u4] "v"(u[4]), [u5] "v"(u[5]), [u6] "v"(u[S8_BS > 6 ? 6 : 0]), [u7] "v"(u[S8_BS > 7 ? 7 : 0]),
                                    [u8] "v"(u[S8_BS > 8 ? 8 : 0]), [u9] "v"(u[S8_BS > 9 ? 9 : 0])
-                                 : "vcc");
+                                 : "vcc", "scc");        // (s_andn2 writes SCC)
 #undef PTE_S8_STEP
                     fin = __builtin_amdgcn_inverse_ballot_w64(fin_mask);
                 } else {
@@ -460,33 +518,38 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                     l += gdone;
                 }
 #else
-                // packed word of a valid hypothesis of level >= 1: bits 0-7 its draw count, bits 8-13 its successor lane (0: none),
-                // bit 16 "one more coordinate done" -- so that ONE masked add per level accumulates both the draws consumed (low
-                // half) and the coordinates retired (high half) of the true path
-                const int packed = (valid && lane != 0) ? (int)(0x10000u | (unsigned)cnt | (inw ? (unsigned)(kn + succ_base) << 8 : 0u)) : 0;
+                // word of a valid hypothesis: bits 0-7 its draw count, bit 16 "one more coordinate done", bits 24-29 its successor lane
+                // (0: none) -- ONE add per level accumulates the draws consumed (low half) and the coordinates retired (bits 16-18) of
+                // the true path (the successor fields pile up above bit 24, out of the way), one shift yields the next lane select
+                // (v_readlane reads six bits of it).  Lane 0 is read through `word`; in `packed` it is 0, because a broken path (an
+                // invalid hypothesis has word 0) falls back to lane 0, which must then contribute nothing.  Round 4: the level-0 hop
+                // used to be re-derived on the scalar side (window test, two selects), the true lanes' mask built by shift + or, the
+                // fields masked before every add: 16 scalar instructions per round less.
+                int word_v = (int)(0x10000u | (unsigned)cnt | (inw ? (unsigned)(kn + succ_base) << 24 : 0u));
+                asm("" : "+v"(word_v));                       // (computed for every lane and selected: hipcc otherwise wraps it into an EXEC-masked branch)
+                const int word = valid ? word_v : 0;
+                const int packed = (lane != 0) ? word : 0;
 #ifdef PTE_PROFILE_SECTIONS
                 asm volatile("" :: "v"(packed));
 #endif
                 PROF_T(t3); PROF_ADD(2, t3 - t2); PROF_ADD(3, 1);
-                int gdone = (int)(vmask & 1ull);
+                int gdone;
                 {
-                    const int cnt0 = __builtin_amdgcn_readlane(cnt, 0);
-                    const int k1 = cnt0 - LO[1];
-                    int acc = gdone ? cnt0 : 0;
-                    int cur = (gdone && (unsigned)k1 < (unsigned)WD[1]) ? BASE[1] + k1 : 0;
+                    int pk = __builtin_amdgcn_readlane(word, 0);
+                    unsigned acc = (unsigned)pk;
                     uint64_t tmask = 1ull;
 #pragma unroll
                     for (int g = 1; g < G; ++g) {
-                        const int pk = __builtin_amdgcn_readlane(packed, cur);
-                        tmask |= 1ull << cur;
-                        acc += pk & 0x100FF;
-                        cur = (int)(((unsigned)pk >> 8) & 63u);
+                        const int cur = (int)((unsigned)pk >> 24);
+                        asm("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(cur));          // tmask |= 1 << (cur & 63)
+                        pk = __builtin_amdgcn_readlane(packed, cur);
+                        acc += (unsigned)pk;
                     }
                     tmask &= vmask;                           // (a path ends AT an invalid lane: its bit was set above)
                     if (__builtin_amdgcn_inverse_ballot_w64(tmask)) s_x[(l + hg) & (BLK - 1)] = xf;
                     __builtin_amdgcn_wave_barrier();
-                    p += acc & 0xFFFF;
-                    gdone += acc >> 16;
+                    p += (int)(acc & 0xFFFFu);
+                    gdone = (int)((acc >> 16) & 0xFFu);
                     l += gdone;
                 }
 #endif
@@ -618,9 +681,16 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
 #endif
 }
 
+#ifndef PTE_S8_DBL_MODE
+#define PTE_S8_DBL_MODE 2
+#endif
 template <int NLU, int S8_BS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES, PTE_S8_WAVES))) void k_explore_slice8(EngineDev e, SliceParams sp) {
-    slice8_body<NLU, S8_BS, PTE_S7_WIN, false>(e, sp);
+    slice8_body<NLU, S8_BS, PTE_S7_WIN, PTE_S8_DBL_MODE>(e, sp);        // requires sp.p >= S8_BD when PTE_S8_DBL_MODE == 2 (launch_explore checks)
+}
+template <int NLU, int S8_BS>           // doubling limit p below the speculative budget (non-default SliceSampler(p = 1, 2)): the select form handles it < p per step
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES, PTE_S8_WAVES))) void k_explore_slice8_smallp(EngineDev e, SliceParams sp) {
+    slice8_body<NLU, S8_BS, PTE_S7_WIN, 0>(e, sp);
 }
 #ifndef PTE_S8_TWIN_WAVES
 #define PTE_S8_TWIN_WAVES PTE_S8_WAVES
@@ -630,7 +700,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES
 #endif
 template <int NLU, int S8_BS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_TWIN_WAVES, PTE_S8_TWIN_WAVES))) void k_explore_slice8_lds10k(EngineDev e, SliceParams sp) {
-    slice8_body<NLU, S8_BS, 256, true>(e, sp);
+    slice8_body<NLU, S8_BS, 256, 1>(e, sp);
 }
 
 }  // namespace pte
