@@ -52,15 +52,25 @@ template <int NLU, int S8_BS, int WINDOW, int DBL_MODE>      // DBL_MODE: form o
 __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
     using namespace s7;
     constexpr int WIN = WINDOW, REFILL_AT = WINDOW - PTE_S7_MARGIN;
-    __shared__ double s_we[256];
-    __shared__ unsigned long long s_ke[256];
-    __shared__ double s_u[WIN];
-    __shared__ double s_e[WIN];              // randexp fast-path value; NaN <=> slow path needed
+    // FAST: the instantiation for S8_BD < sp.p <= 20 and sp.max_iter >= S8_BS (the launcher checks; SliceSampler's defaults are p = 20,
+    // max_iter = 1024), which lets the round drop per-step / per-round tests that cannot fail under these conditions
+    constexpr bool FAST = (DBL_MODE == 2);
+    static_assert(CAP_ITERS >= S8_BS, "lane 0 must be able to run past the speculative budget");
 #ifndef PTE_S8_BLK
 #define PTE_S8_BLK 256
 #endif
     constexpr int BLK = PTE_S8_BLK, CPB = BLK / 64;  // coordinates per block (rounds do not reach across a block end) = CPB 64-leaf chunks of the tree
-    __shared__ double s_x[BLK];              // the current block: start-of-pass values, overwritten as coordinates retire
+    // One struct so that the uniforms sit at LDS offset 0: the nine shrinkage draws of a hypothesis (ds_read2_b64: 8-bit offsets in units
+    // of 8 bytes) and its head draws then need no address arithmetic beyond the lane's own index -- seven v_add_u32 per round
+    // less, five of them between the doubling steps and the shrinkage block (round 4)
+    __shared__ struct {
+        double u[WIN];
+        double e[WIN];                       // randexp fast-path value; NaN <=> slow path needed
+        double x[BLK];                       // the current block: start-of-pass values, overwritten as coordinates retire
+        double we[256];
+        unsigned long long ke[256];
+    } sm;
+    double (&s_u)[WIN] = sm.u; double (&s_e)[WIN] = sm.e; double (&s_x)[BLK] = sm.x; double (&s_we)[256] = sm.we; unsigned long long (&s_ke)[256] = sm.ke;
     const int lane = lane_id();
 #ifdef PTE_PROFILE_WAVES
     const uint64_t wave_t0 = __builtin_amdgcn_s_memrealtime();
@@ -157,9 +167,9 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
             __builtin_amdgcn_wave_barrier();
             double Sest = S * (1.0 + 1e-6) + wsum * inv_abs_nhp;       // upper bound on sum x^2 while this window lasts
             int l = 0;
-            while (l < nl) {
+            do {                                                   // (nl >= 1; one back edge, the refill out of line: a taken branch costs a lone wave ~35 cycles)
                 PROF_T(t0);
-                if (p > REFILL_AT) { wseed += (uint64_t)p * gamma; fill_window(); Sest = Sest * (1.0 + 1e-6) + wsum * inv_abs_nhp; }
+                if (__builtin_expect(p > REFILL_AT, 0)) { wseed += (uint64_t)p * gamma; fill_window(); Sest = Sest * (1.0 + 1e-6) + wsum * inv_abs_nhp; }
                 // ================= speculative round: lane = hypothesis (l + hg, p + hrel) ==========
                 // Decisions are sign tests of d(v) = v^2 - Q; every tested |d| is folded into dmin and the
                 // hypothesis is valid only if dmin clears the margin at the end (so the loops carry no
@@ -176,6 +186,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
 #pragma unroll
                 for (int it = 0; it < S8_BD; ++it) Vd[it] = s_u[idx0 + 2 + it];
                 int ex0 = 0;
+                int cnt_base = 2;                            // draws of the head: E and u0 (+ lane 0's extra draws of a slow-path exponential)
                 if (__builtin_expect((ballot64(E != E) & 1ull) != 0ull, 0)) {
                     // the certain hypothesis needs the ziggurat's slow path for its exponential (2.3 % of the coordinates):
                     // evaluate it exactly at its stream position; its other draws follow `ex0` positions later
@@ -184,7 +195,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                     const int used = (int)((rs.seed - (wseed + (uint64_t)p * gamma)) * gamma_inv);
                     if (used <= 17) {
                         ex0 = used - 1;
-                        if (lane == 0) { E = Ex; idx0 += ex0; }
+                        if (lane == 0) { E = Ex; idx0 += ex0; cnt_base = 2 + ex0; }
                         Sest += Ex * inv_abs_nhp;            // not among the window's fast-path exponentials summed into Sest
                         ex_total += ex0;
                         u0 = s_u[idx0 + 1];
@@ -192,7 +203,6 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                         for (int it = 0; it < S8_BD; ++it) Vd[it] = s_u[idx0 + 2 + it];
                     }
                 }
-                const int ex = (lane == 0) ? ex0 : 0;
                 const double Q = xold * xold - E * inv_nhp;
                 const double Bq = Sest + fabs(Q);
                 double dmin = fabs(E * inv_nhp);             // |x_old^2 - Q|: the old position is inside the slice by the margin too (see the acceptance check)
@@ -344,8 +354,11 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                     }
                     asm volatile("" : "+v"(dL), "+v"(dR), "+v"(kd));
                     dmin_lr = fmin(dL, dR);
+                    if constexpr (FAST) dmin_lr = (kd >= sp.p) ? 0.0 : dmin_lr;   // (the reference's own limit p ended it: not a budget)
                 }
-                const bool dbl_ok = !((kd < sp.p) && (dmin_lr < 0.0));          // ended by itself, not by a budget
+                // ended by itself, not by a budget.  FAST (S8_BD < p <= 20): a speculative lane has kd <= S8_BD < p, and lane 0 leaves
+                // the loop above either satisfied or at kd = p, so "still needs doubling" alone decides
+                const bool dbl_ok = FAST ? !(dmin_lr < 0.0) : !((kd < sp.p) && (dmin_lr < 0.0));
                 double thr2 = 1e-6 * fmax(fabs(LL), fabs(RR));
                 if constexpr (DBL_MODE == 2) asm volatile("" : "+v"(thr2));       // (taken here: LL / RR then live on only as the shrinkage block's bracket, in place)
 #ifdef PTE_PROFILE_SECTIONS
@@ -442,7 +455,10 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                     fin = fin || (lane == 0 && dx < 0.0);
                 }
                 // W > thr2 at the last step (widths only shrink) rules out isapprox(Lbar, Rbar) at every step
-                bool valid = active && !(E != E) && dbl_ok && fin && (W > thr2) && n <= cap_iters;   // (max_iter < S8_BS: exact path raises)
+                // FAST drops two tests that cannot fail there: a NaN exponential makes Q, every d, dmin and Bq NaN, so it fails the margin
+                // test below (and `fin`); n <= S8_BS <= max_iter for a speculative lane, and lane 0's loop above stops at cap_iters
+                bool valid = active && dbl_ok && fin && (W > thr2);
+                if constexpr (!FAST) valid = valid && !(E != E) && n <= cap_iters;                  // (max_iter < S8_BS: exact path raises)
 #ifdef PTE_PROFILE_SECTIONS
                 asm volatile("" :: "v"(xf), "v"(n), "v"(dmin));
 #endif
@@ -462,7 +478,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 {   // why the true path ends where it ends (slots 8..15: all 5 levels done, then the causes)
                     const bool mg = dmin > 2e-12 * Bq;
                     const int rc = !active ? 7 : (E != E) ? 1 : !dbl_ok ? 2 : !fin ? 3 : !valid ? 4 : !mg ? 5 : 0;
-                    const int cnt_ = 2 + kd + n + ex;
+                    const int cnt_ = cnt_base + kd + n;
                     int o_ = 0, g_ = 0, why = 0;
                     for (g_ = 0; g_ < G; ++g_) {
                         if (l + g_ >= nl) { why = 7; break; }
@@ -480,7 +496,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 // ================= chase the true path through the hypotheses =======================
                 // Branch free: every lane names its successor, the chase is one v_readlane per level.  An invalid
                 // hypothesis packs 0, so a broken path falls back to lane 0, which never carries the level >= 1 flag.
-                const int cnt = 2 + kd + n + ex;
+                const int cnt = cnt_base + kd + n;
                 const int kn = cnt + succ_off;
                 const bool inw = (unsigned)kn < (unsigned)succ_wd;
                 const uint64_t vmask = ballot64(valid);
@@ -536,15 +552,16 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 int gdone;
                 {
                     int pk = __builtin_amdgcn_readlane(word, 0);
-                    unsigned acc = (unsigned)pk;
+                    unsigned acc = 0u;
                     uint64_t tmask = 1ull;
 #pragma unroll
                     for (int g = 1; g < G; ++g) {
                         const int cur = (int)((unsigned)pk >> 24);
-                        asm("s_bitset1_b64 %0, %1" : "+s"(tmask) : "s"(cur));          // tmask |= 1 << (cur & 63)
+                        // tmask |= 1 << (cur & 63); the sum taken here, between the hops (hipcc leaves all the adds behind the last hop, on the path to the next round's loads)
+                        asm volatile("s_bitset1_b64 %0, %2\n\ts_add_u32 %1, %1, %3" : "+s"(tmask), "+s"(acc) : "s"(cur), "s"(pk) : "scc");
                         pk = __builtin_amdgcn_readlane(packed, cur);
-                        acc += (unsigned)pk;
                     }
+                    acc += (unsigned)pk;
                     tmask &= vmask;                           // (a path ends AT an invalid lane: its bit was set above)
                     if (__builtin_amdgcn_inverse_ballot_w64(tmask)) s_x[(l + hg) & (BLK - 1)] = xf;
                     __builtin_amdgcn_wave_barrier();
@@ -642,7 +659,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                     fb_draws += used; n_fb += 1;
                     PROF_T(t5); PROF_ADD(7, t5 - t4); PROF_ADD(6, 1);
                 }
-            }
+            } while (l < nl);
             if (err) break;
             {   // write the block back and re-establish the exact fixed-tree values at the block boundary
 #pragma unroll
@@ -686,10 +703,10 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
 #endif
 template <int NLU, int S8_BS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES, PTE_S8_WAVES))) void k_explore_slice8(EngineDev e, SliceParams sp) {
-    slice8_body<NLU, S8_BS, PTE_S7_WIN, PTE_S8_DBL_MODE>(e, sp);        // requires sp.p >= S8_BD when PTE_S8_DBL_MODE == 2 (launch_explore checks)
+    slice8_body<NLU, S8_BS, PTE_S7_WIN, PTE_S8_DBL_MODE>(e, sp);        // PTE_S8_DBL_MODE == 2 requires S8_BD < sp.p <= 20 and sp.max_iter >= S8_BS (launch_explore checks)
 }
-template <int NLU, int S8_BS>           // doubling limit p below the speculative budget (non-default SliceSampler(p = 1, 2)): the select form handles it < p per step
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES, PTE_S8_WAVES))) void k_explore_slice8_smallp(EngineDev e, SliceParams sp) {
+template <int NLU, int S8_BS>           // any p / max_iter (non-default SliceSampler(p = 1 .. 3, p > 20, max_iter < 9)): the select form tests it < p per step, the round keeps every validity test
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES, PTE_S8_WAVES))) void k_explore_slice8_generic(EngineDev e, SliceParams sp) {
     slice8_body<NLU, S8_BS, PTE_S7_WIN, 0>(e, sp);
 }
 #ifndef PTE_S8_TWIN_WAVES
