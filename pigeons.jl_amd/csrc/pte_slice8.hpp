@@ -105,6 +105,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
     // lane  succ_base + (cnt + succ_off)  if that falls into the next level's window (never for the last level)
     const int succ_lo = s7_pick(LO, hg + 1, 0), succ_wd = s7_pick(WD, hg + 1, 0), succ_base = s7_pick(BASE, hg + 1, 0);
     const int succ_off = hrel - succ_lo;
+    const int word_c = 0x10000 - succ_off;           // chase word of a valid hypothesis = (draws consumed + succ_off) + word_c + successor lane << 24
     const uint64_t seed_in = e.rng[2 * slot];
 
     double BS = 0.0;                                   // lane b: exact fixed-tree sum of block b
@@ -167,6 +168,9 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
             __builtin_amdgcn_wave_barrier();
             double Sest = S * (1.0 + 1e-6) + wsum * inv_abs_nhp;       // upper bound on sum x^2 while this window lasts
             int l = 0;
+            // (Requesting the head's LDS loads of the NEXT round as soon as the chase has produced (l, p), so that the stores, exit tests
+            // and back edge run in their shadow, was built and measured in round 4: 0.793 against 0.777 ms -- the two extra not-taken
+            // branches of the restructured tail cost more than the ~55 exposed cycles of the round trip.)
             do {                                                   // (nl >= 1; one back edge, the refill out of line: a taken branch costs a lone wave ~35 cycles)
                 PROF_T(t0);
                 if (__builtin_expect(p > REFILL_AT, 0)) { wseed += (uint64_t)p * gamma; fill_window(); Sest = Sest * (1.0 + 1e-6) + wsum * inv_abs_nhp; }
@@ -371,6 +375,13 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 double u[S8_BS];
 #pragma unroll
                 for (int k = 0; k < S8_BS; ++k) u[k] = us[k];
+                // In the shadow of that LDS round trip (a lone wave has nothing else to put there): everything the validity test and the
+                // chase word need that does not depend on the shrinkage -- the margin, the draws consumed so far relative to the
+                // successor's window, "is this coordinate in the block", "did the doubling end by itself" as lane masks
+                double mthr = 2e-12 * Bq;
+                int kn0 = cnt_base + kd + succ_off;          // + n: offset of the successor in the next level's window
+                uint64_t pre_ok = ballot64(active && dbl_ok);
+                if constexpr (FAST) asm volatile("" : "+v"(mthr), "+v"(kn0), "+s"(pre_ok));
                 double Lbar = LL, Rbar = RR, xf = xold, W = 0.0;
                 int n = 0;
                 bool fin = false;
@@ -457,7 +468,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 // W > thr2 at the last step (widths only shrink) rules out isapprox(Lbar, Rbar) at every step
                 // FAST drops two tests that cannot fail there: a NaN exponential makes Q, every d, dmin and Bq NaN, so it fails the margin
                 // test below (and `fin`); n <= S8_BS <= max_iter for a speculative lane, and lane 0's loop above stops at cap_iters
-                bool valid = active && dbl_ok && fin && (W > thr2);
+                bool valid = __builtin_amdgcn_inverse_ballot_w64(pre_ok) && fin && (W > thr2);
                 if constexpr (!FAST) valid = valid && !(E != E) && n <= cap_iters;                  // (max_iter < S8_BS: exact path raises)
 #ifdef PTE_PROFILE_SECTIONS
                 asm volatile("" :: "v"(xf), "v"(n), "v"(dmin));
@@ -492,48 +503,13 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                     PROF_ADD(8 + why, 1);
                 }
 #endif
-                valid = valid && (dmin > 2e-12 * Bq);
+                valid = valid && (dmin > mthr);
                 // ================= chase the true path through the hypotheses =======================
                 // Branch free: every lane names its successor, the chase is one v_readlane per level.  An invalid
                 // hypothesis packs 0, so a broken path falls back to lane 0, which never carries the level >= 1 flag.
-                const int cnt = cnt_base + kd + n;
-                const int kn = cnt + succ_off;
+                const int kn = kn0 + n;
                 const bool inw = (unsigned)kn < (unsigned)succ_wd;
                 const uint64_t vmask = ballot64(valid);
-#ifdef PTE_S8_CHAINED_CHASE      // measured and dropped: 33 cycles per hop in isolation against 52 (tools/ubench/hop.hip), 2 % SLOWER in the kernel (0.913 against 0.897 ms at matched builds)
-                // word of a valid hypothesis: bits 0-5 its successor lane (0: none), bits 8-15 its draw count, bit 24 "one more
-                // coordinate done"; an invalid hypothesis has word 0.  The successor sits in the LOW bits because v_readlane takes its
-                // lane from bits 5:0 of the scalar operand: the word read at one level is the lane select of the next read as it
-                // stands, so the five reads are chained through ONE register each -- no scalar arithmetic between them (a wave alone
-                // on its SIMD pays ~50 cycles for every vector -> scalar ALU -> vector dependence, tools/ubench/lds_lat.hip: the chase
-                // used to cost ~340 cycles per round, 16 % of it).  The sums are taken afterwards, off the dependence chain.
-                const int word = valid ? (int)(0x1000000u | ((unsigned)cnt << 8) | (inw ? (unsigned)(kn + succ_base) : 0u)) : 0;
-                const int packed = (lane != 0) ? word : 0;      // a broken path falls back to lane 0, which contributes nothing
-#ifdef PTE_PROFILE_SECTIONS
-                asm volatile("" :: "v"(packed));
-#endif
-                PROF_T(t3); PROF_ADD(2, t3 - t2); PROF_ADD(3, 1);
-                int gdone;
-                {
-                    int wv[G];
-                    wv[0] = __builtin_amdgcn_readlane(word, 0);
-#pragma unroll
-                    for (int g = 1; g < G; ++g) wv[g] = __builtin_amdgcn_readlane(packed, wv[g - 1]);
-                    uint64_t tmask = 1ull;
-                    unsigned acc = (unsigned)wv[G - 1] >> 8;
-#pragma unroll
-                    for (int g = 0; g < G - 1; ++g) {
-                        tmask |= 1ull << (wv[g] & 63);
-                        acc += (unsigned)wv[g] >> 8;
-                    }
-                    tmask &= vmask;                           // (a path ends AT an invalid lane: its bit was set above)
-                    if (__builtin_amdgcn_inverse_ballot_w64(tmask)) s_x[(l + hg) & (BLK - 1)] = xf;
-                    __builtin_amdgcn_wave_barrier();
-                    p += (int)(acc & 0xFFFFu);
-                    gdone = (int)(acc >> 16);
-                    l += gdone;
-                }
-#else
                 // word of a valid hypothesis: bits 0-7 its draw count, bit 16 "one more coordinate done", bits 24-29 its successor lane
                 // (0: none) -- ONE add per level accumulates the draws consumed (low half) and the coordinates retired (bits 16-18) of
                 // the true path (the successor fields pile up above bit 24, out of the way), one shift yields the next lane select
@@ -541,7 +517,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 // invalid hypothesis has word 0) falls back to lane 0, which must then contribute nothing.  Round 4: the level-0 hop
                 // used to be re-derived on the scalar side (window test, two selects), the true lanes' mask built by shift + or, the
                 // fields masked before every add: 16 scalar instructions per round less.
-                int word_v = (int)(0x10000u | (unsigned)cnt | (inw ? (unsigned)(kn + succ_base) << 24 : 0u));
+                int word_v = kn + word_c + (inw ? (int)((unsigned)(kn + succ_base) << 24) : 0);     // = 0x10000 | cnt | successor << 24  (cnt = kn - succ_off < 256)
                 asm("" : "+v"(word_v));                       // (computed for every lane and selected: hipcc otherwise wraps it into an EXEC-masked branch)
                 const int word = valid ? word_v : 0;
                 const int packed = (lane != 0) ? word : 0;
@@ -569,7 +545,6 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                     gdone = (int)((acc >> 16) & 0xFFu);
                     l += gdone;
                 }
-#endif
 #ifdef PTE_PROFILE_SECTIONS
                 asm volatile("" :: "s"(p), "s"(l));
 #endif
