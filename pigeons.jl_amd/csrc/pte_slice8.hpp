@@ -106,6 +106,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
     const int succ_lo = s7_pick(LO, hg + 1, 0), succ_wd = s7_pick(WD, hg + 1, 0), succ_base = s7_pick(BASE, hg + 1, 0);
     const int succ_off = hrel - succ_lo;
     const int word_c = 0x10000 - succ_off;           // chase word of a valid hypothesis = (draws consumed + succ_off) + word_c + successor lane << 24
+    const int word_c9 = (1 << 20) - succ_off * 512;   // ... and in the layout of the hand-written tail: (draws consumed + succ_off) << 9 + word_c9 + successor lane
     const uint64_t seed_in = e.rng[2 * slot];
 
     double BS = 0.0;                                   // lane b: exact fixed-tree sum of block b
@@ -385,6 +386,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 double Lbar = LL, Rbar = RR, xf = xold, W = 0.0;
                 int n = 0;
                 bool fin = false;
+                uint64_t fin_m = 0ull;                       // `fin` as a lane mask, for the hand-written tail (hipcc moves a mask through v_cndmask + v_cmp otherwise)
                 if constexpr (S8_BS == PTE_S8_BS && S8_BS >= 6 && S8_BS <= 10) {
                     // Hand-scheduled: a lane whose proposal lands inside the slice drops out of EXEC (v_cmpx), which freezes
                     // its result, step count and bracket -- no per-step selects, no mask arithmetic, no branches.  Fixed
@@ -433,6 +435,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                                  : "vcc", "scc");        // (s_andn2 writes SCC)
 #undef PTE_S8_STEP
                     fin = __builtin_amdgcn_inverse_ballot_w64(fin_mask);
+                    fin_m = fin_mask;
                 } else {
 #pragma unroll
                     for (int k = 0; k < S8_BS; ++k) {
@@ -447,6 +450,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                         Rbar = below ? Rbar : v;
                         fin = fin || (dv < 0.0);
                     }
+                    fin_m = ballot64(fin);
                 }
                 if (__builtin_expect(ballot64(lane == 0 && !fin && n < cap_iters) != 0ull, 0)) {
                     // the certain hypothesis continues from its state after S8_BS rejected proposals
@@ -464,10 +468,78 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                     }
                     asm volatile("" : "+v"(dx), "+v"(n), "+v"(W));
                     fin = fin || (lane == 0 && dx < 0.0);
+                    fin_m = ballot64(fin);
                 }
                 // W > thr2 at the last step (widths only shrink) rules out isapprox(Lbar, Rbar) at every step
                 // FAST drops two tests that cannot fail there: a NaN exponential makes Q, every d, dmin and Bq NaN, so it fails the margin
                 // test below (and `fin`); n <= S8_BS <= max_iter for a speculative lane, and lane 0's loop above stops at cap_iters
+                int gdone;
+#ifdef PTE_PROFILE_SECTIONS
+                constexpr bool ASM_TAIL = false;
+#else
+                constexpr bool ASM_TAIL = FAST && G == 5;
+#endif
+                if constexpr (ASM_TAIL) {
+                    // ================= validity + chase, hand-written (round 4) ===========================
+                    // What tools/ubench/round_cost.hip measured for a lone wave: the validity test as hipcc writes it -- compares into
+                    // scalar pairs combined by s_and -- costs 86 cycles for 8 instructions (every compare -> s_and is a trip from the
+                    // vector to the scalar side), the same conditions applied as a chain of selects on the word itself 40; and a hop of
+                    // the chase costs 34-42 cycles when scalar instructions stand between the v_readlane that produces a lane select and
+                    // the one that consumes it, 27.5 when the word read IS the next lane select (successor in bits 5:0, which is all
+                    // v_readlane and s_bitset1 look at) and the four wait states the hardware demands there (tools/ubench/hop_check.hip:
+                    // without them the chase reads the wrong lanes) are filled by the bookkeeping of the hop before.
+                    // word of a valid hypothesis: bits 0-5 its successor lane (0: none), bits 9-17 its draw count, bit 20 "one more
+                    // coordinate done" -- the five words of the path are summed as they stand (successors pile up below bit 9, counts
+                    // below bit 18).  An invalid hypothesis has word 0; so has lane 0 in `pk`, where a broken path ends up.
+                    const int kn = kn0 + n;
+                    const int wsucc = ((unsigned)kn < (unsigned)succ_wd) ? kn + succ_base : 0;
+                    const int word_v = (kn << 9) + word_c9 + wsucc;
+                    unsigned acc; uint64_t tmask, sA_, sB_; int w_, pk_, s0_, s1_, s2_, s3_, s4_;
+                    asm volatile("v_cmp_gt_f64 vcc, %[W], %[thr]\n"
+                                 "v_cndmask_b32_e64 %[w], 0, %[wv], %[pre]\n"          // in the block, doubling ended by itself
+                                 "v_cmp_gt_f64_e64 %[sA], %[dm], %[mthr]\n"
+                                 "v_cndmask_b32_e64 %[w], 0, %[w], %[fin]\n"           // a proposal inside the slice within the budget
+                                 "v_cndmask_b32_e32 %[w], 0, %[w], vcc\n"              // interval still wider than the isapprox threshold
+                                 "s_nop 0\n"
+                                 "v_cndmask_b32_e64 %[w], 0, %[w], %[sA]\n"            // every decision clears the filter's margin
+                                 "v_cndmask_b32_e64 %[pk], 0, %[w], %[nz]\n"
+                                 : [w] "=&v"(w_), [pk] "=&v"(pk_), [sA] "=&s"(sA_)
+                                 : [wv] "v"(word_v), [pre] "s"(pre_ok), [fin] "s"(fin_m), [nz] "s"(0xFFFFFFFFFFFFFFFEull),
+                                   [W] "v"(W), [thr] "v"(thr2), [dm] "v"(dmin), [mthr] "v"(mthr)
+                                 : "vcc");
+                    // (a second statement: with vector outputs in the same one hipcc takes the scalar results for divergent and routes
+                    // p and l through the vector side -- v_bfe, v_add, v_readfirstlane -- on the way to the next round)
+                    asm volatile("v_cmp_ne_u32_e64 %[sB], 0, %[w]\n"
+                                 "s_mov_b64 %[tm], 1\n"
+                                 "v_readlane_b32 %[s0], %[w], 0\n"
+                                 "s_nop 3\n"
+                                 "v_readlane_b32 %[s1], %[pk], %[s0]\n"
+                                 "s_bitset1_b64 %[tm], %[s0]\n"
+                                 "s_mov_b32 %[acc], %[s0]\n"
+                                 "s_nop 1\n"
+                                 "v_readlane_b32 %[s2], %[pk], %[s1]\n"
+                                 "s_bitset1_b64 %[tm], %[s1]\n"
+                                 "s_add_u32 %[acc], %[acc], %[s1]\n"
+                                 "s_nop 1\n"
+                                 "v_readlane_b32 %[s3], %[pk], %[s2]\n"
+                                 "s_bitset1_b64 %[tm], %[s2]\n"
+                                 "s_add_u32 %[acc], %[acc], %[s2]\n"
+                                 "s_nop 1\n"
+                                 "v_readlane_b32 %[s4], %[pk], %[s3]\n"
+                                 "s_bitset1_b64 %[tm], %[s3]\n"
+                                 "s_add_u32 %[acc], %[acc], %[s3]\n"
+                                 "s_and_b64 %[tm], %[tm], %[sB]\n"                      // (a path ends AT an invalid lane: its bit was set above)
+                                 "s_add_u32 %[acc], %[acc], %[s4]\n"
+                                 : [sB] "=&s"(sB_), [tm] "=&s"(tmask), [acc] "=&s"(acc),
+                                   [s0] "=&s"(s0_), [s1] "=&s"(s1_), [s2] "=&s"(s2_), [s3] "=&s"(s3_), [s4] "=&s"(s4_)
+                                 : [w] "v"(w_), [pk] "v"(pk_)
+                                 : "scc");
+                    if (__builtin_amdgcn_inverse_ballot_w64(tmask)) s_x[(l + hg) & (BLK - 1)] = xf;
+                    __builtin_amdgcn_wave_barrier();
+                    p += (int)((acc >> 9) & 0x1FFu);
+                    gdone = (int)((acc >> 20) & 7u);
+                    l += gdone;
+                } else {
                 bool valid = __builtin_amdgcn_inverse_ballot_w64(pre_ok) && fin && (W > thr2);
                 if constexpr (!FAST) valid = valid && !(E != E) && n <= cap_iters;                  // (max_iter < S8_BS: exact path raises)
 #ifdef PTE_PROFILE_SECTIONS
@@ -525,7 +597,6 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 asm volatile("" :: "v"(packed));
 #endif
                 PROF_T(t3); PROF_ADD(2, t3 - t2); PROF_ADD(3, 1);
-                int gdone;
                 {
                     int pk = __builtin_amdgcn_readlane(word, 0);
                     unsigned acc = 0u;
@@ -544,6 +615,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                     p += (int)(acc & 0xFFFFu);
                     gdone = (int)((acc >> 16) & 0xFFu);
                     l += gdone;
+                }
                 }
 #ifdef PTE_PROFILE_SECTIONS
                 asm volatile("" :: "s"(p), "s"(l));

@@ -4,8 +4,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pigeons.jl_amd")]
 lib = os.path.join(ROOT, "gpurun_out", "libpte_prof.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                "-Wno-unused-value", "-DPTE_PROFILE_SECTIONS", "-DPTE_TEST_KERNELS", *(["-DPTE_DEBUG_S7"] if os.environ.get("S7DBG") else []), "-o", lib, os.path.join(ROOT, "pigeons.jl_amd/csrc/pte.hip"), "-ldl"], check=True)
+if os.environ.get("PROF_LIB"):       # a library built beforehand (tools/build_variant.sh prof -DPTE_PROFILE_SECTIONS): nothing to compile on the GPU box
+    lib = os.environ["PROF_LIB"]
+else:
+  subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                  "-Wno-unused-value", "-DPTE_PROFILE_SECTIONS", "-DPTE_TEST_KERNELS", *(["-DPTE_DEBUG_S7"] if os.environ.get("S7DBG") else []), "-o", lib, os.path.join(ROOT, "pigeons.jl_amd/csrc/pte.hip"), "-ldl"], check=True)
 from pigeons_amd import _lib
 _lib.LIB_PATH = lib
 DK = int(os.environ.get("S_IMPL", "7"))
