@@ -192,6 +192,42 @@ def hbm_kernels(P):
     return out
 
 
+def invariance_check(P, d, total_chains, explorer_name, rank, world, local_rank, dist):
+    """The reference's parallelism invariance (docs/src/distributed.md:37-58) on THIS node and transport, before anything is timed: a short
+    seeded run (rounds 1..3 = 14 scans with schedule adaptation) of the ladder cut over the `world` ranks against the same run on ONE
+    engine (rank 0 holds it), index process / swap recorders / schedule / final states bit for bit.  At most 1024 chains of the ladder's
+    dimension, so that the check costs seconds.  Returns True / False on every rank."""
+    import numpy as np, torch
+    from pigeons_amd.pt import next_round, run_one_round, adapt
+    n = min(total_chains, 128 * world)
+    n -= n % world
+    expl = P.SliceSampler() if explorer_name == "slice" else P.ToyExplorer()
+    mk = lambda: P.Inputs(target=P.toy_mvn_target(d), n_chains=n, n_rounds=3, explorer=expl, seed=7,
+                          record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False, device=local_rank)
+    ok = True
+    try:
+        pt = P.PT(mk(), rank=rank, world=world)
+        one = P.PT(mk()) if rank == 0 else None
+        for _ in range(3):
+            next_round(pt); red = run_one_round(pt); adapt(pt, red)
+            if rank == 0:
+                next_round(one); ra = run_one_round(one); adapt(one, ra)
+                ok = ok and np.array_equal(ra.index_process, red.index_process) and ra.round_trip == red.round_trip \
+                    and np.array_equal(ra.swap_acceptance_pr[0], red.swap_acceptance_pr[0]) and np.array_equal(ra.log_sum_ratio[0], red.log_sum_ratio[0]) \
+                    and np.array_equal(one.shared.tempering.schedule.grids, pt.shared.tempering.schedule.grids)
+        x, chain, rng = pt.shards.states()
+        if rank == 0:
+            xa, ca, ga = one.replicas.states()
+            ok = ok and np.array_equal(x, xa) and np.array_equal(chain, ca) and np.array_equal(rng, ga)
+        pt.replicas.comm_destroy()
+    except Exception as exc:
+        sys.stderr.write("bench.py rank %d: invariance check failed to run: %r\n" % (rank, exc))
+        ok = False
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
 def extra_configs(P):
     """ms / scan (explore + swap, wall clock around pte_run_scans, states resident) of the other BASELINE configs at their per-GPU
     shapes, and the 1-GPU anchor of the strong-scaling clause -- untimed for the headline, so that every config has a driver-visible
@@ -199,6 +235,7 @@ def extra_configs(P):
     import torch
     rec = [P.round_trip, P.log_sum_ratio]
     cfgs = [
+        ("C1 toy_mvn_target(2), n_chains=10, SliceSampler (the reference's quickstart: launch bound)", lambda: P.Inputs(target=P.toy_mvn_target(2), n_chains=10, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 8, 256),
         ("C2 toy_mvn_target(1024), n_chains=256, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(1024), n_chains=256, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 4, 16),
         ("C3 funnel d=128, n_chains=1024, AutoMALA", lambda: P.Inputs(target=P.Funnel(128), reference=P.ScaledPrecisionNormalLogPotential(1 / 9., 128), n_chains=1024, explorer=P.AutoMALA(), record=rec, n_rounds=8, show_report=False), 4, 32),
         ("C4 shard: toy_mvn_target(4096), 1024 of 8192 chains, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(4096), n_chains=1024, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 2, 8),
@@ -257,6 +294,9 @@ def main():
     import numpy as np
     import pigeons_amd as P
     from pigeons_amd.pt import reduce_recorders, adapt, next_round, run_one_round
+    from pigeons_amd import engine as _engine
+    if args.same_device:
+        _engine.comm_allow_library_override(True)        # the test-only RCCL stand-in ($PTE_RCCL_LIB); a real run never opts in, and a stale variable then fails loudly
 
     K, W = args.steps, args.warmup
     if args.scaling == "strong":                # BASELINE configs[3]: d = 4096, 8192 chains in total
@@ -302,9 +342,18 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # warmup: W scans (first RCCL transfers open their connections here), then one reduce + schedule adaptation
+    transport_library = None
+    invariant = None
+    if world > 1 and "FALLBACK" not in transport:
+        path, ver = _engine.comm_library()               # the file ncclSend / ncclRecv really come from, and what it says it is
+        transport_library = {"path": path, "nccl_version": ver}
+        invariant = invariance_check(P, d, total_chains, args.explorer, rank, world, local_rank, dist)
+
+    # warmup: W scans (first RCCL transfers open their connections here: at least two even scans per boundary whatever --warmup says),
+    # then one reduce + schedule adaptation
+    W_run = max(W, 4) if world > 1 else W
     eng.timing_reset(True)              # the swap kernels' duration is taken during the warmup scans ...
-    runner.run_scans(1, W)
+    runner.run_scans(1, W_run)
     sw_ms, sw_n = eng.timing(1)
     adapt(pt, reduce_recorders(pt))
 
@@ -335,6 +384,36 @@ def main():
         t = torch.tensor([dt_noev], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt_noev = float(t.item())
+    # the driver's --steps 20 makes the timed region ~17 ms: when it is shorter than 100 ms the same loop runs once more for 256
+    # scans, bracketed the same way, and the line carries both (`value` stays the requested-K pass)
+    long_run = None
+    if dt < 0.1 and K < 256:
+        K2 = 256
+        sync()
+        t0 = time.perf_counter()
+        runner.run_scans(1, K2)
+        sync()
+        dt2 = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt2], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t.item())
+        long_run = {"steps": K2, "ms_per_step": dt2 / K2 * 1e3, "value": total_chains * K2 / dt2, "hip_events": False,
+                    "note": "the requested --steps make a timed region under 100 ms; the same scan loop for 256 scans, same barriers"}
+    scans_recorded = 2 * K + (256 if long_run else 0)
+    # the boundary exchange as the engine's stream sees it (HIP events around ncclGroupStart .. ncclGroupEnd, one sample per even scan):
+    # the first thing to read on a real multi-GPU node -- the 8-32 KiB message against the 0.8 / 3 ms kernel
+    boundary_exchange = None
+    if world > 1 and "RCCL" in transport and "FALLBACK" not in transport:
+        eng.timing_reset(True)
+        runner.run_scans(1, 16)
+        bs = np.sort(eng.timing_samples(3))
+        eng.timing_reset(False)
+        scans_recorded += 16
+        if len(bs):
+            boundary_exchange = {"samples": int(len(bs)), "us_min_median_max": [float(bs[0]) * 1e3, float(bs[len(bs) // 2]) * 1e3, float(bs[-1]) * 1e3],
+                                 "message_bytes_per_side": int(8 * (d + 8)),
+                                 "note": "HIP events on the engine's stream around the grouped ncclSend / ncclRecv of the ranks' boundary replicas (rank 0's view)"}
     red = reduce_recorders(pt)
     ss_sum, ss_n = red.explorer_n_steps
     boundary = [int(getattr(runner, "n_boundary_swaps", 0))]
@@ -391,25 +470,31 @@ def main():
     except Exception:
         traffic = None
     achieved = alg_bytes / (ex_avg_ms * 1e-3) / 1e9 if ex_avg_ms > 0 else 0.0
-    lp_evals = float(np.sum(ss_sum) / max(2 * K * (total_chains - 1), 1)) + 2.0 * 3 * d if args.explorer == "slice" else 0.0   # (the recorders cover both K-scan passes)
+    lp_evals = float(np.sum(ss_sum) / max(scans_recorded * (total_chains - 1), 1)) + 2.0 * 3 * d if args.explorer == "slice" else 0.0   # (the recorders cover every pass since the adaptation)
     composite_bytes = (24 * d + 128) * value            # B/s over the whole job
     out = {
         "metric": "replica-steps/sec (explore+swap), toy_mvn d=%d, n_chains=%d; round-trip rate" % (d, total_chains),
         "value": value, "unit": "replica-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": dt / K * 1e3, "ms_per_step_without_hip_events": dt_noev / K * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "ms_per_step": dt / K * 1e3, "ms_per_step_without_hip_events": dt_noev / K * 1e3, "long_run": long_run,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "toy_mvn_target(%d), n_chains=%d per GPU x %d GPU, %s, seed=1, DEO swaps every scan"
                                % (d, n_chains, world, "SliceSampler(w=10,p=20,n_passes=3)" if args.explorer == "slice" else "ToyExplorer"),
                    "sharding": ("chains sharded over %d GPUs, boundary replicas only; transport: %s" % (world, transport)) if world > 1 else "single GPU",
                    "n_ranks_seen": ranks_seen, "boundary_swaps_per_rank": boundary, "ms_per_step_per_rank": per_rank_ms,
                    "chains_per_gpu": n_chains, "waves_per_simd": n_chains / 1024.0,      # one wave per replica, 1024 SIMDs per GPU
+                   "transport_library": transport_library, "boundary_exchange": boundary_exchange, "parallelism_invariant": invariant,
+                   "env_overrides": {k: os.environ[k] for k in ("PTE_LIB", "PTE_RCCL_LIB", "PTE_BENCH_BACKEND") if os.environ.get(k)},
                    **({"same_device_test_run": "every rank on HIP device 0 with an RCCL stand-in ($PTE_RCCL_LIB=%s): exercises the "
                        "multi-rank code path, NOT a measurement" % os.environ.get("PTE_RCCL_LIB", "")} if args.same_device else {})},
         "round_trip_rate": rt["round_trip_rate"] if rt else None, "n_round_trips": rt["n_round_trips"] if rt else None,
         "n_tempered_restarts": rt["n_tempered_restarts"] if rt else None, "round_trip": rt,
         "lp_evals_per_replica_step": lp_evals,
-        "roofline": {"bound": "hbm", "kernel": kernel_name,
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "roofline": {"bound": "instruction_issue" if args.explorer == "slice" else "hbm", "kernel": kernel_name,
+                     # what binds the SliceSampler kernel is the issue of ONE wave per replica (frac_of_issue_floor); the HBM figures the
+                     # contract asks for stay beside it: achieved = algorithmic bytes / launch duration, frac = achieved / 8 TB/s
+                     "frac_of_issue_floor": (issue or {}).get("frac_of_issue_floor"),
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "hbm_frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": ex_avg_ms, "launches": ex_n,
                      "launch_ms_min_median_max": [float(samples[0]), float(samples[len(samples) // 2]), float(samples[-1])] if len(samples) else None,
                      "algorithmic_bytes_per_launch": alg_bytes,
@@ -430,6 +515,12 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.explorer == "slice":
             out["cpu_baseline"] = cpu_baseline(d)
+            cb = out["cpu_baseline"]
+            if cb and cb.get("value"):
+                # BASELINE.md publishes no number for this metric; the ratio to the restated CPU baseline timed in this run is given
+                # instead, with its meaning: one GPU against the `cores` host cores the box grants (a reported baseline, not a target)
+                out["vs_baseline"] = value / cb["value"]
+                out["vs_baseline_note"] = "value / cpu_baseline.value: %d GPU(s) against %s host core(s) running the restated CPU path (kind = %s), not a published number" % (world, cb.get("cores"), cb.get("kind"))
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -233,6 +233,12 @@ int pte_shard_sync(pte_engine *h, int64_t *boundary_swaps_out);
  * Message buffers are engine-owned unless the caller installed its own with pte_shard_set_buffers.
  * RCCL is mapped at run time (dlopen; $PTE_RCCL_LIB overrides the search), libpte.so does not link it. */
 #define PTE_COMM_ID_BYTES 128
+/* Which library the transport's entry points come from (the file, via dladdr) and what its ncclGetVersion reports -- for the
+ * log line of a multi-GPU run.  $PTE_RCCL_LIB can name another library (tests: a stand-in that accepts two ranks on one
+ * device); it is honoured only after pte_comm_allow_library_override(1), and a set variable WITHOUT that opt-in makes every
+ * pte_comm_* call fail (a stale variable must not silently re-route the boundary traffic). */
+int pte_comm_allow_library_override(int32_t allow);
+int pte_comm_library(char *path_out, int64_t capacity, int32_t *version_out);
 int pte_comm_unique_id(uint8_t *id_out /*PTE_COMM_ID_BYTES*/);
 int pte_comm_init(pte_engine *h, const uint8_t *id /*PTE_COMM_ID_BYTES*/);   /* ncclCommInitRank(cfg.world_size, id, cfg.rank); collective */
 int pte_comm_destroy(pte_engine *h);
@@ -258,7 +264,8 @@ int pte_get_replica_ids(const pte_engine *h, int64_t *out /*K*/);
 
 /* Measurement hooks (bench.py): per-kernel HIP-event timing accumulated on the engine's stream
  * over pte_run_scans calls since the last reset.  kernel: 0 = explore, 1 = swap; 2 = k_init (create_replicas), timed once
- * at pte_create and not touched by pte_timing_reset.
+ * at pte_create and not touched by pte_timing_reset; 3 = the boundary exchange of a chain-sharded engine (events around
+ * ncclGroupStart .. ncclGroupEnd on the engine's stream: from "messages packed" to "messages landed", one sample per even scan).
  * enable: 0 off, 1 every kernel, 2 the explore kernels only (an event pair costs ~10 us of stream time per launch). */
 int pte_timing_reset(pte_engine *h, int enable);
 int pte_timing_get(const pte_engine *h, int kernel, double *total_ms, int64_t *launches);

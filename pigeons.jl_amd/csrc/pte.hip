@@ -92,9 +92,9 @@ struct pte_engine {
     std::vector<Ev> events;
     std::vector<hipEvent_t> ev_pool;
     double init_ms = -1.0;            // duration of k_init (create_replicas), -1: not launched (Ising, TestSwapper)
-    double t_ms[2] = {0, 0};
-    int64_t t_n[2] = {0, 0};
-    std::vector<float> t_samples[2];  // per-launch durations since the last reset (spread of the timed region)
+    double t_ms[4] = {0, 0, 0, 0};    // by kind: 0 explore, 1 swap, (2 = k_init: init_ms), 3 boundary exchange (ncclGroupStart .. ncclGroupEnd)
+    int64_t t_n[4] = {0, 0, 0, 0};
+    std::vector<float> t_samples[4];  // per-launch durations since the last reset (spread of the timed region)
 };
 
 namespace {
@@ -1081,6 +1081,7 @@ int run_scans_sharded(pte_engine *h, int64_t first_scan, int64_t n_scans) {
         int32_t active[2];
         if (pte_shard_scan_begin(h, s, active)) return 1;
         if (active[0] || active[1]) {
+            time_begin(h, 3);                                // the boundary exchange as the stream sees it: pack done .. messages landed
             NCCL_OK(h, api, api->GroupStart());
             for (int sd = 0; sd < 2; ++sd) {
                 if (!active[sd]) continue;
@@ -1089,6 +1090,7 @@ int run_scans_sharded(pte_engine *h, int64_t first_scan, int64_t n_scans) {
                 NCCL_OK(h, api, api->Recv(h->msg_recv[sd], words, ncclDouble, peer, h->nccl, h->stream));
             }
             NCCL_OK(h, api, api->GroupEnd());
+            time_end(h);
         }
         if (pte_shard_scan_finish(h, s)) return 1;
     }
@@ -1096,6 +1098,17 @@ int run_scans_sharded(pte_engine *h, int64_t first_scan, int64_t n_scans) {
 }
 
 }  // namespace
+
+int pte_comm_allow_library_override(int32_t allow) { rccl_override_allowed() = allow ? 1 : 0; return 0; }
+
+int pte_comm_library(char *path_out, int64_t capacity, int32_t *version_out) {
+    std::string err;
+    RcclApi *api = rccl_api(err);
+    if (!api) return fail(nullptr, "%s", err.c_str());
+    if (path_out && capacity > 0) { std::snprintf(path_out, (size_t)capacity, "%s", api->where.c_str()); }
+    if (version_out) { int v = 0; api->GetVersion(&v); *version_out = v; }
+    return 0;
+}
 
 int pte_comm_unique_id(uint8_t *id_out) {
     if (!id_out) return fail(nullptr, "pte_comm_unique_id: null argument");
@@ -1408,13 +1421,12 @@ int pte_timing_reset(pte_engine *h, int enable) {
     hipStreamSynchronize(h->stream);
     time_collect(h);
     h->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
-    h->t_ms[0] = h->t_ms[1] = 0.0; h->t_n[0] = h->t_n[1] = 0;
-    h->t_samples[0].clear(); h->t_samples[1].clear();
+    for (int k = 0; k < 4; ++k) { h->t_ms[k] = 0.0; h->t_n[k] = 0; h->t_samples[k].clear(); }
     return 0;
 }
 int pte_timing_get_samples(const pte_engine *hc, int kernel, double *out_ms, int64_t capacity, int64_t *n_out) {
     pte_engine *h = const_cast<pte_engine *>(hc);
-    if (!h || kernel < 0 || kernel > 1 || !n_out) return 1;
+    if (!h || kernel < 0 || kernel > 3 || kernel == 2 || !n_out) return 1;
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
     time_collect(h);
@@ -1425,7 +1437,7 @@ int pte_timing_get_samples(const pte_engine *hc, int kernel, double *out_ms, int
 }
 int pte_timing_get(const pte_engine *hc, int kernel, double *total_ms, int64_t *launches) {
     pte_engine *h = const_cast<pte_engine *>(hc);
-    if (!h || kernel < 0 || kernel > 2) return 1;
+    if (!h || kernel < 0 || kernel > 3) return 1;
     if (kernel == 2) {                                  // k_init: timed once, at pte_create
         if (total_ms) *total_ms = h->init_ms < 0 ? 0.0 : h->init_ms;
         if (launches) *launches = h->init_ms < 0 ? 0 : 1;

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 
@@ -34,7 +35,12 @@ struct RcclApi {
     std::string where;
 };
 
-// Returns nullptr and fills `err` when no RCCL can be mapped.  Search order: $PTE_RCCL_LIB (explicit override), a copy
+// $PTE_RCCL_LIB names another library to take the 12 entry points from (tests hand in a stand-in that accepts two ranks on one
+// device, tests/fakerccl).  It is honoured ONLY after the host opted in with pte_comm_allow_library_override(1): a stale variable in
+// a production environment must not silently re-route the boundary traffic, so without the opt-in a set variable is an ERROR.
+inline int &rccl_override_allowed() { static int allowed = 0; return allowed; }
+
+// Returns nullptr and fills `err` when no RCCL can be mapped.  Search order: $PTE_RCCL_LIB (explicit override, opt-in only), a copy
 // already in the process (RTLD_NOLOAD by SONAME), the loader's search path, /opt/rocm/lib.
 inline RcclApi *rccl_api(std::string &err) {
     static RcclApi api;
@@ -48,6 +54,12 @@ inline RcclApi *rccl_api(std::string &err) {
     void *lib = nullptr;
     std::string where;
     const char *env = std::getenv("PTE_RCCL_LIB");
+    if (env && *env && !rccl_override_allowed()) {
+        tried = false;                                   // (not final: the host may opt in and call again)
+        err = std::string("$PTE_RCCL_LIB=") + env + " is set, but the host did not opt in to a transport override "
+              "(pte_comm_allow_library_override(1)): refusing to route the boundary exchange through it -- unset the variable to use RCCL";
+        return nullptr;
+    }
     if (env && *env) {
         lib = dlopen(env, RTLD_NOW | RTLD_LOCAL);
         where = env;
@@ -91,6 +103,14 @@ inline RcclApi *rccl_api(std::string &err) {
     if (!ok) { err = first_err; return nullptr; }
     api.lib = lib;
     api.where = where;
+    {   // the file the entry points really come from (a SONAME or "already mapped" says little)
+        Dl_info di;
+        if (dladdr(reinterpret_cast<void *>(api.CommInitRank), &di) && di.dli_fname) api.where = std::string(di.dli_fname) + (env && *env ? " (override $PTE_RCCL_LIB)" : "");
+    }
+    if (env && *env) {
+        int v = 0; api.GetVersion(&v);
+        std::fprintf(stderr, "[pte] transport OVERRIDE: ncclSend / ncclRecv taken from %s (reports version %d) instead of the process's RCCL\n", api.where.c_str(), v);
+    }
     return &api;
 }
 

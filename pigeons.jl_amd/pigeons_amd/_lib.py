@@ -61,7 +61,7 @@ EXPORTS = [
     "pte_get_stream", "pte_shard_message_bytes", "pte_shard_set_buffers", "pte_shard_scan_begin",
     "pte_shard_scan_finish", "pte_shard_sync",
     "pte_get_online_log_density", "pte_get_energy_ac1", "pte_get_traces", "pte_set_variational_reference",
-    "pte_comm_unique_id", "pte_comm_init", "pte_comm_destroy", "pte_comm_info", "pte_comm_barrier",
+    "pte_comm_allow_library_override", "pte_comm_library", "pte_comm_unique_id", "pte_comm_init", "pte_comm_destroy", "pte_comm_info", "pte_comm_barrier",
     "pte_comm_allreduce", "pte_comm_allgather", "pte_group_run_scans", "pte_kernel_name",
     "pte_set_rng_policy", "pte_get_rng_policy",
 ]
@@ -137,6 +137,8 @@ def load(path=None):
     L.pte_shard_scan_finish.argtypes = [vp, C.c_int64]
     L.pte_shard_sync.argtypes = [vp, ip]
     u8p = C.POINTER(C.c_uint8)
+    L.pte_comm_allow_library_override.argtypes = [C.c_int32]
+    L.pte_comm_library.argtypes = [C.c_char_p, C.c_int64, i32p]
     L.pte_comm_unique_id.argtypes = [u8p]
     L.pte_comm_init.argtypes = [vp, u8p]
     L.pte_comm_destroy.argtypes = [vp]

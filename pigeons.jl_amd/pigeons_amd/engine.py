@@ -316,6 +316,21 @@ def get_rng_policy(device=0):
     return int(out.value)
 
 
+def comm_allow_library_override(allow=True):
+    """Opt in to $PTE_RCCL_LIB (tests: an RCCL stand-in).  Without it a set variable makes every pte_comm_* call fail."""
+    _lib.load().pte_comm_allow_library_override(1 if allow else 0)
+
+
+def comm_library():
+    """(file the transport's entry points come from, what its ncclGetVersion reports)"""
+    L = _lib.load()
+    buf = C.create_string_buffer(1024)
+    ver = C.c_int32(0)
+    if L.pte_comm_library(buf, 1024, C.byref(ver)) != 0:
+        raise PteError(L.pte_last_error(None).decode())
+    return buf.value.decode(), int(ver.value)
+
+
 def comm_unique_id():
     """128 opaque bytes (ncclGetUniqueId) that rank 0 hands to every rank before Engine.comm_init."""
     L = _lib.load()

@@ -38,11 +38,14 @@ def test_single_gpu_line_has_the_contract_fields():
     assert len(lines) == 1
     j = json.loads(lines[0])
     assert j["metric"] == BASELINE["metric"] and j["unit"] == "replica-steps/s" and j["dtype"] == "f64"
-    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["higher_is_better"] is True and j["vs_baseline"] is None
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["higher_is_better"] is True
+    # BASELINE.md publishes no number: the ratio to the CPU baseline timed in the same run, labelled as such
+    assert abs(j["vs_baseline"] - j["value"] / j["cpu_baseline"]["value"]) < 1e-9 * j["vs_baseline"] and "not a published number" in j["vs_baseline_note"]
     assert j["scaling"] == "weak" and j["data"] == "synthetic" and "workload" in j["config"] and "model" not in j["config"]
     assert abs(j["value"] - 1024 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
     r = j["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k_explore_slice8"
+    assert r["bound"] == "instruction_issue" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k_explore_slice8"      # what binds; the HBM figures stay beside it
+    assert r["hbm_frac"] == r["frac"] and (r["frac_of_issue_floor"] is None or 0 < r["frac_of_issue_floor"] <= 1.0)
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["launches"] == 3
     assert r["algorithmic_bytes_per_launch"] == (16 * 1024 + 32) * 1024
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
@@ -52,7 +55,12 @@ def test_single_gpu_line_has_the_contract_fields():
     rt = j["round_trip"]
     assert rt["rounds"] == 4 and rt["scans_in_last_round"] == 16 and rt["global_barrier"] > 0
     # round 3: what is static says so, the instrumentation is cross-checked, the HBM-bound kernels and every BASELINE config are in the line
-    assert j["ms_per_step_without_hip_events"] > 0 and j["ms_per_step_without_hip_events"] <= j["ms_per_step"] * 1.10
+    # (two separate wall-clock passes on a box that may be shared: a sanity bound, not a tolerance)
+    assert 0 < j["ms_per_step_without_hip_events"] < 2.0 * j["ms_per_step"]
+    # a timed region under 100 ms is repeated over 256 scans, both numbers in the line
+    lr = j["long_run"]
+    assert lr["steps"] == 256 and lr["value"] > 0 and abs(lr["value"] - 1024 * 256 / (lr["ms_per_step"] * 256e-3)) < 1e-6 * lr["value"]
+    assert 0.5 * j["ms_per_step"] < lr["ms_per_step"] < 2.0 * j["ms_per_step"]
     assert r["traffic"] is None or str(r["traffic_source"]).startswith("static: profiles/")
     assert r["instruction_issue"] is None or str(r["instruction_issue"]["source"]).startswith("static: profiles/")
     h = j["hbm_kernels"]
@@ -60,6 +68,8 @@ def test_single_gpu_line_has_the_contract_fields():
         assert h[k]["avg_launch_us"] > 0 and h[k]["bytes_per_launch"] > 0 and abs(h[k]["frac_of_8TBps"] - h[k]["GBps"] / 8000.0) < 1e-12
     assert h["k_explore_toy"]["bytes_per_launch"] == (8 * 4096 + 32) * 8192
     x = j["extra_configs"]
-    assert len(x) == 5 and all(c["ms_per_scan"] > 0 and c["kernel"] for c in x)
+    assert len(x) == 6 and all(c["ms_per_scan"] > 0 and c["kernel"] for c in x) and x[0]["config"].startswith("C1 ")
     assert {c["kernel"] for c in x} >= {"k_explore_slice8", "k_explore_slice8_lds10k", "k_explore_automala", "k_explore_ising_spec"}
     assert j["config"]["chains_per_gpu"] == 1024 and j["config"]["waves_per_simd"] == 1.0
+    assert j["config"]["env_overrides"] == {k: os.environ[k] for k in ("PTE_LIB", "PTE_RCCL_LIB", "PTE_BENCH_BACKEND") if os.environ.get(k)}
+    assert j["config"]["transport_library"] is None and j["config"]["parallelism_invariant"] is None       # (single GPU)

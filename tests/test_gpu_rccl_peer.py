@@ -38,7 +38,9 @@ import numpy as np
 root, cfg, rank, world, idfile = sys.argv[1], json.loads(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
 sys.path[:0] = [root, root + "/pigeons.jl_amd", root + "/tests"]
 import pigeons_amd as P
-from pigeons_amd.engine import comm_unique_id
+from pigeons_amd.engine import comm_unique_id, comm_allow_library_override, comm_library
+comm_allow_library_override(True)          # the stand-in is honoured only after this opt-in (a stale $PTE_RCCL_LIB alone is refused)
+assert "fakerccl" in comm_library()[0], comm_library()
 
 def explorer():
     k = cfg["explorer"]
@@ -151,6 +153,12 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     assert len(c["boundary_swaps_per_rank"]) == 2 and sum(c["boundary_swaps_per_rank"]) > 0, c
     assert len(c["ms_per_step_per_rank"]) == 2 and "same_device_test_run" in c
     assert line["value"] > 0 and line["roofline"]["kernel"] == "k_explore_slice8"
+    # round 4: the first line of a multi-GPU run says which library carried the messages, that the G-rank run is bit-identical to one
+    # engine on this transport, what a boundary exchange costs on the stream, and which environment overrides were in effect
+    assert "fakerccl" in c["transport_library"]["path"] and c["env_overrides"]["PTE_RCCL_LIB"] == fake
+    assert c["parallelism_invariant"] is True
+    be = c["boundary_exchange"]
+    assert be["samples"] >= 4 and be["us_min_median_max"][0] > 0 and be["message_bytes_per_side"] == 8 * (1024 + 8)
 
 
 def test_bench_strong_scaling_two_ranks_on_one_device():
@@ -167,3 +175,19 @@ def test_bench_strong_scaling_two_ranks_on_one_device():
     assert line["scaling"] == "strong" and line["n_gpus"] == 2 and c["n_ranks_seen"] == 2 and c["chains_per_gpu"] == 4096
     assert line["roofline"]["kernel"] == "k_explore_slice8_lds10k" and "FALLBACK" not in c["sharding"]
     assert abs(line["value"] - 8192 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-6 * line["value"]
+
+
+def test_rccl_override_needs_the_opt_in():
+    """$PTE_RCCL_LIB alone must not re-route the transport: without pte_comm_allow_library_override(1) every pte_comm_* call fails loudly."""
+    fake = build_fakerccl()
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "from pigeons_amd.engine import comm_unique_id, comm_library, comm_allow_library_override\n"
+            "from pigeons_amd import PteError\n"
+            "try:\n    comm_unique_id(); print('NOT REFUSED')\n"
+            "except PteError as e:\n    print('refused:', e)\n"
+            "comm_allow_library_override(True); print('lib', comm_library())\n") % (ROOT, os.path.join(ROOT, "pigeons.jl_amd"))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PTE_RCCL_LIB=fake), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "refused:" in p.stdout and "did not opt in" in p.stdout and "NOT REFUSED" not in p.stdout, p.stdout
+    assert "fakerccl" in p.stdout.split("lib", 1)[1], p.stdout
+    assert "transport OVERRIDE" in p.stderr                      # ... and an override in effect says so on stderr
