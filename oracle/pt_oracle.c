@@ -128,6 +128,21 @@ void po_zig_install(int which, const void *in) {
     void *dst[6] = { ZIG_KI, ZIG_WI, ZIG_FI, ZIG_KE, ZIG_WE, ZIG_FE };
     if (which >= 0 && which < 6) memcpy(dst[which], in, 256 * 8);
 }
+/* Sensitivity hook (tests only, tests/test_gpu_benchmarked_shapes.py): exp / log of the Langevin family -- the funnel density and the
+ * AutoMALA / MALA bounds and acceptance ratios -- nudged by one ulp: 0 as libm returns them, 1 one ulp up, 2 one ulp down, 3 up and
+ * down alternating per call.  glibc (here) and ocml (device) exp / log are both within an ulp of the truth but not bit-identical; the
+ * test shows that the device's residual against this oracle at BASELINE configs[2] lies inside the band this nudge opens. */
+static int g_libm_nudge = 0;
+static _Thread_local unsigned g_libm_calls = 0;
+int po_set_libm_nudge(int mode) { if (mode < 0 || mode > 3) return 1; g_libm_nudge = mode; return 0; }
+static inline double libm_nudge(double v) {
+    if (g_libm_nudge == 0 || !isfinite(v)) return v;
+    const int up = g_libm_nudge == 1 || (g_libm_nudge == 3 && ((g_libm_calls++) & 1u));
+    return nextafter(v, up ? INFINITY : -INFINITY);
+}
+static inline double po_exp(double x) { return libm_nudge(exp(x)); }
+static inline double po_log(double x) { return libm_nudge(log(x)); }
+
 int po_set_rng_policy(uint32_t policy) {
     if (policy & ~PTE_RNG_POLICY_VALID_MASK) return 1;
     g_rng_policy = policy;
@@ -531,8 +546,8 @@ static double funnel_lp_grad(const double *z, int64_t d, double *g, double *term
     const double y = z[0];
     const double zv = y / 3.0;
     terms[0] = -(zv * zv + PO_LOG2PI) / 2.0 - log(3.0);
-    const double sigma = exp(y / 2.0);
-    const double logsigma = log(sigma);
+    const double sigma = po_exp(y / 2.0);
+    const double logsigma = po_log(sigma);
     for (int64_t i = 1; i < d; i++) {
         double zi = z[i] / sigma;
         terms[i] = -(zi * zi + PO_LOG2PI) / 2.0 - logsigma;
@@ -932,7 +947,7 @@ static int mala_step(po_pt *pt, po_replica *r) {
         if (!isfinite(init_joint_log)) { fail(pt, "MALA can only be called on a configuration of positive density."); return 1; }
         am_leap_frog(&a, cfg->am_step_size);
         for (int64_t i = 0; i < d; i++) a.momentum[i] = a.momentum[i] * -1.0;
-        const double e = exp(am_log_joint(&a) - init_joint_log);
+        const double e = po_exp(am_log_joint(&a) - init_joint_log);
         double probability = e < 1.0 ? e : 1.0;
         if (isnan(e)) probability = e;
         mean_fit(&r->rec.expl_acc[a.chain], probability);
@@ -956,7 +971,7 @@ static int automala_step(po_pt *pt, po_replica *r) {
         const double init_joint_log = am_log_joint(&a);
         if (!isfinite(init_joint_log)) { fail(pt, "AutoMALA can only be called on a configuration of positive density."); return 1; }
         double ua = po_rand(&r->rng), ub = po_rand(&r->rng);
-        double lower = log(ua < ub ? ua : ub), upper = log(ua < ub ? ub : ua);
+        double lower = po_log(ua < ub ? ua : ub), upper = po_log(ua < ub ? ub : ua);
         int proposed_exponent, reversed_exponent;
         if (am_auto_step_size(&a, pt->step_size, lower, upper, &proposed_exponent)) return 1;
         const double proposed_step_size = pt->step_size * ldexp(1.0, proposed_exponent);
@@ -969,7 +984,7 @@ static int automala_step(po_pt *pt, po_replica *r) {
             double probability = 0.0;
             if (passed) {
                 double final_joint_log = am_log_joint(&a);
-                double e = exp(final_joint_log - init_joint_log);
+                double e = po_exp(final_joint_log - init_joint_log);
                 probability = e < 1.0 ? e : 1.0;      /* min(1.0, NaN) is NaN in Julia; rand < NaN is false either way */
                 if (isnan(e)) probability = e;
             }

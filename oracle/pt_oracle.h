@@ -39,6 +39,7 @@ void     po_zig_table(int which, void *out /*256 x 8 bytes*/);
 void     po_zig_install(int which, const void *in /*256 x 8 bytes*/);
 /* include/pte_rng_policy.h: process-wide; returns != 0 on an invalid policy */
 int      po_set_rng_policy(uint32_t policy);
+int      po_set_libm_nudge(int mode);        /* tests only: exp / log of the Langevin family one ulp up (1), down (2), alternating (3) */
 uint32_t po_get_rng_policy(void);
 
 /* ---- numerics ------------------------------------------------------------ */

@@ -215,6 +215,15 @@ def zig_table(name, derived=False):
     return out
 
 
+def set_libm_nudge(mode):
+    """tests only: exp / log of the Langevin family as libm returns them (0), one ulp up (1), down (2), alternating per call (3)"""
+    L = lib()
+    L.po_set_libm_nudge.restype = C.c_int
+    L.po_set_libm_nudge.argtypes = [C.c_int]
+    if L.po_set_libm_nudge(int(mode)) != 0:
+        raise ValueError("invalid libm nudge %r" % (mode,))
+
+
 def set_rng_policy(policy):
     if lib().po_set_rng_policy(policy) != 0:
         raise ValueError("invalid rng policy %r" % (policy,))

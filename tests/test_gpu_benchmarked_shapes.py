@@ -65,8 +65,60 @@ def test_config3_full_size_against_the_oracle(P):
     # or two out of 1024 (measured: 2 chains, 3.2e-6); likewise 2 of the 131,072 state coordinates, of magnitude 4e-3 in replicas
     # whose other coordinates are O(1), differ by 1.1e-7 absolute after 14 scans of leapfrog steps (states are not a recorder: the
     # test asks 1e-6 of the replica's scale there).  Every integer, the swap recorders and the schedule stay at 1e-6 relative.
+    # The cause is demonstrated, not only stated, by test_config3_residual_is_one_ulp_of_exp_and_log below.
     for _ in range(3):
         _check_am_round(P, pt, ref, rtol=1e-6, acc_rtol=1e-5, state_atol=1e-6)
+
+
+def test_config3_residual_is_one_ulp_of_exp_and_log(P):
+    """Why BASELINE configs[2] at full size needs acc_rtol = 1e-5 / state_atol = 1e-6 in round 3 (the test above), shown instead of asserted:
+    the oracle's OWN exp / log nudged by one ulp (po_set_libm_nudge: up, down, alternating -- glibc and ocml both err by less than that,
+    differently) moves exactly these outputs by exactly this much and nothing else.  Per round, four oracle runs and the device:
+      * every integer (index process, leapfrog counts, RNG counters, chains) is the same in all five;
+      * rounds 1-2: the device agrees with the plain oracle to 1e-9 everywhere;
+      * round 3: wherever the device leaves the 1e-9 band -- a few chains' mean MH acceptance, a few hundred state coordinates in the
+        funnel's neck -- its residual is no larger than the spread the nudged oracles show among themselves (x2 for the head-room of three samples)."""
+    N, d, rounds = 1024, 128, 3
+    runs = {}
+    try:
+        for mode in (0, 1, 2, 3):
+            O.set_libm_nudge(mode)
+            ref = O.OraclePT(n_chains=N, dim=d, seed=1, explorer=O.EXPLORER_AUTOMALA, target=O.TARGET_FUNNEL, p0=1.0 / 9.0, am_preconditioner=2,
+                             n_threads=_threads())
+            out = []
+            for _ in range(rounds):
+                ref.run_round()
+                am, an, ss, sn = ref.explorer_stats()
+                x, chain, rng = ref.states()
+                out.append(dict(index=ref.index_process().copy(), steps=np.array(ss).copy(), steps_n=np.array(sn).copy(), acc=np.array(am).copy(),
+                                acc_n=np.array(an).copy(), swap=np.array(ref.swap_pr()[0]).copy(), sched=np.array(ref.schedule()).copy(),
+                                x=x.copy(), chain=chain.copy(), rng=rng.copy()))
+            runs[mode] = out
+    finally:
+        O.set_libm_nudge(0)
+    pt, _ = _mk_am(P, N, d, rounds, "funnel", seed=1)
+    for r in range(rounds):
+        assert P.next_round(pt)
+        red = P.run_one_round(pt); P.adapt(pt, red)
+        x, chain, rng = pt.replicas.states()
+        base = runs[0][r]
+        for mode in (1, 2, 3):                                      # the nudge moves no integer
+            o = runs[mode][r]
+            assert all(np.array_equal(o[k], base[k]) for k in ("index", "steps", "steps_n", "acc_n", "chain", "rng")), (r, mode)
+        assert np.array_equal(red.index_process, base["index"]) and np.array_equal(chain, base["chain"]) and np.array_equal(rng, base["rng"])
+        assert np.array_equal(red.explorer_n_steps[0], base["steps"]) and np.array_equal(red.explorer_acceptance_pr[1], base["acc_n"])
+        rel = lambda a, b: np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
+        band_acc = max(rel(runs[m][r]["acc"], base["acc"]).max() for m in (1, 2, 3))
+        band_x = max(np.abs(runs[m][r]["x"] - base["x"]).max() for m in (1, 2, 3))
+        dev_acc = rel(red.explorer_acceptance_pr[0], base["acc"]).max()
+        dev_x = np.abs(x - base["x"]).max()
+        np.testing.assert_allclose(red.swap_acceptance_pr[0], base["swap"], rtol=1e-6, atol=1e-300)
+        np.testing.assert_allclose(pt.shared.tempering.schedule.grids, base["sched"], rtol=1e-6)
+        if r < 2:
+            assert dev_acc < 1e-9 and dev_x < 1e-9, (r, dev_acc, dev_x)
+        else:
+            assert band_acc > 1e-7 and band_x > 1e-8, (band_acc, band_x)        # the sensitivity is real: one ulp opens a band five to six orders above it
+            assert dev_acc <= 2.0 * band_acc and dev_x <= 2.0 * band_x, (dev_acc, band_acc, dev_x, band_x)
 
 
 def test_toy_explorer_hbm_shape_against_the_oracle(P):
