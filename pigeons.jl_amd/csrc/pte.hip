@@ -1272,13 +1272,20 @@ const char *pte_kernel_name(const pte_engine *h) {
     switch (h->cfg.explorer) {
     case PTE_EXPLORER_TOY: return "k_explore_toy";
     case PTE_EXPLORER_SLICE:
-        if (h->cfg.target == PTE_TARGET_FUNNEL) return "k_explore_automala";      // its SliceSampler instantiation
+        // The register-resident Langevin-family kernel keeps a replica's eight vectors in VGPRs: 16 coordinates per lane (d > 512) is past
+        // what the register file holds -- those instantiations spill (316-364 VGPRs to scratch, profiles/r04_kernel_resources.txt) and run
+        // at one wave per SIMD.  They are correct (held to the oracle at every layout) and UNOPTIMISED: the name says so, and no quoted
+        // number uses them (BASELINE configs[2] is d = 128).
+        if (h->cfg.target == PTE_TARGET_FUNNEL) return h->d > 512 ? "k_explore_automala [d > 512: unoptimised, spills to scratch]" : "k_explore_automala";      // its SliceSampler instantiation
         switch (h->slice_impl) {
         case 1: return "k_explore_slice"; case 2: return "k_explore_slice2"; case 5: return "k_explore_slice5";
         case 7: return "k_explore_slice7";
-        default: return h->K <= PTE_S8_TWIN_FROM ? "k_explore_slice8" : "k_explore_slice8_lds10k";
+        default:
+            if (h->K > PTE_S8_TWIN_FROM) return "k_explore_slice8_lds10k";
+            return (h->cfg.slice_p > PTE_S8_BD && h->cfg.slice_p <= 20 && h->cfg.slice_max_iter >= PTE_S8_BS) ? "k_explore_slice8" : "k_explore_slice8_generic";
         }
-    case PTE_EXPLORER_AUTOMALA: case PTE_EXPLORER_MALA: return "k_explore_automala";
+    case PTE_EXPLORER_AUTOMALA: case PTE_EXPLORER_MALA:
+        return h->d > 512 ? "k_explore_automala [d > 512: unoptimised, spills to scratch]" : "k_explore_automala";
     case PTE_EXPLORER_ISING_METROPOLIS: {
         const int64_t L = (int64_t)std::llround(std::sqrt((double)h->d));
         return (L % 32 == 0 && h->ising_impl == 0) ? "k_explore_ising_spec" : (L % 32 == 0 && h->ising_impl == 1) ? "k_explore_ising_bits" : "k_explore_ising";

@@ -42,12 +42,15 @@ constexpr int S8_BD = PTE_S8_BD;                 // doubling budget of a specula
 #ifndef PTE_S8_WAVES                     // occupancy hint to the register allocator (waves per SIMD)
 #define PTE_S8_WAVES 4
 #endif
-// The body is shared by two kernels that differ in the size of the LDS draw window: 512 draws convert fewer draws twice
-// (1.2 % faster), 256 draws keep the block at 10 KB of LDS when a GPU holds more than ~2800 replicas.  Register use is
-// ~145 VGPRs whatever the hint says (the hand-scheduled shrinkage block pins v96-v113), i.e. 3 resident waves per SIMD,
-// 12 replicas per CU; forcing 128 VGPRs (amdgpu_num_vgpr: 4 waves per SIMD, 36 B of scratch per lane) was measured at
-// 3072 / 4096 / 8192 replicas and changes nothing (1.875 / 2.318 / 4.250 against 1.877 / 2.316 / 4.252 ms): three waves
-// already saturate a SIMD's issue slots.
+// The body is shared by the kernels below, which differ in the size of the LDS draw window and in the form of the doubling steps:
+// 512 draws convert fewer draws twice (1.2 % faster), 256 draws keep the block at 10 KB of LDS when a GPU holds more than ~2800 replicas.
+// The 512-draw kernel needs ~145 VGPRs whatever the occupancy hint says (the hand-scheduled blocks pin v96-v123): 3 resident waves per SIMD,
+// all its LDS allows.  The many-replica twin is CAPPED at 128 VGPRs by amdgpu_waves_per_eu(4, 4) and spills up to 16 VGPRs at the deeper
+// trees (12-20 B of scratch per lane at d >= 1024, profiles/r04_kernel_resources.txt; 14-20 VGPRs in round 3); the capped, spilling build is the FASTER one (round 3 A/B at N = 3072 / 4096 / 8192: 1.868 /
+// 2.311 / 4.211 ms against 1.864 / 2.500 / 4.448 ms with three waves per SIMD and no spill, profiles/r03_twin_kernel_ab.txt).
+// None of the spills of either kernel is executed per round: the round loop of k_explore_slice8<4, 9> holds no v_writelane and no
+// spill reload (profiles/r04_slice8_round_loop.txt lists every lane instruction of the loop: the five of the chase) -- the 134 spilled
+// SGPRs of the resource table live in the prologue, the window refill and the exact sequential procedure.
 template <int NLU, int S8_BS, int WINDOW, int DBL_MODE>      // DBL_MODE: form of the budgeted doubling steps (0 selects, 1 EXEC masks, 2 v_cmpx + selects)
 __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
     using namespace s7;
