@@ -167,11 +167,11 @@ def cpu_baseline(d, target_seconds=12.0):
 
 def hbm_kernels(P):
     """The kernels the HBM roofline applies to, untimed for the headline: ToyExplorer at N = 8192, d = 4096 (256 MiB of
-    state).  Durations are HIP events on the engine's stream in THIS run (pte_timing_*; k_init is timed at pte_create: three constructions, the fastest reported);
+    state).  Durations are HIP events carried by the launch itself (hipExtLaunchKernelGGL: the kernel's own begin and end, what rocprofv3's kernel trace reports) in THIS run (pte_timing_*; k_init is timed at pte_create: five constructions, the fastest reported);
     bytes are algorithmic: k_explore_toy / k_init write 8 d + 32 B per replica, k_swap moves 96 B per replica."""
     N, d = 8192, 4096
     init_all = []
-    for _ in range(3):                                   # k_init runs once per pte_create: three constructions, the first one cold
+    for _ in range(5):                                   # k_init runs once per pte_create: five constructions (the first one cold, fresh allocations first-touched)
         pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=8, record=[P.round_trip, P.log_sum_ratio], show_report=False))
         e = pt.replicas
         init_all.append(e.timing(2)[0])
@@ -187,7 +187,7 @@ def hbm_kernels(P):
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         out[name] = {"bytes_per_launch": nbytes, "avg_launch_us": ms * 1e3, "GBps": gbs,
                      "frac_of_6.29TBps": gbs / HBM_ACHIEVABLE_GBS, "frac_of_8TBps": gbs / HBM_PEAK_GBS}
-    out["k_init"]["launch_us_of_3_constructions"] = [m * 1e3 for m in init_all]      # (avg_launch_us is their minimum: the first is a cold launch)
+    out["k_init"]["launch_us_of_5_constructions"] = [m * 1e3 for m in init_all]      # (avg_launch_us is their minimum: the first is a cold launch)
     e.timing_reset(False)
     return out
 

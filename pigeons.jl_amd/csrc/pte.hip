@@ -2,6 +2,7 @@
 // Owns device memory, one HIP stream per engine, launches the kernels of pte_kernels.hpp.
 // There is no CPU fallback: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -92,6 +93,7 @@ struct pte_engine {
     std::vector<Ev> events;
     std::vector<hipEvent_t> ev_pool;
     double init_ms = -1.0;            // duration of k_init (create_replicas), -1: not launched (Ising, TestSwapper)
+    bool ev_ext = false, ev_ext_done = false;   // the open bracket's events ride on its ONE kernel launch (PTE_LAUNCH1)
     double t_ms[4] = {0, 0, 0, 0};    // by kind: 0 explore, 1 swap, (2 = k_init: init_ms), 3 boundary exchange (ncclGroupStart .. ncclGroupEnd)
     int64_t t_n[4] = {0, 0, 0, 0};
     std::vector<float> t_samples[4];  // per-launch durations since the last reset (spread of the timed region)
@@ -122,40 +124,51 @@ int dev_alloc(pte_engine *h, T **p, size_t n, bool zero = true) {
 
 int next_pow2_log(int64_t n) { int l = 0; while (((int64_t)1 << l) < n) ++l; return l; }
 
+// One kernel launch that may carry the timing events of the bracket it stands in (time_begin(h, kind, true) ... time_end(h)): with
+// hipExtLaunchKernelGGL the start / stop events take the kernel's own begin / end timestamps -- what rocprofv3's kernel trace reports --
+// instead of bracketing it with two event-record commands, which add the stream's hand-over time around a ~85 us kernel (~7 us).
+#define PTE_LAUNCH1(KERNEL, grid, block, shmem, stream, ...)                                                                      \
+    do {                                                                                                                          \
+        if (h->ev_open && h->ev_ext && !h->ev_ext_done) {                                                                         \
+            hipExtLaunchKernelGGL(KERNEL, grid, block, shmem, stream, h->events.back().a, h->events.back().b, 0, __VA_ARGS__);    \
+            h->ev_ext_done = true;                                                                                                \
+        } else hipLaunchKernelGGL(KERNEL, grid, block, shmem, stream, __VA_ARGS__);                                               \
+    } while (0)
+
 #ifdef PTE_DEV_FEW_NLU   // development builds only (tools/build_variant.sh): the tree depths of d = 1024 and d = 4096, a fifth of the compile time
 #define DISPATCH_NLU_M(nlu, KERNEL, MM, grid, block, stream, ...)                                 \
     switch (nlu) {                                                                               \
-    case 4: hipLaunchKernelGGL((KERNEL<4, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
-    case 6: hipLaunchKernelGGL((KERNEL<6, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    case 4: PTE_LAUNCH1((KERNEL<4, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    case 6: PTE_LAUNCH1((KERNEL<6, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
     default: fprintf(stderr, "PTE_DEV_FEW_NLU build: d must be 1024 or 4096\n"); abort();        \
     }
 #define DISPATCH_NLU(nlu, KERNEL, grid, block, stream, ...)                                      \
     switch (nlu) {                                                                               \
-    case 4: hipLaunchKernelGGL(KERNEL<4>, grid, block, 0, stream, __VA_ARGS__); break;           \
-    case 6: hipLaunchKernelGGL(KERNEL<6>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    case 4: PTE_LAUNCH1(KERNEL<4>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    case 6: PTE_LAUNCH1(KERNEL<6>, grid, block, 0, stream, __VA_ARGS__); break;           \
     default: fprintf(stderr, "PTE_DEV_FEW_NLU build: d must be 1024 or 4096\n"); abort();        \
     }
 #else
 #define DISPATCH_NLU_M(nlu, KERNEL, MM, grid, block, stream, ...)                                 \
     switch (nlu) {                                                                               \
-    case 0: hipLaunchKernelGGL((KERNEL<0, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
-    case 1: hipLaunchKernelGGL((KERNEL<1, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
-    case 2: hipLaunchKernelGGL((KERNEL<2, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
-    case 3: hipLaunchKernelGGL((KERNEL<3, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
-    case 4: hipLaunchKernelGGL((KERNEL<4, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
-    case 5: hipLaunchKernelGGL((KERNEL<5, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
-    default: hipLaunchKernelGGL((KERNEL<6, MM>), grid, block, 0, stream, __VA_ARGS__); break;    \
+    case 0: PTE_LAUNCH1((KERNEL<0, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    case 1: PTE_LAUNCH1((KERNEL<1, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    case 2: PTE_LAUNCH1((KERNEL<2, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    case 3: PTE_LAUNCH1((KERNEL<3, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    case 4: PTE_LAUNCH1((KERNEL<4, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    case 5: PTE_LAUNCH1((KERNEL<5, MM>), grid, block, 0, stream, __VA_ARGS__); break;     \
+    default: PTE_LAUNCH1((KERNEL<6, MM>), grid, block, 0, stream, __VA_ARGS__); break;    \
     }
 
 #define DISPATCH_NLU(nlu, KERNEL, grid, block, stream, ...)                                      \
     switch (nlu) {                                                                               \
-    case 0: hipLaunchKernelGGL(KERNEL<0>, grid, block, 0, stream, __VA_ARGS__); break;           \
-    case 1: hipLaunchKernelGGL(KERNEL<1>, grid, block, 0, stream, __VA_ARGS__); break;           \
-    case 2: hipLaunchKernelGGL(KERNEL<2>, grid, block, 0, stream, __VA_ARGS__); break;           \
-    case 3: hipLaunchKernelGGL(KERNEL<3>, grid, block, 0, stream, __VA_ARGS__); break;           \
-    case 4: hipLaunchKernelGGL(KERNEL<4>, grid, block, 0, stream, __VA_ARGS__); break;           \
-    case 5: hipLaunchKernelGGL(KERNEL<5>, grid, block, 0, stream, __VA_ARGS__); break;           \
-    default: hipLaunchKernelGGL(KERNEL<6>, grid, block, 0, stream, __VA_ARGS__); break;          \
+    case 0: PTE_LAUNCH1(KERNEL<0>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    case 1: PTE_LAUNCH1(KERNEL<1>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    case 2: PTE_LAUNCH1(KERNEL<2>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    case 3: PTE_LAUNCH1(KERNEL<3>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    case 4: PTE_LAUNCH1(KERNEL<4>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    case 5: PTE_LAUNCH1(KERNEL<5>, grid, block, 0, stream, __VA_ARGS__); break;           \
+    default: PTE_LAUNCH1(KERNEL<6>, grid, block, 0, stream, __VA_ARGS__); break;          \
     }
 
 #endif
@@ -234,22 +247,24 @@ int check_device_error(pte_engine *h) {
 }
 
 // h->timing: 0 off, 1 every kernel, 2 the explore kernels only (an event pair costs ~10 us of stream time per launch)
-void time_begin(pte_engine *h, int kernel) {
-    h->ev_open = false;
+// on_launch: the bracket holds exactly ONE kernel launch, written with PTE_LAUNCH1 / DISPATCH_NLU*, which then carries the events
+void time_begin(pte_engine *h, int kernel, bool on_launch = false) {
+    h->ev_open = false; h->ev_ext = false; h->ev_ext_done = false;
     if (!h->timing || (h->timing == 2 && kernel != 0)) return;
     pte_engine::Ev ev; ev.kernel = kernel;
     if (h->ev_pool.size() >= 2) {
         ev.a = h->ev_pool.back(); h->ev_pool.pop_back();
         ev.b = h->ev_pool.back(); h->ev_pool.pop_back();
     } else { hipEventCreate(&ev.a); hipEventCreate(&ev.b); }
-    hipEventRecord(ev.a, h->stream);
+    if (!on_launch) hipEventRecord(ev.a, h->stream);
     h->events.push_back(ev);
-    h->ev_open = true;
+    h->ev_open = true; h->ev_ext = on_launch;
 }
 void time_end(pte_engine *h) {
     if (!h->ev_open) return;
-    hipEventRecord(h->events.back().b, h->stream);
-    h->ev_open = false;
+    if (h->ev_ext && !h->ev_ext_done) hipEventRecord(h->events.back().a, h->stream);      // (no launch took them: an empty bracket)
+    if (!(h->ev_ext && h->ev_ext_done)) hipEventRecord(h->events.back().b, h->stream);
+    h->ev_open = false; h->ev_ext = false;
 }
 void time_collect(pte_engine *h) {
     for (auto &ev : h->events) {
@@ -286,7 +301,7 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
     switch (kind) {
     case PTE_EXPLORER_NONE: return 0;
     case PTE_EXPLORER_TOY:
-        time_begin(h, 0);
+        time_begin(h, 0, true);
         DISPATCH_NLU(h->nlu, k_explore_toy, dim3((unsigned)((N + NRM_WPB - 1) / NRM_WPB)), dim3(64 * NRM_WPB), h->stream, h->dev);
         time_end(h);
         break;
@@ -299,16 +314,16 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
             ap.slice_max_iter = h->cfg.slice_max_iter;
             ap.ref_prec = h->cfg.target_params[0]; ap.log3 = std::log(3.0);
             const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
-            time_begin(h, 0);
+            time_begin(h, 0, true);
 #ifdef PTE_DEV_NO_LANGEVIN
             return fail(h, "PTE_DEV_NO_LANGEVIN build");
 #else
             switch (E) {
-            case 1: hipLaunchKernelGGL((k_explore_automala<1, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
-            case 2: hipLaunchKernelGGL((k_explore_automala<2, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
-            case 4: hipLaunchKernelGGL((k_explore_automala<4, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
-            case 8: hipLaunchKernelGGL((k_explore_automala<8, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
-            default: hipLaunchKernelGGL((k_explore_automala<16, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
+            case 1: PTE_LAUNCH1((k_explore_automala<1, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
+            case 2: PTE_LAUNCH1((k_explore_automala<2, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
+            case 4: PTE_LAUNCH1((k_explore_automala<4, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
+            case 8: PTE_LAUNCH1((k_explore_automala<8, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
+            default: PTE_LAUNCH1((k_explore_automala<16, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
             }
 #endif
             time_end(h);
@@ -316,7 +331,7 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
         }
         {
         SliceParams sp{h->cfg.slice_w, h->cfg.slice_p, h->cfg.slice_n_passes, h->cfg.slice_max_iter};
-        time_begin(h, 0);
+        time_begin(h, 0, true);
         if (h->slice_impl == 1) {          // PTE_KERNEL_SLICE_SEQUENTIAL: the plain sequential kernel (exact fallback, bisecting)
             DISPATCH_NLU(h->nlu, k_explore_slice, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_impl == 8) {
@@ -352,13 +367,13 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
         ap.ref_prec = h->cfg.target_params[0]; ap.log3 = std::log(3.0);
         const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
         const bool fun = h->cfg.target == PTE_TARGET_FUNNEL;
-        time_begin(h, 0);
+        time_begin(h, 0, true);
         const bool full = h->d == 64 * (int64_t)E;       // no ragged last block: the instantiation without per-lane validity masks
 #define AM_LAUNCH(EE)                                                                                         \
-        if (fun && full) hipLaunchKernelGGL((k_explore_automala<EE, TGT_FUNNEL, false, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
-        else if (fun) hipLaunchKernelGGL((k_explore_automala<EE, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
-        else if (full) hipLaunchKernelGGL((k_explore_automala<EE, TGT_MVN, false, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
-        else hipLaunchKernelGGL((k_explore_automala<EE, TGT_MVN>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap);
+        if (fun && full) PTE_LAUNCH1((k_explore_automala<EE, TGT_FUNNEL, false, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
+        else if (fun) PTE_LAUNCH1((k_explore_automala<EE, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
+        else if (full) PTE_LAUNCH1((k_explore_automala<EE, TGT_MVN, false, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
+        else PTE_LAUNCH1((k_explore_automala<EE, TGT_MVN>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap);
 #ifdef PTE_DEV_NO_LANGEVIN      // development builds only (tools/build_variant.sh): three quarters of the compile time are these instantiations
         (void)fun; (void)full; return fail(h, "PTE_DEV_NO_LANGEVIN build");
 #else
@@ -371,16 +386,16 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
     }
     case PTE_EXPLORER_ISING_METROPOLIS: {
         IsingParams ip{(int)std::llround(std::sqrt((double)h->d)), h->cfg.slice_n_passes, h->cfg.target_params[0]};
-        time_begin(h, 0);
+        time_begin(h, 0, true);
         // L % 32 == 0: lane-speculative bit-packed sweep; other lattice sizes: the scalar byte-lattice kernel
         if (ip.L % 32 == 0 && h->ising_impl == 0)
-            hipLaunchKernelGGL(k_explore_ising_spec, dim3((unsigned)N), dim3(64), (size_t)(h->d / 8), h->stream, h->dev, ip);
+            PTE_LAUNCH1(k_explore_ising_spec, dim3((unsigned)N), dim3(64), (size_t)(h->d / 8), h->stream, h->dev, ip);
 #ifdef PTE_TEST_KERNELS
         else if (ip.L % 32 == 0 && h->ising_impl == 1)
-            hipLaunchKernelGGL(k_explore_ising_bits, dim3((unsigned)N), dim3(64), (size_t)(h->d / 8), h->stream, h->dev, ip);
+            PTE_LAUNCH1(k_explore_ising_bits, dim3((unsigned)N), dim3(64), (size_t)(h->d / 8), h->stream, h->dev, ip);
 #endif
         else
-            hipLaunchKernelGGL(k_explore_ising, dim3((unsigned)N), dim3(64), (size_t)h->d, h->stream, h->dev, ip);
+            PTE_LAUNCH1(k_explore_ising, dim3((unsigned)N), dim3(64), (size_t)h->d, h->stream, h->dev, ip);
         time_end(h);
         break;
     }
@@ -398,8 +413,8 @@ int launch_swap(pte_engine *h, int64_t scan) {
     if (h->world != 1) return fail(h, "pte_swap / pte_run_scans need world_size == 1; sharded engines use pte_swap_begin / pte_swap_finish");
     const int even = (scan % 2 == 0) ? 1 : 0;          // create_swap_graph(::DEO), DEO.jl:12
     const unsigned block = 256, grid = (unsigned)((N + block - 1) / block);
-    time_begin(h, 1);
-    hipLaunchKernelGGL(k_swap, dim3(grid), dim3(block), 0, h->stream, h->dev, even, h->scans_in_round);
+    time_begin(h, 1, true);
+    PTE_LAUNCH1(k_swap, dim3(grid), dim3(block), 0, h->stream, h->dev, even, h->scans_in_round);
     time_end(h);
     HIP_OK(h, hipGetLastError());
     h->scans_in_round += 1;
@@ -599,9 +614,12 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     hipEvent_t init_a = nullptr, init_b = nullptr;       // k_init's duration: pte_timing_get(kernel = 2), one event pair per engine
     if (!ising) {
         hipEventCreate(&init_a); hipEventCreate(&init_b);
-        hipEventRecord(init_a, h->stream);
-        DISPATCH_NLU(h->nlu, k_init, dim3((unsigned)((K + NRM_WPB - 1) / NRM_WPB)), dim3(64 * NRM_WPB), h->stream, e, (uint64_t)cfg->seed, init_sd);
-        hipEventRecord(init_b, h->stream);
+        {   // the events ride on the launch (PTE_LAUNCH1): the kernel's own begin / end
+            pte_engine::Ev ev; ev.a = init_a; ev.b = init_b; ev.kernel = 2;
+            h->events.push_back(ev); h->ev_open = true; h->ev_ext = true; h->ev_ext_done = false;
+            DISPATCH_NLU(h->nlu, k_init, dim3((unsigned)((K + NRM_WPB - 1) / NRM_WPB)), dim3(64 * NRM_WPB), h->stream, e, (uint64_t)cfg->seed, init_sd);
+            h->events.pop_back(); h->ev_open = false; h->ev_ext = false;
+        }
     }
     else {
         std::vector<int32_t> ch((size_t)K), sl((size_t)K); std::vector<int64_t> rid((size_t)K);
