@@ -1066,12 +1066,16 @@ def test_checkpoint_without_a_folder_gets_the_reference_default(P, tmp_path, mon
 
 @pytest.mark.parametrize("impl", [1, 0])
 def test_slice_parameters_off_the_defaults(P, impl):
-    """w, p, n_passes away from the defaults (small p / w exercise the doubling budget and the exact path)."""
-    for w, p, n_passes in [(0.5, 1, 2), (2.0, 3, 1), (30.0, 20, 2)]:
+    """w, p, n_passes away from the defaults (small p / w exercise the doubling budget and the exact path).  Since round 4 the default
+    kernel has two instantiations: the one for the default parameter range (3 < p <= 20, max_iter >= 9) and the generic one -- both are in
+    the list, and a p between them (4: the FAST one with the doubling limit right behind the speculative budget)."""
+    for w, p, n_passes in [(0.5, 1, 2), (2.0, 3, 1), (30.0, 20, 2), (0.3, 4, 2), (0.5, 25, 1)]:
         N, d, rounds = 5, 20, 4
         rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.online]
         pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=P.SliceSampler(w=w, p=p, n_passes=n_passes),
                            record=rec, show_report=False), debug_kernel=impl)
+        if impl == 0:
+            assert pt.replicas.kernel_name() == ("k_explore_slice8" if 3 < p <= 20 else "k_explore_slice8_generic")
         ref = O.OraclePT(n_chains=N, dim=d, explorer=O.EXPLORER_SLICE, record_online=1, slice_w=w, slice_p=p, slice_n_passes=n_passes)
         for _ in range(rounds):
             _check_round(P, pt, ref)
