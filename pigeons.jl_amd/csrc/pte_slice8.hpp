@@ -123,6 +123,11 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
     if (nhp * S == -INFINITY) { if (lane == 0) set_error(e, ERR_SLICE_SUPPORT, (int)c, -1); return; }
 
     // ---- the stream window: s_u[i], s_e[i] = draw #i after `wseed`
+    // (Round 4 built a window that resolves the ziggurat's slow-path exponentials when it is FILLED and keeps, per stream position, the whole
+    // head of a coordinate starting there -- exponential, the extra draws its slow path consumed, the uniforms behind them: 48 B per position,
+    // one LDS round trip as before, every hypothesis passes a slow-path exponential (7 % of the rounds end at one), no per-round test for
+    // lane 0's.  Bit-identical, 3.2 % fewer rounds (4.01 -> 4.14 coordinates per round) -- and 3 % SLOWER, 0.789 against 0.765 ms: the
+    // 16-byte head reads cost the round 60 cycles and the refill, which now evaluates ~12 slow paths and builds 512 records, the rest.)
     uint64_t wseed = e.rng[2 * slot];
     const uint64_t gamma = e.rng[2 * slot + 1];
     int p = 0;                                         // uniform: next unread draw of the window
@@ -478,6 +483,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                 // W > thr2 at the last step (widths only shrink) rules out isapprox(Lbar, Rbar) at every step
                 // FAST drops two tests that cannot fail there: a NaN exponential makes Q, every d, dmin and Bq NaN, so it fails the margin
                 // test below (and `fin`); n <= S8_BS <= max_iter for a speculative lane, and lane 0's loop above stops at cap_iters
+                PROF_T(t2); PROF_ADD(1, t2 - t1); PROF_ADD(3, 1);      // (validity + chase are one section since round 4: slot 5)
                 int gdone;
 #ifdef PTE_PROFILE_SECTIONS
                 constexpr bool ASM_TAIL = false;
@@ -550,7 +556,6 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
 #ifdef PTE_PROFILE_SECTIONS
                 asm volatile("" :: "v"(xf), "v"(n), "v"(dmin));
 #endif
-                PROF_T(t2); PROF_ADD(1, t2 - t1);
                 // ---- acceptance check of the doubling scheme (:192-237): provably a no-op on this path, so it is not executed.
                 //      slice_accept rejects iff at some halving the old and the new position lie on different sides of the midpoint
                 //      (D) and BOTH ends of the halved interval are outside the slice.  Once D holds, the end on the old position's
@@ -601,7 +606,6 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
 #ifdef PTE_PROFILE_SECTIONS
                 asm volatile("" :: "v"(packed));
 #endif
-                PROF_T(t3); PROF_ADD(2, t3 - t2); PROF_ADD(3, 1);
                 {
                     int pk = __builtin_amdgcn_readlane(word, 0);
                     unsigned acc = 0u;
@@ -625,7 +629,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
 #ifdef PTE_PROFILE_SECTIONS
                 asm volatile("" :: "s"(p), "s"(l));
 #endif
-                PROF_T(t4); PROF_ADD(5, t4 - t3); PROF_ADD(4, gdone);
+                PROF_T(t4); PROF_ADD(5, t4 - t2); PROF_ADD(4, gdone);
                 if (__builtin_expect(gdone == 0, 0)) {
                     // ================= exact sequential procedure for coordinate l ===================
                     ex_total -= ex0;                              // (its exponential is drawn again below)
