@@ -22,6 +22,7 @@ RNG_TAIL_LOG1P = 1                      # include/pte_rng_policy.h
 def rng_bool_bit(k):
     return (k & 63) << 8
 TEST_LIB_PATH = os.path.join(PKG_ROOT, "lib", "libpte_test.so")    # -DPTE_TEST_KERNELS build: every kernel generation (parity tests, bisecting)
+NRMCUT_LIB_PATH = os.path.join(PKG_ROOT, "lib", "libpte_nrmcut.so")   # -DNRM_MAX_EV_=2 build: the normal generator's cut-short / fallback paths run on most chunks
 
 
 class PteConfig(C.Structure):

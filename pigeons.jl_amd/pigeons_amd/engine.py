@@ -25,7 +25,8 @@ def _up(a):
 
 class Engine:
     def __init__(self, test_build=False, **kw):
-        self.L = _lib.load(_lib.TEST_LIB_PATH if test_build else None)   # test_build: libpte_test.so (every kernel generation)
+        # test_build: True = libpte_test.so (every kernel generation); a path = that build (e.g. _lib.NRMCUT_LIB_PATH)
+        self.L = _lib.load(test_build if isinstance(test_build, str) else (_lib.TEST_LIB_PATH if test_build else None))
         cfg = PteConfig()
         self.L.pte_default_config(C.byref(cfg))
         tp = kw.pop("target_params", None)

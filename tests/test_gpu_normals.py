@@ -88,3 +88,42 @@ def test_divisor_with_an_all_ones_significand_takes_the_ieee_division(P):
         assert np.array_equal(x[i], z / sd[chain[i]]), i
     if not any((np.float64(s).view(np.uint64) & np.uint64(0xfffffffffffff)) == np.uint64(0xfffffffffffff) for s in sd):
         pytest.skip("could not construct a divisor with an all-ones significand through the schedule (sd = %r)" % (sd,))
+
+
+@pytest.mark.parametrize("d,N", [(3, 6), (256, 12), (512, 40), (577, 33), (1024, 64), (1500, 50), (4096, 24)])
+def test_cut_short_and_fallback_paths_equal_sequential_draws(P, d, N):
+    """libpte_nrmcut.so is the product source with -DNRM_MAX_EV_=2: the generator lists TWO events per chunk where ~9 occur, so nearly
+    every chunk is cut short at its second event (pos_limit), most groups of 256 outputs stop at the `break` (the next chunk starts at the
+    first output not emitted) and a chunk whose second event lies inside its first group produces that group with the block-by-block
+    fallback.  A live tail that leaves the chunk cuts the chunk through the same pos_limit.  The product build reaches these paths with
+    probability ~0 (more than 32 events in 576 positions); here they carry most of the outputs, and every state and stream position
+    must still be the sequential procedure's."""
+    import os
+    from pigeons_amd.engine import Engine, test_rng_fill
+    from pigeons_amd import _lib
+    if not os.path.exists(_lib.NRMCUT_LIB_PATH):
+        pytest.fail("libpte_nrmcut.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    e = Engine(test_build=_lib.NRMCUT_LIB_PATH, n_chains=N, dim=d, seed=5 + d, explorer=_lib.EXPLORER_TOY)
+    p = Engine(n_chains=N, dim=d, seed=5 + d, explorer=_lib.EXPLORER_TOY)          # the product build: same states, same streams
+    x, chain, rng = e.states()
+    xp, chainp, rngp = p.states()
+    assert np.array_equal(x, xp) and np.array_equal(rng, rngp) and np.array_equal(chain, chainp)
+    sd0 = np.sqrt(10.0)
+    for i, st in enumerate(_streams(5 + d, N)):
+        z, st1 = test_rng_fill(st, 1, d)
+        assert np.array_equal(x[i], z / sd0), (i, np.flatnonzero(x[i] != z / sd0)[:5])
+        assert tuple(int(v) for v in rng[i]) == st1, i
+    betas = e.schedule()
+    sd = np.sqrt((1.0 - betas) * 1.0 + betas * 10.0)
+    for scan in (1, 2):
+        _, chain0, rng0 = e.states()
+        e.explore(scan); p.explore(scan)
+        x, chain, rng = e.states()
+        xp, chainp, rngp = p.states()
+        assert np.array_equal(x, xp) and np.array_equal(rng, rngp)
+        for i in range(N):
+            z, st1 = test_rng_fill(tuple(int(v) for v in rng0[i]), 1, d)
+            assert np.array_equal(x[i], z / sd[chain[i]]), (scan, i)
+            assert tuple(int(v) for v in rng[i]) == st1, (scan, i)
+        e.swap(scan); p.swap(scan)
+        assert np.array_equal(e.states()[1], p.states()[1])      # same swap decisions: the fallback leaves the same block sums
