@@ -288,6 +288,9 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
 #ifdef PTE_PROFILE_WAVES
     const uint64_t wave_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef PTE_PROFILE_ISING_SECTIONS
+    unsigned long long prof_pass = 0, prof_chase = 0, prof_loop = 0;
+#endif
 
     for (int wd = lane; wd < NW; wd += 64) {
         unsigned v = 0;
@@ -328,6 +331,8 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
         const int lidx = lane - lbase;
         const int lc = lidx >> 1;
         const unsigned lb = (unsigned)(lidx & 1);
+        const int lnext = (lk == 0 ? 2 : lk == 1 ? 12 : lk == 2 ? 30 : 0) + 2 * lc;      // lane of the next quad's hypothesis (c, spin) = lnext + 2 dc + spin
+        const int lacc_sh = 7 + 4 * lk;
         double unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma));
         // The 64 buffered uniforms enter the vector pass only through four comparisons of their high words with the guard-banded
         // thresholds: taken once per refill for the whole buffer (four ballots, bit i = uniform i), a hypothesis that has consumed
@@ -342,18 +347,31 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
         };
         classify();
         int p = 0;
+#ifdef PTE_PROFILE_ISING_SECTIONS          // debug builds only (with -DPTE_PROFILE_WAVES): shader-clock cycles of the vector pass / the chase, summed over the chunks
+        const unsigned long long prof_t0 = __builtin_readcyclecounter();
+#endif
         for (int k = 0; k < ip.n_steps; ++k) {
             for (int i = 0; i < L; ++i) {
                 const int rowu = ((i == 0 ? L : i) - 1) * W, rowd = (i == L - 1 ? 0 : i + 1) * W, row = i * W;
                 unsigned b = lds_word(words, row + W - 1) >> 31;             // left neighbour of (i, 0): (i, L-1), not yet updated
                 unsigned first_updated = 0;
+                // The words of a row are read one iteration AHEAD (the sweep of word wj writes words[row + wj] only; the rows above and
+                // below and the words to its right keep their values while it runs): the LDS round trip of the next word's three reads
+                // (~120 cycles of a lone wave, 8 % of a word's time) runs under this word's two passes, and the word to the right --
+                // read for its bit 0 -- IS the next word to sweep.
+                unsigned cur = lds_word(words, row), up = lds_word(words, rowu), dn = lds_word(words, rowd);
+                unsigned nxt = W > 1 ? lds_word(words, row + 1) : 0u;
                 for (int wj = 0; wj < W; ++wj) {
-                    unsigned cur = lds_word(words, row + wj);
-                    const unsigned up = lds_word(words, rowu + wj), dn = lds_word(words, rowd + wj);
-                    const unsigned rightbit = (wj == W - 1) ? (first_updated & 1u) : (lds_word(words, row + wj + 1) & 1u);
+                    const bool more = wj + 1 < W;
+                    unsigned pf_up = 0, pf_dn = 0, pf_nx = 0;                       // (every lane reads the same address: a broadcast)
+                    if (more) { pf_up = words[rowu + wj + 1]; pf_dn = words[rowd + wj + 1]; pf_nx = words[row + (wj + 2 < W ? wj + 2 : 0)]; }
+                    const unsigned rightbit = (wj == W - 1) ? (first_updated & 1u) : (nxt & 1u);
                     const unsigned cur0 = cur;
 #pragma unroll
                     for (int T0 = 0; T0 < 32; T0 += 16) {
+#ifdef PTE_PROFILE_ISING_SECTIONS
+                        const unsigned long long pa = __builtin_readcyclecounter();
+#endif
                         if (p + 16 > 64) {
                             seed += (uint64_t)p * gamma; unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma)); p = 0;
                             classify();
@@ -394,27 +412,33 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                         }
                         const int accbits = (int)(rejn ^ 15u);
                         ambu &= 1u;
-                        const bool amb = ambu != 0;
-                        const int c_run = lc + dc;
-                        // packed: bit 0 = ambiguous somewhere in the quad, bits 1-4 = accepts, bits 5.. = NEXT chase state 2 c + spin
-                        const int pk = (amb ? 1 : 0) | (accbits << 1) | ((2 * c_run + (int)left) << 5);
+                        // The word a hypothesis hands to the chase: bits 0-5 = the LANE of the hypothesis that continues it in the next quad
+                        // (quad 3: the state 2 c + spin the chunk ends in), bit 6 = a guard-band decision somewhere in the quad, bits 7-22 =
+                        // its accepts already at the quad's place in the chunk.  A hop is then ONE v_readlane whose lane select is the word
+                        // read before (the hardware takes bits 0-5), and the chunk's flips are the OR of the four words: round 4 priced a hop
+                        // with a shift and an add between the reads at 34-42 cycles against 27.5 chained (tools/ubench/round_cost.hip).
+                        const int pk = (lnext + 2 * dc + (int)left) | ((int)ambu << 6) | (accbits << lacc_sh);
                         // ---- chase over the four quads: state s2 = 2 c + b
                         int s2 = (int)b;
+#ifdef PTE_PROFILE_ISING_SECTIONS
+                        asm volatile("" :: "v"(pk));
+                        const unsigned long long pb = __builtin_readcyclecounter();
+#endif
                         // all four quads at once when none of them met a guard-band decision (the common case): no branches
                         const int q0 = __builtin_amdgcn_readlane(pk, s2);
-                        const int q1 = __builtin_amdgcn_readlane(pk, 2 + (q0 >> 5));
-                        const int q2 = __builtin_amdgcn_readlane(pk, 12 + (q1 >> 5));
-                        const int q3 = __builtin_amdgcn_readlane(pk, 30 + (q2 >> 5));
-                        if (__builtin_expect(((q0 | q1 | q2 | q3) & 1) == 0, 1)) {
-                            const unsigned flips = (unsigned)((q0 >> 1) & 15) | ((unsigned)((q1 >> 1) & 15) << 4)
-                                                 | ((unsigned)((q2 >> 1) & 15) << 8) | ((unsigned)((q3 >> 1) & 15) << 12);
-                            cur ^= flips << T0;
-                            s2 = q3 >> 5;
+                        const int q1 = __builtin_amdgcn_readlane(pk, q0);
+                        const int q2 = __builtin_amdgcn_readlane(pk, q1);
+                        const int q3 = __builtin_amdgcn_readlane(pk, q2);
+                        const int qa = q0 | q1 | q2 | q3;
+                        if (__builtin_expect((qa & 64) == 0, 1)) {
+                            cur ^= (((unsigned)qa >> 7) & 0xFFFFu) << T0;
+                            s2 = q3 & 63;
                         } else {
 #pragma unroll
                             for (int kq = 0; kq < 4; ++kq) {
-                                const int q = __builtin_amdgcn_readlane(pk, (kq == 0 ? 0 : kq == 1 ? 2 : kq == 2 ? 12 : 30) + s2);
-                                if (__builtin_expect(q & 1, 0)) {
+                                const int qbase = kq == 0 ? 0 : kq == 1 ? 2 : kq == 2 ? 12 : 30, nbase = kq == 0 ? 2 : kq == 1 ? 12 : kq == 2 ? 30 : 0;
+                                const int q = __builtin_amdgcn_readlane(pk, qbase + s2);
+                                if (__builtin_expect(q & 64, 0)) {
                                     // a guard-band decision (or a chain whose filter is not valid) inside this quad: its four sites by
                                     // the scalar procedure with the exact arithmetic of the reference where needed
                                     int cc = s2 >> 1;
@@ -451,20 +475,32 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                                     s2 = __builtin_amdgcn_readfirstlane(2 * cc + (int)bb_);
                                     cur = (unsigned)__builtin_amdgcn_readfirstlane((int)cur);
                                 } else {
-                                    cur ^= (unsigned)((q >> 1) & 15) << (T0 + 4 * kq);
-                                    s2 = q >> 5;
+                                    cur ^= (((unsigned)q >> 7) & 0xFFFFu) << T0;      // (the accepts sit at the quad's place; the other quads' bits are 0)
+                                    s2 = (q & 63) - nbase;
                                 }
                             }
                         }
+#ifdef PTE_PROFILE_ISING_SECTIONS
+                        asm volatile("" :: "s"(s2), "s"(cur));
+                        { const unsigned long long pc = __builtin_readcyclecounter(); prof_pass += pb - pa; prof_chase += pc - pb; }
+#endif
                         p += s2 >> 1;
                         b = (unsigned)(s2 & 1);
                     }
                     if (cur != cur0 && lane == 0) words[row + wj] = cur;
                     if (wj == 0) first_updated = cur;
+                    if (more) {
+                        cur = nxt;
+                        up = (unsigned)__builtin_amdgcn_readfirstlane((int)pf_up); dn = (unsigned)__builtin_amdgcn_readfirstlane((int)pf_dn);
+                        nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)pf_nx);
+                    }
                 }
             }
         }
         seed += (uint64_t)p * gamma;
+#ifdef PTE_PROFILE_ISING_SECTIONS
+        prof_loop = __builtin_readcyclecounter() - prof_t0;
+#endif
     }
     __syncthreads();
     const long long spp = recompute();
@@ -476,6 +512,9 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
         double *o = e.on_m2 + 2 * (e.d + 1) + 4 * cl;
         o[0] = (double)wave_t0; o[1] = (double)__builtin_amdgcn_s_memrealtime();
         o[2] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4); o[3] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+#ifdef PTE_PROFILE_ISING_SECTIONS
+        o[0] = (double)prof_loop; o[1] = (double)prof_pass; o[2] = (double)prof_chase;
+#endif
     }
 #endif
 }
