@@ -388,8 +388,10 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
         IsingParams ip{(int)std::llround(std::sqrt((double)h->d)), h->cfg.slice_n_passes, h->cfg.target_params[0]};
         time_begin(h, 0, true);
         // L % 32 == 0: lane-speculative bit-packed sweep; other lattice sizes: the scalar byte-lattice kernel
-        if (ip.L % 32 == 0 && h->ising_impl == 0)
-            PTE_LAUNCH1(k_explore_ising_spec, dim3((unsigned)N), dim3(64), (size_t)(h->d / 8), h->stream, h->dev, ip);
+        if (ip.L % 32 == 0 && h->ising_impl == 0) {
+            if (ip.L == 32) PTE_LAUNCH1(k_explore_ising_spec<true>, dim3((unsigned)N), dim3(64), (size_t)(h->d / 8 + 8), h->stream, h->dev, ip);
+            else            PTE_LAUNCH1(k_explore_ising_spec<false>, dim3((unsigned)N), dim3(64), (size_t)(h->d / 8 + 8), h->stream, h->dev, ip);
+        }
 #ifdef PTE_TEST_KERNELS
         else if (ip.L % 32 == 0 && h->ising_impl == 1)
             PTE_LAUNCH1(k_explore_ising_bits, dim3((unsigned)N), dim3(64), (size_t)(h->d / 8), h->stream, h->dev, ip);

@@ -17,6 +17,11 @@ namespace pte {
 
 struct IsingParams { int L; int n_steps; double beta_target; };
 
+#ifndef PTE_ISING_STORE
+#define PTE_ISING_STORE 2       // how k_explore_ising_spec writes a swept word back: 0 = lane 0 if it changed (a compare, two scalar ANDs, an EXEC save / restore:
+                                // 4.34 ms per scan at the C5 shard shape), 1 = lane 0 always (4.32), 2 = every lane the same word to the same address (4.18)
+#endif
+
 // InterpolatedLogPotential between IsingLogPotential(0.0, L) and IsingLogPotential(beta_target, L)
 // (examples/ising.jl:74-77, src/paths/InterpolatedLogPotential.jl:9-16) as a function of sum_pair_products
 __device__ __forceinline__ double ising_lp(double beta, double beta_target, double spp) {
@@ -272,6 +277,10 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
 // whose filter is not valid) are taken by the exact arithmetic of the reference, with sum_pair_products
 // recomputed on demand; the final sum_pair_products is recomputed from the lattice by popcounts.
 // ---------------------------------------------------------------------------------------------
+// ONE_WORD: base_length == 32 (a row is one word: bit 31's right neighbour is bit 0 of the same word, swept in the same iteration) -- its
+// own instantiation, so that the wider lattices do not test for it twice per word.  Dynamic LDS: L * L / 8 bytes + 8 (the read-ahead of the
+// word to the right runs two words past a row's end).
+template <bool ONE_WORD>
 __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingParams ip) {
     extern __shared__ unsigned words[];
     const int lane = lane_id();
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
     if (cl >= e.K) return;
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];
-    const int L = ip.L, d = L * L, W = L >> 5, NW = d >> 5;
+    const int L = ip.L, d = L * L, W = ONE_WORD ? 1 : (L >> 5), NW = d >> 5;
     unsigned *wrow = reinterpret_cast<unsigned *>(e.x + (int64_t)slot * e.ld);     // bit-packed lattice in HBM, same word layout as the LDS copy
     uint64_t seed = e.rng[2 * slot];
     const uint64_t gamma = e.rng[2 * slot + 1];
@@ -347,6 +356,18 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
         };
         classify();
         int p = 0;
+        // What a chunk's sites need from their surroundings (see the vector pass below) does not depend on the sweep of the chunk BEFORE it:
+        // that one flips its own 16 bits only.  So the boolean functions of a chunk are evaluated before the chase of the previous one, in
+        // whose wait states they can issue (a chained hop leaves ~20 cycles in which a lone wave issues nothing otherwise).
+        struct ChunkStatics { unsigned NN, II, SN; };
+        auto chunk_statics = [&](unsigned upw, unsigned dnw, unsigned curw, unsigned cur_r, int T0) -> ChunkStatics {
+            const int t0 = T0 + 4 * lk;
+            const unsigned U = (upw >> t0) & 15u, D = (dnw >> t0) & 15u, R = (cur_r >> t0) & 15u, S = (curw >> t0) & 15u;
+            const unsigned b0 = U ^ D ^ R, b1 = (U & D) | (R & (U ^ D));
+            const unsigned N0 = (S & b1 & b0) | (~S & ~b1),       I0 = (S & b1 & b0) | (~S & ~b1 & b0);
+            const unsigned N1 = (S & b1) | (~S & ~b1 & ~b0),      I1 = (S & b1 & ~b0) | (~S & ~b1 & ~b0);
+            return ChunkStatics{(N0 & 15u) | ((N1 & 15u) << 4), (I0 & 15u) | ((I1 & 15u) << 4), ~S};      // bit j + 4 left
+        };
 #ifdef PTE_PROFILE_ISING_SECTIONS          // debug builds only (with -DPTE_PROFILE_WAVES): shader-clock cycles of the vector pass / the chase, summed over the chunks
         const unsigned long long prof_t0 = __builtin_readcyclecounter();
 #endif
@@ -360,13 +381,16 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                 // (~120 cycles of a lone wave, 8 % of a word's time) runs under this word's two passes, and the word to the right --
                 // read for its bit 0 -- IS the next word to sweep.
                 unsigned cur = lds_word(words, row), up = lds_word(words, rowu), dn = lds_word(words, rowd);
-                unsigned nxt = W > 1 ? lds_word(words, row + 1) : 0u;
+                unsigned nxt = ONE_WORD ? 0u : lds_word(words, row + 1);
+                ChunkStatics st0 = chunk_statics(up, dn, cur, cur >> 1, 0), st1 = st0;      // (chunk 0 never looks at bit 31's right neighbour)
                 for (int wj = 0; wj < W; ++wj) {
                     const bool more = wj + 1 < W;
                     unsigned pf_up = 0, pf_dn = 0, pf_nx = 0;                       // (every lane reads the same address: a broadcast)
-                    if (more) { pf_up = words[rowu + wj + 1]; pf_dn = words[rowd + wj + 1]; pf_nx = words[row + (wj + 2 < W ? wj + 2 : 0)]; }
+                    if (more) { pf_up = words[rowu + wj + 1]; pf_dn = words[rowd + wj + 1]; pf_nx = words[row + wj + 2]; }    // (the last one: two words of padding behind the lattice)
                     const unsigned rightbit = (wj == W - 1) ? (first_updated & 1u) : (nxt & 1u);
+#if PTE_ISING_STORE == 0
                     const unsigned cur0 = cur;
+#endif
 #pragma unroll
                     for (int T0 = 0; T0 < 32; T0 += 16) {
 #ifdef PTE_PROFILE_ISING_SECTIONS
@@ -376,7 +400,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                             seed += (uint64_t)p * gamma; unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma)); p = 0;
                             classify();
                         }
-                        const unsigned rt31 = (W == 1) ? (cur & 1u) : rightbit;
+                        const unsigned rt31 = ONE_WORD ? (cur & 1u) : rightbit;
                         // ---- vector pass: every (quad, consumed, left) hypothesis of the chunk walks its four sites
                         // (its uniforms are the next <= 4 of the buffer from position p + lc: bits p + lc .. of the masks)
                         const int sh = p + lc;                                   // <= 48 + 12
@@ -388,15 +412,10 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                         //   a draw is needed iff  s ? cnt > 2 : cnt < 2,   delta == -4 iff  s ? cnt == 3 : cnt == 1
                         // as boolean functions of (b1 b0 = U + D + R, s), once for left = 0 and once for left = 1; the walk then only
                         // picks bits: 12 instead of 19 instructions per site.
-                        const int t0 = T0 + 4 * lk;
-                        const unsigned cur_r = (cur >> 1) | (rt31 << 31);        // right neighbours, site 31's from the next word (scalar)
-                        const unsigned U = (up >> t0) & 15u, D = (dn >> t0) & 15u, R = (cur_r >> t0) & 15u, S = (cur >> t0) & 15u;
-                        const unsigned b0 = U ^ D ^ R, b1 = (U & D) | (R & (U ^ D));
-                        const unsigned N0 = (S & b1 & b0) | (~S & ~b1),       I0 = (S & b1 & b0) | (~S & ~b1 & b0);
-                        const unsigned N1 = (S & b1) | (~S & ~b1 & ~b0),      I1 = (S & b1 & ~b0) | (~S & ~b1 & ~b0);
-                        const unsigned NN = (N0 & 15u) | ((N1 & 15u) << 4), II = (I0 & 15u) | ((I1 & 15u) << 4);   // bit j + 4 left
+                        if (T0 == 16 && ONE_WORD) st1 = chunk_statics(up, dn, cur, (cur >> 1) | (rt31 << 31), 16);   // (a one-word row: bit 31's right neighbour is bit 0, just swept)
+                        const ChunkStatics st = T0 == 0 ? st0 : st1;
+                        const unsigned NN = st.NN, II = st.II, SN = st.SN;
                         const unsigned WR = (wR8 & 15u) | ((wR4 & 15u) << 4), WA = (wA8 & 15u) | ((wA4 & 15u) << 4);   // bit dc + 4 [delta == -4]
-                        const unsigned SN = ~S;
                         int dc = 0;
                         unsigned left = lb, ambu = 0, rejn = 0;
 #pragma unroll
@@ -424,16 +443,39 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                         asm volatile("" :: "v"(pk));
                         const unsigned long long pb = __builtin_readcyclecounter();
 #endif
-                        // all four quads at once when none of them met a guard-band decision (the common case): no branches
-                        const int q0 = __builtin_amdgcn_readlane(pk, s2);
-                        const int q1 = __builtin_amdgcn_readlane(pk, q0);
-                        const int q2 = __builtin_amdgcn_readlane(pk, q1);
+                        // all four quads at once when none of them met a guard-band decision (the common case): no branches.
+                        // The statics of the chunk AFTER this one are evaluated in three pieces of four instructions BETWEEN the hops: the
+                        // empty asm statements tie each piece's inputs to the hop before it and its results to the hop after it (pure
+                        // data flow: hipcc would otherwise schedule all of it above the first hop and fill the gaps with s_nop).
+                        const unsigned n_up = T0 == 0 ? up : pf_up, n_dn = T0 == 0 ? dn : pf_dn, n_cw = T0 == 0 ? cur : nxt;
+                        const unsigned n_cr = T0 == 0 ? ((cur >> 1) | (rightbit << 31)) : (nxt >> 1);
+                        int nt0 = (T0 == 0 ? 16 : 0) + 4 * lk;
+                        int q0 = __builtin_amdgcn_readlane(pk, s2);
+                        asm volatile("" : "+s"(q0), "+v"(nt0));
+                        unsigned sU = n_up >> nt0, sD = n_dn >> nt0, sR = n_cr >> nt0, sS = n_cw >> nt0;
+                        asm volatile("" : "+s"(q0), "+v"(sU), "+v"(sD), "+v"(sR), "+v"(sS));
+                        int q1 = __builtin_amdgcn_readlane(pk, q0);
+                        asm volatile("" : "+s"(q1), "+v"(sU), "+v"(sD), "+v"(sR), "+v"(sS));
+                        unsigned sb0 = sU ^ sD ^ sR, sb1 = (sU & sD) | (sR & (sU ^ sD));
+                        unsigned sN0 = (sS & sb1 & sb0) | (~sS & ~sb1), sN1 = (sS & sb1) | (~sS & ~sb1 & ~sb0);
+                        asm volatile("" : "+s"(q1), "+v"(sb0), "+v"(sb1), "+v"(sN0), "+v"(sN1));
+                        int q2 = __builtin_amdgcn_readlane(pk, q1);
+                        asm volatile("" : "+s"(q2), "+v"(sb0), "+v"(sb1), "+v"(sN0), "+v"(sN1));
+                        unsigned sI0 = (sS & sb1 & sb0) | (~sS & ~sb1 & sb0), sI1 = (sS & sb1 & ~sb0) | (~sS & ~sb1 & ~sb0);
+                        unsigned sNN = (sN0 & 15u) | ((sN1 & 15u) << 4);
+                        asm volatile("" : "+s"(q2), "+v"(sI0), "+v"(sI1), "+v"(sNN));
                         const int q3 = __builtin_amdgcn_readlane(pk, q2);
+                        {
+                            const ChunkStatics nst{sNN, (sI0 & 15u) | ((sI1 & 15u) << 4), ~sS};
+                            if (T0 == 0) st1 = nst; else st0 = nst;          // (T0 == 16: the next word, read ahead; zeros behind the row's last word)
+                        }
                         const int qa = q0 | q1 | q2 | q3;
-                        if (__builtin_expect((qa & 64) == 0, 1)) {
-                            cur ^= (((unsigned)qa >> 7) & 0xFFFFu) << T0;
-                            s2 = q3 & 63;
-                        } else {
+                        // (the result of the common case first, ONE branch around the rest: with an if / else hipcc keeps a "took the fast
+                        // side" flag in a scalar pair and tests it again behind the join)
+                        unsigned cur_fast = cur ^ ((((unsigned)qa >> 7) & 0xFFFFu) << T0);
+                        int s2_fast = q3 & 63;
+                        asm volatile("" : "+s"(cur_fast), "+s"(s2_fast));      // (evaluated HERE: hipcc sinks them into an else side otherwise)
+                        if (__builtin_expect((qa & 64) != 0, 0)) {
 #pragma unroll
                             for (int kq = 0; kq < 4; ++kq) {
                                 const int qbase = kq == 0 ? 0 : kq == 1 ? 2 : kq == 2 ? 12 : 30, nbase = kq == 0 ? 2 : kq == 1 ? 12 : kq == 2 ? 30 : 0;
@@ -479,6 +521,8 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                                     s2 = (q & 63) - nbase;
                                 }
                             }
+                        } else {
+                            cur = cur_fast; s2 = s2_fast;
                         }
 #ifdef PTE_PROFILE_ISING_SECTIONS
                         asm volatile("" :: "s"(s2), "s"(cur));
@@ -487,13 +531,18 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                         p += s2 >> 1;
                         b = (unsigned)(s2 & 1);
                     }
+#if PTE_ISING_STORE == 0
                     if (cur != cur0 && lane == 0) words[row + wj] = cur;
+#elif PTE_ISING_STORE == 1
+                    if (lane == 0) words[row + wj] = cur;
+#else
+                    words[row + wj] = cur;                                      // (every lane the same word to the same address)
+#endif
                     if (wj == 0) first_updated = cur;
-                    if (more) {
-                        cur = nxt;
-                        up = (unsigned)__builtin_amdgcn_readfirstlane((int)pf_up); dn = (unsigned)__builtin_amdgcn_readfirstlane((int)pf_dn);
-                        nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)pf_nx);
-                    }
+                    // (behind the row's last word these are zeros nobody reads: the row loop reloads)
+                    cur = nxt;
+                    up = (unsigned)__builtin_amdgcn_readfirstlane((int)pf_up); dn = (unsigned)__builtin_amdgcn_readfirstlane((int)pf_dn);
+                    nxt = (unsigned)__builtin_amdgcn_readfirstlane((int)pf_nx);
                 }
             }
         }
