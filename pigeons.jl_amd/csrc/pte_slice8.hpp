@@ -176,7 +176,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
             for (int k = 0; k < CPB; ++k) s_x[64 * k + lane] = (64 * k + lane < nl) ? xrow[base + 64 * k + lane] : 0.0;
             __builtin_amdgcn_wave_barrier();
             double Sest = S * (1.0 + 1e-6) + wsum * inv_abs_nhp;       // upper bound on sum x^2 while this window lasts
-            int l = 0;
+            int l = 0, l_end = nl;
             // (Requesting the head's LDS loads of the NEXT round as soon as the chase has produced (l, p), so that the stores, exit tests
             // and back edge run in their shadow, was built and measured in round 4: 0.793 against 0.777 ms -- the two extra not-taken
             // branches of the restructured tail cost more than the ~55 exposed cycles of the round trip.)
@@ -705,7 +705,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                         if (newpos < xo) Lbar = newpos; else Rbar = newpos;
                         if (jl_isapprox(Lbar, Rbar)) { steps_sum += n; steps_n += 1; fin = true; break; }
                     }
-                    if (!fin) { err = ERR_SLICE_MAX_ITER; err_coord = (int)(base + l); break; }
+                    if (!fin) { err = ERR_SLICE_MAX_ITER; err_coord = (int)(base + l); l_end = 0; continue; }   // (leaves through the loop's ONE exit test: a `break` makes hipcc carry a "no error" flag over the back edge of every round)
                     Sest = Sest + fabs(xn * xn - xo * xo);
                     if (lane == li) s_x[l] = xn;
                     __builtin_amdgcn_wave_barrier();
@@ -715,7 +715,7 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                     fb_draws += used; n_fb += 1;
                     PROF_T(t5); PROF_ADD(7, t5 - t4); PROF_ADD(6, 1);
                 }
-            } while (l < nl);
+            } while (l < l_end);
             if (err) break;
             {   // write the block back and re-establish the exact fixed-tree values at the block boundary
 #pragma unroll
