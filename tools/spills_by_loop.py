@@ -8,7 +8,7 @@ innermost loop; one at depth 0 / 1 runs once per launch / per outer step.
 Usage: python tools/spills_by_loop.py [kernel-substring ...] > profiles/rNN_spills_by_loop.txt      (ROUND_LOOP_REUSE=1: reuse /tmp/pte_round_loop.s)"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEFAULT = ["k_explore_automalaILi2ELi2ELb0ELb1E", "k_explore_ising_spec", "k_explore_slice8ILi4ELi9E"]
+DEFAULT = ["k_explore_automalaILi2ELi2ELb0ELb1E", "k_explore_ising_specILb0E", "k_explore_slice8ILi4ELi9E"]
 
 
 def kernel_body(lines, sub):
