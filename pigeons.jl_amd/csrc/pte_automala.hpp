@@ -54,6 +54,9 @@ __device__ __forceinline__ double tree_sum_regs(const double (&t)[E]) {
         }
         return block_tree<E / 2>(s);
     } else {
+#ifndef PTE_WSP_ROWS_ONLY
+        if constexpr (E == 2) return wave_sum_pair(t[0], t[1]);
+#endif
         double s[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) s[j] = t[j];

@@ -148,12 +148,74 @@ __device__ __forceinline__ void permlane32_swap_f64(double &a, double &b) {
     a = __hiloint2double((int)hi[0], (int)lo[0]); b = __hiloint2double((int)hi[1], (int)lo[1]);
 }
 // M = 4 or 8 wave sums, v[2i] and v[2i+1] being two 64-blocks whose totals the tree adds next: out[i] = sum(v[2i]) + sum(v[2i+1]).
-// Every addition is one the fixed tree makes (same operand pairs as wave_sum_dpp, then the block pair), but from the rows upwards the
-// partial sums of two chains share a register: 15.6 instructions per chain instead of 20.5.
-//   levels 1-4 (inside a row of 16): per chain, as in wave_sum_dpp
-//   level 5 (rows 0+1, 2+3):  pairs of chains through permlane16_swap  -> M/2 registers  [A01, B01, A23, B23]
-//   level 6 (halves):         pairs of those through permlane32_swap   -> M/4 registers  [A, B, C, D]  (one total per row)
-//   block pair A+B, C+D:      permlane16_swap again                    -> row 0 / row 2 (and rows 1 / 3 for the second register)
+// Every addition is one the fixed tree makes (same operand pairs as wave_sum_dpp, then the block pair); what changes is how many
+// registers carry the partial sums.  A level of the tree leaves the same value in both lanes (quads, ...) it combined, so after level k
+// only one lane in 2^k needs to keep a chain's partial sum and the others can carry ANOTHER chain's:
+//   level 1 (l, l^1), per chain                         then chains 2i / 2i+1 share a register: even lanes one, odd lanes the other (a select)
+//   level 2 (l, l^2), per register (parity kept)        then two registers share one: a quad holds four chains [c0 c1 c2 c3] (a select)
+//   level 3 / 4: row_shr:4 / row_shr:8 (lane & 3 kept)  -> the quad's four totals of a row in lanes 12..15 of the row
+//   level 5 (rows 0+1, 2+3): permlane16_swap of the two registers (M = 8) / of the register with itself (M = 4)
+//   level 6 (halves): permlane32_swap with itself;  block pair c0 + c1, c2 + c3: quad_perm [1,0,3,2]
+// 73 vector instructions for eight chains (round 3, packing from the rows upwards only: 117; one chain at a time: 164), 43 for four (62).
+#ifndef PTE_WSP_ROWS_ONLY
+// lanes whose bit is set in `mask` take b, the others a: two v_cndmask_b32 on a scalar pair.  (Written as `odd ? v[2 * i + 1] : v[2 * i]`
+// hipcc turns the select into an INDEXED access of the array -- through LDS / scratch -- and the reduction takes twice as long as before.)
+__device__ __forceinline__ double select_lanes_f64(unsigned long long mask, double a, double b) {
+    int lo, hi;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(a)), "v"(__double2loint(b)), "s"(mask));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(a)), "v"(__double2hiint(b)), "s"(mask));
+    return __hiloint2double(hi, lo);
+}
+// the two 64-blocks of ONE pair: sum(a) + sum(b), uniform.  30 vector instructions (two wave_sum_dpp + the add: 37)
+__device__ __forceinline__ double wave_sum_pair(double a, double b) {
+    a = dpp_add_step<0xB1, 0xF>(a); b = dpp_add_step<0xB1, 0xF>(b);
+    double m = select_lanes_f64(0xAAAAAAAAAAAAAAAAull, a, b);          // even lanes a, odd lanes b
+    m = dpp_add_step<0x4E, 0xF>(m);
+    m = dpp_add_step<0x114, 0xF>(m);
+    m = dpp_add_step<0x118, 0xF>(m);
+    double t = m;
+    permlane16_swap_f64(m, t);
+    double w = m + t, t2 = w;
+    permlane32_swap_f64(w, t2);
+    double z = w + t2;
+    z = dpp_add_step<0xB1, 0xF>(z);
+    return readlane_f64(z, 12);
+}
+template <int M>
+__device__ __forceinline__ void wave_sum_pairs(double (&v)[M], double (&out)[M / 2]) {
+    static_assert(M == 4 || M == 8, "wave_sum_pairs: 4 or 8 chains");
+    constexpr unsigned long long ODD = 0xAAAAAAAAAAAAAAAAull, HI2 = 0xCCCCCCCCCCCCCCCCull;      // lanes with bit 0 / bit 1 set
+#pragma unroll
+    for (int j = 0; j < M; ++j) v[j] = dpp_add_step<0xB1, 0xF>(v[j]);
+    double m[M / 2];
+#pragma unroll
+    for (int i = 0; i < M / 2; ++i) m[i] = select_lanes_f64(ODD, v[2 * i], v[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < M / 2; ++i) m[i] = dpp_add_step<0x4E, 0xF>(m[i]);
+    double n[M / 4];
+#pragma unroll
+    for (int i = 0; i < M / 4; ++i) n[i] = select_lanes_f64(HI2, m[2 * i], m[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < M / 4; ++i) n[i] = dpp_add_step<0x114, 0xF>(n[i]);     // row_shr:4  (quads 1 and 3 of a row hold q0 + q1, q2 + q3)
+#pragma unroll
+    for (int i = 0; i < M / 4; ++i) n[i] = dpp_add_step<0x118, 0xF>(n[i]);     // row_shr:8  (quad 3: the row's totals)
+    double w;
+    if constexpr (M == 8) {
+        permlane16_swap_f64(n[0], n[1]);               // n0' = [a.r0, b.r0, a.r2, b.r2], n1' = [a.r1, b.r1, a.r3, b.r3]
+        w = n[0] + n[1];                               // rows: a.r01, b.r01, a.r23, b.r23
+    } else {
+        double t = n[0];
+        permlane16_swap_f64(n[0], t);                  // [r0, r0, r2, r2], [r1, r1, r3, r3]
+        w = n[0] + t;
+    }
+    double t2 = w;
+    permlane32_swap_f64(w, t2);                        // [w.lo, w.lo], [w.hi, w.hi]
+    double z = w + t2;                                 // rows 0 / 1 (and 2 / 3): chains 0..3 / 4..7 in lanes 12..15
+    z = dpp_add_step<0xB1, 0xF>(z);                    // the block pairs
+    out[0] = readlane_f64(z, 12); out[1] = readlane_f64(z, 14);
+    if constexpr (M == 8) { out[2] = readlane_f64(z, 28); out[3] = readlane_f64(z, 30); }
+}
+#else       // round 3's form (A/B builds): the partial sums of two chains share a register from the rows upwards only
 template <int M>
 __device__ __forceinline__ void wave_sum_pairs(double (&v)[M], double (&out)[M / 2]) {
     static_assert(M == 4 || M == 8, "wave_sum_pairs: 4 or 8 chains");
@@ -183,6 +245,7 @@ __device__ __forceinline__ void wave_sum_pairs(double (&v)[M], double (&out)[M /
         out[0] = readlane_f64(z, 0); out[1] = readlane_f64(z, 32);
     }
 }
+#endif
 // ---- sequential (uniform) stream: used on slow paths and for single draws ---------------------
 struct SeqRng {
     uint64_t seed, gamma;   // uniform
