@@ -317,6 +317,20 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
 #endif
                 sq[g] = (q[g][0] * q[g][0] + q[g][1] * q[g][1]) + (q[g][2] * q[g][2] + q[g][3] * q[g][3]);
             }
+#ifndef NRM_PLAIN_TREE
+            if constexpr (NG == 2) {
+                // the same additions with the two groups' partial sums sharing a register from level 2 on (pte_device.hpp, wave_sum_pairs):
+                // even lanes carry group 0, odd lanes group 1; row_shr:4 / row_shr:8 keep a lane's parity and leave a row's (= one
+                // block's) two sums in its lanes 12 and 13 -- 17 instead of 26 vector instructions per chunk
+                sq[0] = dpp_add_step<0xB1, 0xF>(sq[0]); sq[1] = dpp_add_step<0xB1, 0xF>(sq[1]);
+                double m = select_lanes_f64(0xAAAAAAAAAAAAAAAAull, sq[0], sq[1]);
+                m = dpp_add_step<0x4E, 0xF>(m);
+                m = dpp_add_step<0x114, 0xF>(m);
+                m = dpp_add_step<0x118, 0xF>(m);
+                if ((lane & 14) == 12) L.bs[wv][(int)(done >> 6) + 4 * (lane & 1) + (lane >> 4)] = m;      // lane 16 r + 12 + g: block 4 g + r of the chunk
+            } else
+#endif
+            {
 #pragma unroll
             for (int lv = 0; lv < 4; ++lv)
 #pragma unroll
@@ -326,6 +340,7 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
 #pragma unroll
             for (int g = 1; g < NG; ++g) sel = ((lane & 15) == g) ? sq[g] : sel;
             if ((lane & 15) < NG) L.bs[wv][(int)(done >> 6) + 4 * (lane & 15) + (lane >> 4)] = sel;
+            }
             emitted = NRM_CO; shift_emitted = shift_all;
         } else
         for (int g0 = 0; g0 < want; g0 += 256) {
