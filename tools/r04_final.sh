@@ -13,4 +13,5 @@ python tools/bench_nchains.py 2>&1 | grep -v amdgpu.ids | tee $O/nchains.txt
 python tools/bench_toy_n.py 2>&1 | grep -v amdgpu.ids | tee $O/toy_nchains.txt
 ./tools/ubench/round_cost.bin > $O/round_cost.txt 2>&1; ./tools/ubench/hop_check.bin > $O/hop_check.txt 2>&1
 for p in 1 2 3 5; do timeout 60 ./tools/ubench/rate2.bin $p; done > $O/rate2.txt 2>&1
-for b in normals_dev_r03 normals_dev; do for i in 1 2 3; do printf "%-18s " $b; ./tools/ubench/$b.bin; done; printf "%-18s " $b; ./tools/ubench/$b.bin 32768; done > $O/normals_dev.txt 2>&1
+for b in normals_dev_r03 normals_dev_plain normals_dev; do for i in 1 2 3; do printf "%-18s " $b; ./tools/ubench/$b.bin; done; printf "%-18s " $b; ./tools/ubench/$b.bin 32768; done > $O/normals_dev.txt 2>&1
+./tools/ubench/wave_sum_pairs_r03.bin > $O/wave_sum_pairs.txt 2>&1; ./tools/ubench/wave_sum_pairs.bin >> $O/wave_sum_pairs.txt 2>&1
