@@ -10,7 +10,7 @@ SRC = os.path.join(ROOT, "pigeons.jl_amd", "csrc", "pte.hip")
 
 
 def main():
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-align-all-nofallthru-blocks=6", "-fPIC", "-shared",
            "-Wno-unused-value", "-Rpass-analysis=kernel-resource-usage", *sys.argv[1:], "-o", "/tmp/libpte_resources.so", SRC, "-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
