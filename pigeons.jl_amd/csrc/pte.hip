@@ -21,7 +21,11 @@
 #include "pte_slice5.hpp"
 #include "pte_slice7.hpp"
 #include "pte_slice8.hpp"
-#include "pte_automala.hpp"
+#ifdef PTE_SPLIT_LANGEVIN          // the product build: the Langevin-family kernels are the library's second translation unit (pte_langevin.hip)
+#include "pte_automala_params.hpp"
+#else                              // tools / development builds: one translation unit
+#include "pte_langevin_launch.hpp"
+#endif
 #include "pte_ising.hpp"
 #if defined(PTE_PROFILE_AM)               // debug builds only (tools/prof_automala.py): 12 words per wave, section times of k_explore_automala
 #define PTE_WAVE_PROFILE_WORDS 12
@@ -278,6 +282,15 @@ void time_collect(pte_engine *h) {
     h->events.clear();
 }
 
+
+// one launch of the Langevin-family kernel (pte_automala_params.hpp); like PTE_LAUNCH1, the open timing bracket's events ride on it
+static int launch_langevin(pte_engine *h, int E, int target, bool slice, bool full, int64_t N, const AmParams &ap) {
+    LangevinLaunch L{E, target, slice, full, (unsigned)N, h->stream, false, nullptr, nullptr};
+    if (h->ev_open && h->ev_ext && !h->ev_ext_done) { L.ext = true; L.ev_a = h->events.back().a; L.ev_b = h->events.back().b; h->ev_ext_done = true; }
+    if (langevin_launch(L, h->dev, ap)) return fail(h, "this build holds no Langevin-family kernels (PTE_DEV_NO_LANGEVIN)");
+    return 0;
+}
+
 int launch_explorer_kind(pte_engine *h, int64_t scan, int kind);
 int launch_explore(pte_engine *h, int64_t scan) {
     (void)scan;
@@ -315,17 +328,7 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
             ap.ref_prec = h->cfg.target_params[0]; ap.log3 = std::log(3.0);
             const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
             time_begin(h, 0, true);
-#ifdef PTE_DEV_NO_LANGEVIN
-            return fail(h, "PTE_DEV_NO_LANGEVIN build");
-#else
-            switch (E) {
-            case 1: PTE_LAUNCH1((k_explore_automala<1, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
-            case 2: PTE_LAUNCH1((k_explore_automala<2, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
-            case 4: PTE_LAUNCH1((k_explore_automala<4, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
-            case 8: PTE_LAUNCH1((k_explore_automala<8, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
-            default: PTE_LAUNCH1((k_explore_automala<16, TGT_FUNNEL, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); break;
-            }
-#endif
+            if (launch_langevin(h, E, TGT_FUNNEL, true, false, N, ap)) return 1;
             time_end(h);
             break;
         }
@@ -369,18 +372,7 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
         const bool fun = h->cfg.target == PTE_TARGET_FUNNEL;
         time_begin(h, 0, true);
         const bool full = h->d == 64 * (int64_t)E;       // no ragged last block: the instantiation without per-lane validity masks
-#define AM_LAUNCH(EE)                                                                                         \
-        if (fun && full) PTE_LAUNCH1((k_explore_automala<EE, TGT_FUNNEL, false, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
-        else if (fun) PTE_LAUNCH1((k_explore_automala<EE, TGT_FUNNEL>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
-        else if (full) PTE_LAUNCH1((k_explore_automala<EE, TGT_MVN, false, true>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap); \
-        else PTE_LAUNCH1((k_explore_automala<EE, TGT_MVN>), dim3((unsigned)N), dim3(64), 0, h->stream, h->dev, ap);
-#ifdef PTE_DEV_NO_LANGEVIN      // development builds only (tools/build_variant.sh): three quarters of the compile time are these instantiations
-        (void)fun; (void)full; return fail(h, "PTE_DEV_NO_LANGEVIN build");
-#else
-        switch (E) { case 1: AM_LAUNCH(1) break; case 2: AM_LAUNCH(2) break; case 4: AM_LAUNCH(4) break;
-                     case 8: AM_LAUNCH(8) break; default: AM_LAUNCH(16) break; }
-#endif
-#undef AM_LAUNCH
+        if (launch_langevin(h, E, fun ? TGT_FUNNEL : TGT_MVN, false, full, N, ap)) return 1;
         time_end(h);
         break;
     }
@@ -1319,13 +1311,7 @@ int refresh_funnel_stats(pte_engine *h) {
     const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
     const double log3 = std::log(3.0);
     const unsigned N = (unsigned)h->K;
-    switch (E) {
-    case 1: hipLaunchKernelGGL(k_refresh_funnel_stats<1>, dim3(N), dim3(64), 0, h->stream, h->dev, log3); break;
-    case 2: hipLaunchKernelGGL(k_refresh_funnel_stats<2>, dim3(N), dim3(64), 0, h->stream, h->dev, log3); break;
-    case 4: hipLaunchKernelGGL(k_refresh_funnel_stats<4>, dim3(N), dim3(64), 0, h->stream, h->dev, log3); break;
-    case 8: hipLaunchKernelGGL(k_refresh_funnel_stats<8>, dim3(N), dim3(64), 0, h->stream, h->dev, log3); break;
-    default: hipLaunchKernelGGL(k_refresh_funnel_stats<16>, dim3(N), dim3(64), 0, h->stream, h->dev, log3); break;
-    }
+    langevin_refresh_funnel_stats(E, N, h->stream, h->dev, log3);
     HIP_OK(h, hipGetLastError());
     HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
@@ -1483,6 +1469,7 @@ int pte_set_rng_policy(int32_t device, uint32_t policy) {
     if (policy & ~PTE_RNG_POLICY_VALID_MASK) return fail(nullptr, "pte_set_rng_policy: invalid policy 0x%x", policy);
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, "pte_set_rng_policy: no HIP device %d", device);
     hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_rng_policy), &policy, sizeof policy);
+    if (e == hipSuccess) e = (hipError_t)langevin_set_rng_policy(policy);       // the second translation unit's copy of the word
     if (e == hipSuccess) e = hipDeviceSynchronize();
     return e == hipSuccess ? 0 : fail(nullptr, "pte_set_rng_policy: %s", hipGetErrorString(e));
 }

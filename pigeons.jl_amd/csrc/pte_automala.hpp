@@ -10,26 +10,9 @@
 //   TGT_FUNNEL InterpolatedAD of {ScaledPrecisionNormal(p0) reference, Neal's funnel}
 //              (src/explorers/BufferedAD.jl:89-112; funnel test/supporting/dimensional-analysis.jl:36-48)
 #pragma once
-#include "pte_kernels.hpp"
+#include "pte_automala_params.hpp"
 
 namespace pte {
-
-enum { TGT_MVN = 0, TGT_FUNNEL = 2 };
-enum { ERR_AM_DENSITY = 5, ERR_AM_STEP = 6 };
-
-struct AmParams {
-    double step_size;
-    int n_refresh;
-    int precond;            // 0 identity, 1 diagonal, 2 mix-diagonal
-    double p0, p1;          // mix proportions
-    const double *target_std;   // [d] or nullptr (== `nothing`: identity, no draw)
-    int use_mh;             // scan != 1
-    int mala;               // 1: MALA (src/explorers/MALA.jl:74-97) -- fixed step size, one leapfrog, always MH
-    int slice;              // 1: SliceSampler on this path (SliceSampler.jl:24-237) with the full log potential per evaluation
-    double slice_w; int slice_p, slice_n_passes, slice_max_iter;
-    double ref_prec;        // funnel: precision of the normal reference
-    double log3;            // log(3.0) from the host libm
-};
 
 // tree over the E block sums (uniform values), E a power of two
 template <int E>

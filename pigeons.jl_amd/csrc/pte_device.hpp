@@ -18,7 +18,7 @@ constexpr uint64_t MASK52 = 0x000fffffffffffffULL;
 
 // include/pte_rng_policy.h: the conventions of Julia's Random that no fixture pins yet, one word per device, set by
 // pte_set_rng_policy (hipMemcpyToSymbol).  Read on the ziggurat tails (~3e-4 of the draws) and by the Bernoulli refresh only.
-__device__ unsigned g_rng_policy = PTE_RNG_POLICY_DEFAULT;
+static __device__ unsigned g_rng_policy = PTE_RNG_POLICY_DEFAULT;      // (one copy per translation unit: pte_set_rng_policy writes every one)
 __device__ __forceinline__ double zig_tail_neglog(double u) { return (g_rng_policy & PTE_RNG_TAIL_LOG1P) ? -log1p(-u) : -log(u); }
 __device__ __forceinline__ unsigned rng_bool_bit() { return PTE_RNG_POLICY_BOOL_BIT(g_rng_policy); }
 

@@ -473,6 +473,7 @@ __device__ __forceinline__ double dev_logaddexp(double x, double y) {
     return m + t;
 }
 
+#ifndef PTE_TU_LANGEVIN
 __global__ __launch_bounds__(256) void k_swap(EngineDev e, int even, int64_t scan_idx) {
     const int64_t N = e.N;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -531,6 +532,7 @@ __global__ __launch_bounds__(256) void k_swap(EngineDev e, int even, int64_t sca
         if (do_swap) { e.chain_of_slot[slot] = (int32_t)pc; e.slot_of_chain[pc] = slot; }
     }
 }
+#endif
 
 
 // ---------------------------------------------------------------------------------------------
@@ -546,6 +548,7 @@ __device__ __forceinline__ int64_t deo_partner(int64_t N, int even, int64_t c) {
     return (proposed == 0) ? 0 : (proposed == N + 1 ? N - 1 : proposed - 1);
 }
 
+#ifndef PTE_TU_LANGEVIN
 __global__ __launch_bounds__(256) void k_swap_stats(EngineDev e, int even, int64_t scan_idx) {
     const int64_t cl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (cl >= e.K) return;
@@ -573,7 +576,9 @@ __global__ __launch_bounds__(256) void k_swap_stats(EngineDev e, int even, int64
         else if (st == 2 && is_ref) { e.rt_state[slot] = 1; e.rt_trips[slot] += 1; }
     }
 }
+#endif
 
+#ifndef PTE_TU_LANGEVIN
 __global__ __launch_bounds__(256) void k_swap_decide(EngineDev e, int even) {
     const int64_t cl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (cl >= e.K) return;
@@ -610,9 +615,11 @@ __global__ __launch_bounds__(256) void k_swap_decide(EngineDev e, int even) {
     }
     e.slot_of_chain_alt[new_cl] = slot;
 }
+#endif
 
 // payload layout (8-byte words, sw = e.sw state words: d coordinates, or the bit-packed Ising row):
 // [0..sw) state, sw: sum x^2 / sum_pair_products, sw+1,sw+2: rng, sw+3: replica id, sw+4: round-trip state, sw+5: suff2
+#ifndef PTE_TU_LANGEVIN
 __global__ __launch_bounds__(256) void k_boundary_export(EngineDev e, int side, double *buf) {
     const int slot = e.slot_of_chain[side == 0 ? 0 : e.K - 1];
     const double *xrow = e.x + (int64_t)slot * e.ld;
@@ -626,6 +633,8 @@ __global__ __launch_bounds__(256) void k_boundary_export(EngineDev e, int side, 
         buf[e.sw + 5] = e.suff2[slot];
     }
 }
+#endif
+#ifndef PTE_TU_LANGEVIN
 __global__ __launch_bounds__(256) void k_boundary_import(EngineDev e, int side, const double *buf) {
     const int slot = e.slot_of_chain[side == 0 ? 0 : e.K - 1];
     double *xrow = e.x + (int64_t)slot * e.ld;
@@ -639,11 +648,13 @@ __global__ __launch_bounds__(256) void k_boundary_import(EngineDev e, int side, 
         e.suff2[slot] = buf[e.sw + 5];
     }
 }
+#endif
 
 // ---- device-resident boundary exchange (no host round trip per scan) -----------------------------
 // message layout (8-byte words): [0] log_ratio, [1] uniform of the boundary chain, [2 .. sw+8) payload.
 // The payload travels speculatively with the SwapStat; the receiver applies it iff the swap is accepted
 // (both sides take the same decision from the same two stats).
+#ifndef PTE_TU_LANGEVIN
 __global__ __launch_bounds__(256) void k_boundary_pack(EngineDev e, int active0, int active1, double *msg0, double *msg1) {
     const int side = blockIdx.x;
     if (!(side == 0 ? active0 : active1)) return;
@@ -663,6 +674,8 @@ __global__ __launch_bounds__(256) void k_boundary_pack(EngineDev e, int active0,
         buf[e.sw + 5] = e.suff2[slot];
     }
 }
+#endif
+#ifndef PTE_TU_LANGEVIN
 __global__ void k_boundary_stats_in(EngineDev e, int active0, int active1, const double *msg0, const double *msg1) {
     if (threadIdx.x == 0) {
         e.nbr_stat[0] = active0 ? msg0[0] : 0.0; e.nbr_stat[1] = active0 ? msg0[1] : 0.0;
@@ -670,8 +683,10 @@ __global__ void k_boundary_stats_in(EngineDev e, int active0, int active1, const
         e.bflag[0] = 0; e.bflag[1] = 0;
     }
 }
+#endif
 // runs after k_swap_decide (slot maps already flipped on the host side: e.slot_of_chain is the new map,
 // in which a boundary slot keeps its chain)
+#ifndef PTE_TU_LANGEVIN
 __global__ __launch_bounds__(256) void k_boundary_apply(EngineDev e, const double *msg0, const double *msg1, int64_t *n_applied) {
     const int side = blockIdx.x;
     if (!e.bflag[side]) return;
@@ -689,10 +704,12 @@ __global__ __launch_bounds__(256) void k_boundary_apply(EngineDev e, const doubl
         n_applied[side] += 1;
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // test kernels
 // ---------------------------------------------------------------------------------------------
+#ifndef PTE_TU_LANGEVIN
 __global__ __launch_bounds__(64) void k_test_rng(uint64_t *sg, int kind, int64_t n, double *out) {
     const int lane = lane_id();
     if (kind == 0 || kind == 3) {
@@ -730,7 +747,9 @@ __global__ __launch_bounds__(64) void k_test_rng(uint64_t *sg, int kind, int64_t
         if (lane == 0) sg[0] = dr.final_seed();
     }
 }
+#endif
 
+#ifndef PTE_TU_LANGEVIN
 __global__ __launch_bounds__(64) void k_test_sqr_norm(const double *x, int64_t rows, int64_t d, int nlu, double *out) {
     const int lane = lane_id();
     const int64_t r = blockIdx.x;
@@ -748,5 +767,6 @@ __global__ __launch_bounds__(64) void k_test_sqr_norm(const double *x, int64_t r
     double S = upper_tree_root_dyn(acc, nlu);
     if (lane == 0) out[r] = S;
 }
+#endif
 
 }  // namespace pte
