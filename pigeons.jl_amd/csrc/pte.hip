@@ -339,7 +339,7 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
             DISPATCH_NLU(h->nlu, k_explore_slice, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp);
         } else if (h->slice_impl == 8) {
             // shrinkage steps for every hypothesis: PTE_S8_BS = 9, re-measured after every change of the round's cost (tools/bench_variant.py)
-            // 14 KB of LDS per replica (512-draw window) allow 11 replicas per CU; beyond 256 x 11 the 10 KB variant keeps 16
+            // beyond two replicas per SIMD (PTE_S8_TWIN_FROM = 2048: the 512-draw kernel holds 189 VGPRs) the 10 KB / 128-VGPR variant keeps 16 per CU
             const bool fast_ok = sp.p > PTE_S8_BD && sp.p <= 20 && sp.max_iter >= PTE_S8_BS;       // what the FAST instantiation assumes (pte_slice8.hpp)
             if (N <= PTE_S8_TWIN_FROM && fast_ok) { DISPATCH_NLU_M(h->nlu, k_explore_slice8, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp); }
             else if (N <= PTE_S8_TWIN_FROM) { DISPATCH_NLU_M(h->nlu, k_explore_slice8_generic, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp); }

@@ -769,7 +769,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES
 #define PTE_S8_TWIN_WAVES PTE_S8_WAVES
 #endif
 #ifndef PTE_S8_TWIN_FROM                 // more local replicas than this run the 10 KB-LDS twin
-#define PTE_S8_TWIN_FROM (256 * 11)
+// Two waves of the 512-draw kernel per SIMD: scheduled for instruction-level parallelism (-amdgpu-sched-strategy=max-ilp: 1.3-2.3 % faster with one
+// wave per SIMD) it holds 189 VGPRs, and a third wave per SIMD would wait for the first two -- 2304 .. 2816 replicas took 1.58 ms per scan at
+// d = 1024 where the twin takes 1.45 (its LDS allowed 11 replicas per CU = 2816, the bound of rounds 2-3).
+#define PTE_S8_TWIN_FROM (256 * 8)
 #endif
 template <int NLU, int S8_BS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_TWIN_WAVES, PTE_S8_TWIN_WAVES))) void k_explore_slice8_lds10k(EngineDev e, SliceParams sp) {

@@ -3,7 +3,7 @@ this engine) -- VERDICT r02 "next round" item 1:
 
   * the metric configuration itself, toy_mvn_target(1024), N = 1024, SliceSampler, rounds 1-2 (6 scans x 1024 replicas)
   * BASELINE configs[2] at full size: funnel d = 128, N = 1024, AutoMALA, 3 rounds
-  * k_explore_slice8_lds10k -- the kernel every run with more than 2816 chains per GPU launches (the strong-scaling anchor) --
+  * k_explore_slice8_lds10k -- the kernel every run with more than 2048 chains per GPU launches (the strong-scaling anchor) --
     at N = 3000, d = 70 and N = 4096, d = 256, with kernel_name() asserted
   * ToyExplorer at N = 8192, d = 4096 (the shape the HBM-bound kernels are profiled at), 2 rounds
 

@@ -1082,7 +1082,7 @@ def test_slice_parameters_off_the_defaults(P, impl):
 
 
 def test_slice_kernel_many_replicas_equals_sequential_kernel(P):
-    """More than 256 x 11 replicas on one GPU run the default SliceSampler kernel with the 256-draw window (10 KB of LDS, 16
+    """More than 2048 replicas on one GPU (two waves of the 512-draw kernel per SIMD) run the default SliceSampler kernel with the 256-draw window (10 KB of LDS, 16
     resident replicas per CU); same bits as the plain sequential kernel (which the oracle pins at small sizes)."""
     def run(impl):
         pt = P.PT(P.Inputs(target=P.toy_mvn_target(70), n_chains=3000, n_rounds=3, seed=11, explorer=P.SliceSampler(),

@@ -10,16 +10,24 @@ SRC = os.path.join(ROOT, "pigeons.jl_amd", "csrc", "pte.hip")
 
 
 def main():
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-align-all-nofallthru-blocks=6", "-fPIC", "-shared",
-           "-Wno-unused-value", "-Rpass-analysis=kernel-resource-usage", *sys.argv[1:], "-o", "/tmp/libpte_resources.so", SRC, "-ldl"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode:
-        sys.exit(r.stderr)
-    blocks = re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]
+    # the product's two translation units with the flags __graft_entry__.build_hip gives them
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    err = ""
+    cmds = []
+    for src, unit_flags in g.UNITS:
+        cmd = [g.HIPCC, *g.FLAGS, *unit_flags, "-Rpass-analysis=kernel-resource-usage", *sys.argv[1:], "-c", "-o", "/tmp/libpte_resources.o", os.path.join(g.CSRC, src)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            sys.exit(r.stderr)
+        err += r.stderr
+        cmds.append(" ".join(cmd[1:]))
+    blocks = re.split(r"remark: [^\n]*Function Name: ", err)[1:]
     keys = [("vgpr", r" VGPRs"), ("agpr", r"AGPRs"), ("sgpr", r"TotalSGPRs"), ("spilled_vgpr", r"VGPRs Spill"), ("spilled_sgpr", r"SGPRs Spill"),
             ("scratch_B_per_lane", r"ScratchSize \[bytes/lane\]"), ("waves_per_simd", r"Occupancy \[waves/SIMD\]"),
             ("lds_B", r"LDS Size \[bytes/block\]")]
-    print("# " + " ".join(cmd[1:]))
+    for c in cmds:
+        print("# " + c)
     print("%-78s " % "kernel" + " ".join("%s" % k for k, _ in keys))
     for b in blocks:
         name = b.split("\n")[0].split(" [")[0].strip()

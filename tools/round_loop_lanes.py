@@ -11,7 +11,7 @@ KERNEL = "_ZN3pte16k_explore_slice8ILi4ELi9EEEvNS_9EngineDevENS_11SliceParamsE"
 
 def main():
     out = os.path.join(tempfile.gettempdir(), "pte_round_loop.s")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-align-all-nofallthru-blocks=6", "-Wno-unused-value", "--cuda-device-only", "-S",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-align-all-nofallthru-blocks=6", "-DPTE_SPLIT_LANGEVIN", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-Wno-unused-value", "--cuda-device-only", "-S",
            *sys.argv[1:], "-o", out, os.path.join(ROOT, "pigeons.jl_amd", "csrc", "pte.hip")]
     if not (os.environ.get("ROUND_LOOP_REUSE") and os.path.exists(out)):
         subprocess.run(cmd, check=True, capture_output=True)

@@ -72,13 +72,17 @@ def analyse(name, body):
 
 
 def main():
-    out = os.path.join(tempfile.gettempdir(), "pte_round_loop.s")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-align-all-nofallthru-blocks=6", "-Wno-unused-value", "--cuda-device-only", "-S",
-           "-o", out, os.path.join(ROOT, "pigeons.jl_amd", "csrc", "pte.hip")]
-    if not (os.environ.get("ROUND_LOOP_REUSE") and os.path.exists(out)):
-        subprocess.run(cmd, check=True, capture_output=True)
-    lines = open(out).read().split("\n")
-    print("# " + " ".join(cmd[1:]))
+    # the product's two translation units with the flags __graft_entry__.build_hip gives them
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    lines = []
+    for src, unit_flags in g.UNITS:
+        out = os.path.join(tempfile.gettempdir(), "pte_loops_%s.s" % os.path.splitext(src)[0])
+        cmd = [g.HIPCC, *[f for f in g.FLAGS if f != "-fPIC"], *unit_flags, "--cuda-device-only", "-S", "-o", out, os.path.join(g.CSRC, src)]
+        if not (os.environ.get("ROUND_LOOP_REUSE") and os.path.exists(out)):
+            subprocess.run(cmd, check=True, capture_output=True)
+        lines += open(out).read().split("\n")
+        print("# " + " ".join(cmd[1:]))
     print("# per loop: the blocks whose INNERMOST loop it is (a block of a nested loop is counted with the nested loop only)\n")
     for sub in (sys.argv[1:] or DEFAULT):
         name, body = kernel_body(lines, sub)
