@@ -11,8 +11,10 @@ KERNEL = "_ZN3pte16k_explore_slice8ILi4ELi9EEEvNS_9EngineDevENS_11SliceParamsE"
 
 def main():
     out = os.path.join(tempfile.gettempdir(), "pte_round_loop.s")
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-align-all-nofallthru-blocks=6", "-DPTE_SPLIT_LANGEVIN", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-Wno-unused-value", "--cuda-device-only", "-S",
-           *sys.argv[1:], "-o", out, os.path.join(ROOT, "pigeons.jl_amd", "csrc", "pte.hip")]
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g                     # the flags the product gives pte.hip
+    src, unit_flags = g.UNITS[0]
+    cmd = [g.HIPCC, *[f for f in g.FLAGS if f != "-fPIC"], *unit_flags, "--cuda-device-only", "-S", *sys.argv[1:], "-o", out, os.path.join(g.CSRC, src)]
     if not (os.environ.get("ROUND_LOOP_REUSE") and os.path.exists(out)):
         subprocess.run(cmd, check=True, capture_output=True)
     lines = open(out).read().split("\n")
