@@ -531,6 +531,29 @@ def test_automala_mvn_parity(P, N, d, rounds, seed):
         _check_am_round(P, pt, ref, rtol=1e-9)
 
 
+def test_automala_follows_the_rng_policy(P):
+    """libpte is built from two translation units and each holds its own copy of the policy word (include/pte_rng_policy.h;
+    csrc/pte_automala_params.hpp): pte_set_rng_policy must reach the Langevin-family kernels too.  AutoMALA draws ~0.3 M momentum
+    normals here, ~100 of them on the ziggurat's tail, whose formula the policy picks: engine == oracle under -log1p(-u), and the
+    oracle under the default policy is somewhere else (the switch is live)."""
+    from pigeons_amd.engine import set_rng_policy
+    pol = O.RNG_TAIL_LOG1P
+    N, d, rounds, seed = 24, 256, 4, 5
+    try:
+        set_rng_policy(pol); O.set_rng_policy(pol)
+        pt, ref = _mk_am(P, N, d, rounds, "mvn", seed)
+        for _ in range(rounds):
+            _check_am_round(P, pt, ref, rtol=1e-9)
+        x_pol = ref.states()[0].copy()
+        set_rng_policy(0); O.set_rng_policy(0)
+        _, ref0 = _mk_am(P, N, d, rounds, "mvn", seed)
+        for _ in range(rounds):
+            ref0.run_round()
+        assert not np.array_equal(ref0.states()[0], x_pol)
+    finally:
+        set_rng_policy(0); O.set_rng_policy(0)
+
+
 @pytest.mark.parametrize("precond", ["IdentityPreconditioner", "DiagonalPreconditioner"])
 def test_automala_other_preconditioners(P, precond):
     pt, ref = _mk_am(P, 5, 20, 5, "mvn", 4, precond=getattr(P, precond)())
