@@ -384,9 +384,9 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
                 unsigned nxt = ONE_WORD ? 0u : lds_word(words, row + 1);
                 ChunkStatics st0 = chunk_statics(up, dn, cur, cur >> 1, 0), st1 = st0;      // (chunk 0 never looks at bit 31's right neighbour)
                 for (int wj = 0; wj < W; ++wj) {
-                    const bool more = wj + 1 < W;
-                    unsigned pf_up = 0, pf_dn = 0, pf_nx = 0;                       // (every lane reads the same address: a broadcast)
-                    if (more) { pf_up = words[rowu + wj + 1]; pf_dn = words[rowd + wj + 1]; pf_nx = words[row + wj + 2]; }    // (the last one: two words of padding behind the lattice)
+                    // (every lane reads the same address: a broadcast.  Unconditional: behind a row's last word these are words of the next
+                    // row or of the two words of padding behind the lattice, and nobody uses them -- a branch around three loads costs more)
+                    const unsigned pf_up = words[rowu + wj + 1], pf_dn = words[rowd + wj + 1], pf_nx = words[row + wj + 2];
                     const unsigned rightbit = (wj == W - 1) ? (first_updated & 1u) : (nxt & 1u);
 #if PTE_ISING_STORE == 0
                     const unsigned cur0 = cur;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
 #ifdef PTE_PROFILE_ISING_SECTIONS
                         const unsigned long long pa = __builtin_readcyclecounter();
 #endif
-                        if (p + 16 > 64) {
+                        if (__builtin_expect(p + 16 > 64, 0)) {           // (one chunk in ~5: laid out behind the loop, so that the common path falls through -- a lone wave refetches after a taken branch)
                             seed += (uint64_t)p * gamma; unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma)); p = 0;
                             classify();
                         }
