@@ -126,7 +126,7 @@ struct AmTarget {
         for (int j = 0; j < E; ++j) { const double dx = x[j] - VM(j); t[j] = valid(j) ? (VC0(j) - VI2(j) * (dx * dx)) : 0.0; }
         return tree_sum_regs<E>(t);
     }
-    __device__ __forceinline__ double ref_lp(const double (&x)[E], double S) const { return vr ? variational_lp(x) : ref_nhp * S; }
+    __device__ __forceinline__ double ref_lp(const double (&x)[E], double S) const { if (__builtin_expect(vr, 0)) return variational_lp(x); return ref_nhp * S; }
     __device__ __forceinline__ bool valid(int j) const { return FULL || 64 * (int64_t)j + lane < d; }
 
     // funnel: log density and (optionally) gradient; S = sum x^2 supplied by the caller
@@ -230,7 +230,7 @@ struct AmTarget {
         const double l1 = ref_lp(x, S);
         logdens += l1 * omb;
         logdens += l2 * beta;
-        if (vr) {                                    // BufferedAD{GaussianReference}: -1/s^2 (x - m)
+        if (__builtin_expect(vr, 0)) {               // BufferedAD{GaussianReference}: -1/s^2 (x - m)   (the fixed reference falls through)
 #pragma unroll
             for (int j = 0; j < E; ++j) g[j] = (VGF(j) * (x[j] - VM(j))) * omb + g2[j] * beta;
         } else {
@@ -391,12 +391,12 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         const double ke_mid = 0.5 * pp_mid;
         ke_out = ke_mid;
         const double cur = logp - ke_mid;
-        if (!isfinite(cur)) return false;
+        if (__builtin_expect(!isfinite(cur), 0)) return false;          // (rare: laid out behind the loop -- a lone wave refetches after every taken branch)
 #pragma unroll
         for (int j = 0; j < E; ++j) p[j] = p[j] + half * g[j];
         const double sq = sqr_norm_regs<E>(p);
         ke_out = 0.5 * sq;
-        if (!isfinite(sq)) return false;
+        if (__builtin_expect(!isfinite(sq), 0)) return false;
         return true;
     };
     // auto_step_size (:184-214): returns the exponent; h_before = log_joint at the start point (g0 / lp0 valid there).
