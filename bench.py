@@ -240,7 +240,7 @@ def extra_configs(P):
         ("C3 funnel d=128, n_chains=1024, AutoMALA", lambda: P.Inputs(target=P.Funnel(128), reference=P.ScaledPrecisionNormalLogPotential(1 / 9., 128), n_chains=1024, explorer=P.AutoMALA(), record=rec, n_rounds=8, show_report=False), 4, 32),
         ("C4 shard: toy_mvn_target(4096), 1024 of 8192 chains, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(4096), n_chains=1024, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 2, 8),
         ("C4 on ONE GPU (strong-scaling anchor): toy_mvn_target(4096), n_chains=8192, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(4096), n_chains=8192, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 1, 4),
-        ("C5 shard: Ising 256x256, 512 of 4096 chains, IsingMetropolis(3 sweeps)", lambda: P.Inputs(target=P.IsingLogPotential(1.0, 256), n_chains=512, record=rec, n_rounds=8, show_report=False), 1, 4),
+        ("C5 shard: Ising 256x256, 512 of 4096 chains, IsingMetropolis(3 sweeps)", lambda: P.Inputs(target=P.IsingLogPotential(1.0, 256), n_chains=512, record=rec, n_rounds=8, show_report=False), 4, 8),
     ]
     out = []
     for name, mk, warm, scans in cfgs:
