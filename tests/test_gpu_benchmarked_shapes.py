@@ -5,6 +5,8 @@ this engine) -- VERDICT r02 "next round" item 1:
   * BASELINE configs[2] at full size: funnel d = 128, N = 1024, AutoMALA, 3 rounds
   * k_explore_slice8_lds10k -- the kernel every run with more than 2048 chains per GPU launches (the strong-scaling anchor) --
     at N = 3000, d = 70 and N = 4096, d = 256, with kernel_name() asserted
+  * the same kernel at the tree depths it is QUOTED at: N = 2304, d = 1024 against the oracle; N = 2100 / 8192 at
+    d = 4096, N = 2100 at d = 1500, N = 2500 at d = 1024 bit for bit against the sequential kernel + the run's properties
   * ToyExplorer at N = 8192, d = 4096 (the shape the HBM-bound kernels are profiled at), 2 rounds
 
 Reference procedure being restated by the oracle: src/explorers/SliceSampler.jl:24-237, src/explorers/AutoMALA.jl:106-182,
@@ -54,6 +56,57 @@ def test_many_replica_slice_kernel_against_the_oracle(P, N, d, rounds, seed):
     assert pt.replicas.kernel_name() == "k_explore_slice8_lds10k"
     for _ in range(rounds):
         _check_round(P, pt, ref)
+
+
+def test_strong_scaling_anchor_kernel_against_the_oracle(P):
+    """k_explore_slice8_lds10k<4, 9> -- the tree depth of d = 1024 with more than 2048 replicas on the GPU, one of
+    the instantiations that spill VGPRs to scratch (profiles/r04_kernel_resources.txt) -- rounds 1-2 against the ORACLE's full O(d)
+    recompute (SliceSampler.jl:89-237): states, RNG counters, chains, index process, recorders, schedule (about a minute of one host core)."""
+    pt, ref = _mk_slice(P, 2304, 1024, 2, seed=3)
+    assert pt.replicas.kernel_name() == "k_explore_slice8_lds10k"
+    for _ in range(2):
+        _check_round(P, pt, ref)
+
+
+def _run_slice_rounds(P, N, d, rounds, seed, impl):
+    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, seed=seed, explorer=P.SliceSampler(),
+                       record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False), debug_kernel=impl)
+    assert pt.replicas.kernel_name() == ("k_explore_slice" if impl == 1 else "k_explore_slice8_lds10k")
+    out = []
+    for _ in range(rounds):
+        assert P.next_round(pt)
+        red = P.run_one_round(pt); P.adapt(pt, red)
+        out.append((red.index_process.copy(), red.swap_acceptance_pr[0].copy(), red.explorer_n_steps[0].copy(), red.explorer_acceptance_pr[0].copy(),
+                    red.log_sum_ratio[0].copy(), np.array(pt.shared.tempering.schedule.grids).copy()))
+    return pt, out
+
+
+@pytest.mark.parametrize("N,d,rounds,seed", [
+    (2100, 4096, 2, 7),       # <6, 9>: the deepest tree, just past the switch to the 10 KB kernel
+    (8192, 4096, 2, 1),       # <6, 9> at BASELINE configs[3] on ONE GPU: the shape behind "C4 on one GPU" in the bench line and DESIGN's strong-scaling anchor
+    (2100, 1500, 2, 4),       # <5, 9>: 24 blocks, a ragged 256-coordinate block and a tree padded to 32
+    (2500, 1024, 3, 9),       # <4, 9> once more, three rounds
+])
+def test_strong_scaling_anchor_kernel_equals_sequential_kernel(P, N, d, rounds, seed):
+    """the instantiations of k_explore_slice8_lds10k for d = 1024 ... 4096 -- the ones with scratch spills, the ones
+    every N >= 2304 cell of DESIGN's chains-per-GPU table and the 1-GPU strong-scaling anchor run -- bit for bit against the plain sequential
+    kernel (debug_kernel = 1, which the oracle pins at every size it can afford, incl. d = 4096 and the metric shape), then the
+    size-independent properties of the run (tests/test_gpu_configs.py)."""
+    from test_gpu_configs import _mvn_properties
+    pa, a = _run_slice_rounds(P, N, d, rounds, seed, 1)
+    sa = pa.replicas.states(); del pa
+    pb, b = _run_slice_rounds(P, N, d, rounds, seed, 0)
+    sb = pb.replicas.states(); del pb
+    for r, (ra, rb) in enumerate(zip(a, b)):
+        for k, (x, y) in enumerate(zip(ra, rb)):
+            assert np.array_equal(x, y), (r, k)
+    for x, y in zip(sa, sb):
+        assert np.array_equal(x, y)
+    del a, b, sa, sb
+    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=2, seed=seed + 100, explorer=P.SliceSampler(),
+                       record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False))
+    assert pt.replicas.kernel_name() == "k_explore_slice8_lds10k"
+    _mvn_properties(P, pt, N, d, 2)
 
 
 def test_config3_full_size_against_the_oracle(P):

@@ -17,10 +17,14 @@ def run(impl, N, d, seed, rounds, w, p):
 
 bad = 0; n = 0
 shapes = [(64, 300), (33, 64), (16, 1000), (128, 129), (8, 4096), (50, 7)]
+if os.environ.get("STRESS_MANY", "1") != "0":      # more than 2048 replicas: k_explore_slice8_lds10k at the tree depths it is quoted at (<4,9>, <6,9>)
+    shapes += [(2304, 1024), (2100, 4096)]
 params = [(10.0, 20), (1.0, 20), (0.2, 4), (100.0, 20)]
 seed0 = int(os.environ.get("STRESS_SEED0", "1")); nseeds = int(os.environ.get("STRESS_NSEEDS", "6")); extra = int(os.environ.get("STRESS_EXTRA_ROUNDS", "0"))
 for (N, d), (w, p), seed in itertools.product(shapes, params, range(seed0, seed0 + nseeds)):
-    rounds = (4 if d >= 1000 else 5) + extra
+    rounds = (2 if N > 2048 else 4 if d >= 1000 else 5) + extra
+    if N > 2048 and seed >= seed0 + 2:          # the big shapes: two seeds per parameter set (16 runs of the sequential kernel at 2304 x 1024 / 2100 x 4096)
+        continue
     a, sa = run(1, N, d, seed, rounds, w, p)
     b, sb = run(int(os.environ.get("STRESS_IMPL", "0")), N, d, seed, rounds, w, p)      # 0 = the default kernel; 2 / 5 / 7: test build
     ok = all(np.array_equal(x, y) for ra, rb in zip(a, b) for x, y in zip(ra, rb)) and all(np.array_equal(x, y) for x, y in zip(sa, sb))
