@@ -167,15 +167,16 @@ def cpu_baseline(d, target_seconds=12.0):
 
 def hbm_kernels(P):
     """The kernels the HBM roofline applies to, untimed for the headline: ToyExplorer at N = 8192, d = 4096 (256 MiB of
-    state).  Durations are HIP events carried by the launch itself (hipExtLaunchKernelGGL: the kernel's own begin and end, what rocprofv3's kernel trace reports) in THIS run (pte_timing_*; k_init is timed at pte_create: five constructions, the fastest reported);
+    state).  Durations are HIP events carried by the launch itself (hipExtLaunchKernelGGL: the kernel's own begin and end, what rocprofv3's kernel trace reports) in THIS run (pte_timing_*; k_init is timed at pte_create: six constructions, the mean of the five warm ones reported, their minimum beside it);
     bytes are algorithmic: k_explore_toy / k_init write 8 d + 32 B per replica, k_swap moves 96 B per replica."""
     N, d = 8192, 4096
     init_all = []
-    for _ in range(5):                                   # k_init runs once per pte_create: five constructions (the first one cold, fresh allocations first-touched)
+    for _ in range(6):                                   # k_init runs once per pte_create: six constructions (the first one cold, fresh allocations first-touched)
         pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=8, record=[P.round_trip, P.log_sum_ratio], show_report=False))
         e = pt.replicas
         init_all.append(e.timing(2)[0])
-    init_ms = min(init_all)
+    init_warm = init_all[1:]                             # the first construction is a cold launch (code object load, first touch)
+    init_ms = sum(init_warm) / len(init_warm)
     e.run_scans(1, 4)
     e.timing_reset(True)
     e.run_scans(1, 16)
@@ -187,7 +188,9 @@ def hbm_kernels(P):
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         out[name] = {"bytes_per_launch": nbytes, "avg_launch_us": ms * 1e3, "GBps": gbs,
                      "frac_of_6.29TBps": gbs / HBM_ACHIEVABLE_GBS, "frac_of_8TBps": gbs / HBM_PEAK_GBS}
-    out["k_init"]["launch_us_of_5_constructions"] = [m * 1e3 for m in init_all]      # (avg_launch_us is their minimum: the first is a cold launch)
+    out["k_init"]["launch_us_of_6_constructions"] = [m * 1e3 for m in init_all]      # avg_launch_us is the MEAN of the five warm ones (the first is a cold launch) ...
+    out["k_init"]["min_launch_us"] = min(init_all) * 1e3                              # ... the minimum is reported separately, not as the average
+    out["k_init"]["GBps_at_min_launch"] = (8 * d + 32) * N / (min(init_all) * 1e-3) / 1e9
     e.timing_reset(False)
     return out
 
@@ -204,28 +207,60 @@ def invariance_check(P, d, total_chains, explorer_name, rank, world, local_rank,
     expl = P.SliceSampler() if explorer_name == "slice" else P.ToyExplorer()
     mk = lambda: P.Inputs(target=P.toy_mvn_target(d), n_chains=n, n_rounds=3, explorer=expl, seed=7,
                           record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False, device=local_rank)
-    ok = True
+    def agree(flag_ok):
+        """MIN over ranks of a local ok flag: every rank learns of a failure anywhere BEFORE it enters the next step's collectives"""
+        flag = torch.tensor([1 if flag_ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
+    # (1) the sharded run, every rank in lock step; a rank that fails says so at the next agreement point and all stop together
+    #     (libpte's RCCL exchanges inside run_one_round need every rank: nobody may step alone)
+    pt, sharded, err = None, [], None
     try:
         pt = P.PT(mk(), rank=rank, world=world)
-        one = P.PT(mk()) if rank == 0 else None
-        for _ in range(3):
-            next_round(pt); red = run_one_round(pt); adapt(pt, red)
-            if rank == 0:
-                next_round(one); ra = run_one_round(one); adapt(one, ra)
-                ok = ok and np.array_equal(ra.index_process, red.index_process) and ra.round_trip == red.round_trip \
-                    and np.array_equal(ra.swap_acceptance_pr[0], red.swap_acceptance_pr[0]) and np.array_equal(ra.log_sum_ratio[0], red.log_sum_ratio[0]) \
-                    and np.array_equal(one.shared.tempering.schedule.grids, pt.shared.tempering.schedule.grids)
-        x, chain, rng = pt.shards.states()
-        if rank == 0:
-            xa, ca, ga = one.replicas.states()
-            ok = ok and np.array_equal(x, xa) and np.array_equal(chain, ca) and np.array_equal(rng, ga)
-        pt.replicas.comm_destroy()
     except Exception as exc:
-        sys.stderr.write("bench.py rank %d: invariance check failed to run: %r\n" % (rank, exc))
-        ok = False
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    return bool(int(flag.item()))
+        err = exc
+    ok = agree(err is None)
+    for _ in range(3):
+        if not ok:
+            break
+        try:
+            next_round(pt); red = run_one_round(pt); adapt(pt, red)
+            sharded.append((red.index_process.copy(), red.round_trip, red.swap_acceptance_pr[0].copy(), red.log_sum_ratio[0].copy(),
+                            np.array(pt.shared.tempering.schedule.grids).copy()))
+        except Exception as exc:
+            err = exc
+        ok = agree(err is None)
+    states = None
+    if ok:
+        try:
+            states = pt.shards.states()                 # (an all-gather inside libpte: still in lock step)
+        except Exception as exc:
+            err = exc
+        ok = agree(err is None)
+    if pt is not None:
+        try:
+            pt.replicas.comm_destroy()
+        except Exception as exc:
+            err = err or exc
+    # (2) rank 0's single-engine run and the comparisons: only AFTER every collective of the sharded run is done, so an exception here
+    #     cannot leave the peers waiting inside a collective (they go straight to the final agreement)
+    if ok and rank == 0:
+        try:
+            one = P.PT(mk())
+            for r in range(3):
+                next_round(one); ra = run_one_round(one); adapt(one, ra)
+                ip, rt, sw, ls, gr = sharded[r]
+                ok = ok and np.array_equal(ra.index_process, ip) and ra.round_trip == rt and np.array_equal(ra.swap_acceptance_pr[0], sw) \
+                    and np.array_equal(ra.log_sum_ratio[0], ls) and np.array_equal(one.shared.tempering.schedule.grids, gr)
+            xa, ca, ga = one.replicas.states()
+            ok = ok and np.array_equal(states[0], xa) and np.array_equal(states[1], ca) and np.array_equal(states[2], ga)
+        except Exception as exc:
+            err = exc
+            ok = False
+    if err is not None:
+        sys.stderr.write("bench.py rank %d: invariance check failed to run: %r\n" % (rank, err))
+    return agree(ok)
 
 
 def extra_configs(P):
@@ -490,9 +525,10 @@ def main():
         "round_trip_rate": rt["round_trip_rate"] if rt else None, "n_round_trips": rt["n_round_trips"] if rt else None,
         "n_tempered_restarts": rt["n_tempered_restarts"] if rt else None, "round_trip": rt,
         "lp_evals_per_replica_step": lp_evals,
-        "roofline": {"bound": "instruction_issue" if args.explorer == "slice" else "hbm", "kernel": kernel_name,
-                     # what binds the SliceSampler kernel is the issue of ONE wave per replica (frac_of_issue_floor); the HBM figures the
-                     # contract asks for stay beside it: achieved = algorithmic bytes / launch duration, frac = achieved / 8 TB/s
+        "roofline": {"bound": "hbm", "limited_by": "instruction_issue" if args.explorer == "slice" else "hbm", "kernel": kernel_name,
+                     # the contract's roofline: bound = "hbm" (no MFMA on this path), achieved = algorithmic bytes / launch duration, frac =
+                     # achieved / 8 TB/s -- well under 1 % for the SliceSampler kernel BY CONSTRUCTION: what limits it is the
+                     # instruction issue of ONE wave per replica (limited_by, frac_of_issue_floor)
                      "frac_of_issue_floor": (issue or {}).get("frac_of_issue_floor"),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "hbm_frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": ex_avg_ms, "launches": ex_n,
@@ -517,10 +553,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline(d)
             cb = out["cpu_baseline"]
             if cb and cb.get("value"):
-                # BASELINE.md publishes no number for this metric; the ratio to the restated CPU baseline timed in this run is given
-                # instead, with its meaning: one GPU against the `cores` host cores the box grants (a reported baseline, not a target)
-                out["vs_baseline"] = value / cb["value"]
-                out["vs_baseline_note"] = "value / cpu_baseline.value: %d GPU(s) against %s host core(s) running the restated CPU path (kind = %s), not a published number" % (world, cb.get("cores"), cb.get("kind"))
+                # BASELINE.md publishes no number for this metric, so `vs_baseline` stays null (the contract).  The ratio to the restated CPU
+                # path timed in this run is a separate, fully labelled object: ONE GPU against the `cores` host cores this box grants the
+                # process (the driver's box: 1) running the oracle's O(d)-per-evaluation port -- a reported baseline, neither a speed-up over
+                # Pigeons.jl on a realistic host nor a target
+                out["vs_restated_cpu_port"] = {"ratio": value / cb["value"], "gpus": world, "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                               "per_core_replica_steps_per_s": cb.get("per_core"),
+                                               "note": "value / cpu_baseline.value; cpu_baseline is the restated CPU path (kind = port) on %s host core(s), "
+                                                       "not Pigeons.jl and not a published number" % cb.get("cores")}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

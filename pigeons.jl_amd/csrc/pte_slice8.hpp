@@ -348,6 +348,11 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
                     dL = nl_ ? dc : dL;
                     dR = nr_ ? dc : dR;
                 }
+#if !(PTE_S8_BD >= 1 && PTE_S8_BD <= 4) || defined(PTE_S8_DOUBLING_SELECTS)
+                // the hand-written block is compiled out in this variant build: DBL_MODE 2 would run the select loop above and leave dmin_lr at 0.0
+                // (dbl_ok always true, lane 0's further doublings never run -- silently wrong samples); such builds must ask for DBL_MODE 0 or 1
+                static_assert(DBL_MODE != 2, "PTE_S8_DBL_MODE == 2 needs the v_cmpx doubling block: 1 <= PTE_S8_BD <= 4 and no PTE_S8_DOUBLING_SELECTS");
+#endif
                 if constexpr (DBL_MODE != 2) dmin_lr = fmin(dL, dR);
                 // ... and the rest for the certain hypothesis only.  (Round 4 built the alternative -- no test inside the round, a round whose
                 // lane 0 ran out of a budget or met a slow-path exponential redoes lane 0 without budgets out of line and runs the tail again --

@@ -68,6 +68,16 @@ EXPORTS = [
 ]
 
 _libs = {}
+_comm_override_allowed = False      # the opt-in to $PTE_RCCL_LIB lives in a static of EACH loaded library: applied to all of them, now and at load
+
+
+def comm_allow_library_override(allow=True):
+    """pte_comm_allow_library_override on every libpte build this process has mapped (libpte.so, the test builds, a $PTE_LIB build) and on
+    every one it maps later: the flag is a function-local static of the library, so each build has its own copy."""
+    global _comm_override_allowed
+    _comm_override_allowed = bool(allow)
+    for L in _libs.values():
+        L.pte_comm_allow_library_override(1 if allow else 0)
 
 
 def load(path=None):
@@ -155,5 +165,7 @@ def load(path=None):
     for name in EXPORTS:
         if name not in ("pte_last_error", "pte_boundary_payload_bytes", "pte_get_stream", "pte_shard_message_bytes", "pte_kernel_name"):
             getattr(L, name).restype = C.c_int
+    if _comm_override_allowed:
+        L.pte_comm_allow_library_override(1)
     _libs[path] = L
     return L

@@ -318,13 +318,16 @@ def get_rng_policy(device=0):
 
 
 def comm_allow_library_override(allow=True):
-    """Opt in to $PTE_RCCL_LIB (tests: an RCCL stand-in).  Without it a set variable makes every pte_comm_* call fail."""
-    _lib.load().pte_comm_allow_library_override(1 if allow else 0)
+    """Opt in to $PTE_RCCL_LIB (tests: an RCCL stand-in).  Without it a set variable makes every pte_comm_* call fail.  The flag is per
+    loaded library (a static inside each build): it is applied to the default library, to every other build already mapped
+    (Engine(test_build=...)) and to those mapped later."""
+    _lib.load()
+    _lib.comm_allow_library_override(allow)
 
 
-def comm_library():
-    """(file the transport's entry points come from, what its ncclGetVersion reports)"""
-    L = _lib.load()
+def comm_library(test_build=False):
+    """(file the transport's entry points come from, what its ncclGetVersion reports) -- of the default library, or of the test build"""
+    L = _lib.load(_lib.TEST_LIB_PATH if test_build else None)
     buf = C.create_string_buffer(1024)
     ver = C.c_int32(0)
     if L.pte_comm_library(buf, 1024, C.byref(ver)) != 0:

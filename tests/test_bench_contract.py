@@ -39,12 +39,16 @@ def test_single_gpu_line_has_the_contract_fields():
     j = json.loads(lines[0])
     assert j["metric"] == BASELINE["metric"] and j["unit"] == "replica-steps/s" and j["dtype"] == "f64"
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["higher_is_better"] is True
-    # BASELINE.md publishes no number: the ratio to the CPU baseline timed in the same run, labelled as such
-    assert abs(j["vs_baseline"] - j["value"] / j["cpu_baseline"]["value"]) < 1e-9 * j["vs_baseline"] and "not a published number" in j["vs_baseline_note"]
+    # BASELINE.md publishes no number: vs_baseline is null (the contract); the ratio to the restated CPU port timed in the same run lives
+    # under its own key with the core count and the kind inline (a bare 5859x must not travel as "a speed-up over the reference")
+    assert j["vs_baseline"] is None and "vs_baseline_note" not in j
+    v = j["vs_restated_cpu_port"]
+    assert abs(v["ratio"] - j["value"] / j["cpu_baseline"]["value"]) < 1e-9 * v["ratio"] and v["cores"] == j["cpu_baseline"]["cores"] and v["kind"] == "port"
+    assert "not Pigeons.jl" in v["note"] and "not a published number" in v["note"]
     assert j["scaling"] == "weak" and j["data"] == "synthetic" and "workload" in j["config"] and "model" not in j["config"]
     assert abs(j["value"] - 1024 * 3 / (j["ms_per_step"] * 3e-3)) < 1e-6 * j["value"]
     r = j["roofline"]
-    assert r["bound"] == "instruction_issue" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k_explore_slice8"      # what binds; the HBM figures stay beside it
+    assert r["bound"] == "hbm" and r["limited_by"] == "instruction_issue" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "k_explore_slice8"
     assert r["hbm_frac"] == r["frac"] and (r["frac_of_issue_floor"] is None or 0 < r["frac_of_issue_floor"] <= 1.0)
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["launches"] == 3
     assert r["algorithmic_bytes_per_launch"] == (16 * 1024 + 32) * 1024
@@ -55,18 +59,29 @@ def test_single_gpu_line_has_the_contract_fields():
     rt = j["round_trip"]
     assert rt["rounds"] == 4 and rt["scans_in_last_round"] == 16 and rt["global_barrier"] > 0
     # round 3: what is static says so, the instrumentation is cross-checked, the HBM-bound kernels and every BASELINE config are in the line
-    # (two separate wall-clock passes on a box that may be shared: a sanity bound, not a tolerance)
-    assert 0 < j["ms_per_step_without_hip_events"] < 2.0 * j["ms_per_step"]
+    # (the events ride on the launches -- hipExtLaunchKernelGGL -- so the instrumented pass may cost at most a few us per scan more; a
+    # 3-scan region is 2 ms of wall clock, so a violation is re-measured once over 64 scans before it counts: 1.25x)
+    ratio = j["ms_per_step_without_hip_events"] / j["ms_per_step"]
+    if not (0.8 < ratio < 1.25):
+        p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "64", "--warmup", "4", "--round-trip-rounds", "0",
+                             "--no-extra", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+        assert p2.returncode == 0, p2.stderr[-3000:]
+        j2 = json.loads([ln for ln in p2.stdout.splitlines() if ln.startswith("{")][-1])
+        ratio = j2["ms_per_step_without_hip_events"] / j2["ms_per_step"]
+    assert 0.8 < ratio < 1.25, ratio
     # a timed region under 100 ms is repeated over 256 scans, both numbers in the line
     lr = j["long_run"]
     assert lr["steps"] == 256 and lr["value"] > 0 and abs(lr["value"] - 1024 * 256 / (lr["ms_per_step"] * 256e-3)) < 1e-6 * lr["value"]
-    assert 0.5 * j["ms_per_step"] < lr["ms_per_step"] < 2.0 * j["ms_per_step"]
+    assert 0.6 * j["ms_per_step"] < lr["ms_per_step"] < 1.25 * j["ms_per_step"]      # (the 3-scan region carries its ramp: it may be the slower one)
     assert r["traffic"] is None or str(r["traffic_source"]).startswith("static: profiles/")
     assert r["instruction_issue"] is None or str(r["instruction_issue"]["source"]).startswith("static: profiles/")
     h = j["hbm_kernels"]
     for k in ("k_explore_toy", "k_init", "k_swap"):
         assert h[k]["avg_launch_us"] > 0 and h[k]["bytes_per_launch"] > 0 and abs(h[k]["frac_of_8TBps"] - h[k]["GBps"] / 8000.0) < 1e-12
     assert h["k_explore_toy"]["bytes_per_launch"] == (8 * 4096 + 32) * 8192
+    ki = h["k_init"]                                    # the average is an average (of the warm constructions); the minimum has its own key
+    assert len(ki["launch_us_of_6_constructions"]) == 6 and ki["min_launch_us"] == min(ki["launch_us_of_6_constructions"])
+    assert abs(ki["avg_launch_us"] - sum(ki["launch_us_of_6_constructions"][1:]) / 5) < 1e-9 * ki["avg_launch_us"] and ki["min_launch_us"] <= ki["avg_launch_us"]
     x = j["extra_configs"]
     assert len(x) == 6 and all(c["ms_per_scan"] > 0 and c["kernel"] for c in x) and x[0]["config"].startswith("C1 ")
     assert {c["kernel"] for c in x} >= {"k_explore_slice8", "k_explore_slice8_lds10k", "k_explore_automala", "k_explore_ising_spec"}
