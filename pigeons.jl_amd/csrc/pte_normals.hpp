@@ -33,7 +33,10 @@ namespace pte {
 #define NRM_CHUNK 512                       // measured at 1024 (round 3): LDS then allows 3 waves per SIMD -- the same within 2 %
 #endif
 constexpr int NRM_CO = NRM_CHUNK;           // outputs per chunk (groups of 256)
-constexpr int NRM_CP = NRM_CO + 64;         // stream positions evaluated per chunk
+#ifndef NRM_SLACK
+#define NRM_SLACK 64                        // (measurement builds: 0 with -DNRM_MEASURE_IGNORE_LIMIT = what a chunk without the slack slot would cost; wrong samples)
+#endif
+constexpr int NRM_CP = NRM_CO + NRM_SLACK;  // stream positions evaluated per chunk
 constexpr int NRM_SLOTS = NRM_CP / 64;      // positions per lane
 #ifndef NRM_MAX_EV_
 #define NRM_MAX_EV_ 32                       // (test builds force the cut-short / fallback paths with a small value)
@@ -297,7 +300,11 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
             return below ? __builtin_amdgcn_readlane(e_incl, 63 - (int)__builtin_clzll(below)) : 0;
         };
         const int shift_all = consumed_below(NRM_CO);
+#ifdef NRM_MEASURE_IGNORE_LIMIT     // measurement builds only (wrong samples): the straight-line path whatever the chunk resolved
+        if (want == NRM_CO && markstein) {
+#else
         if (want == NRM_CO && markstein && NRM_CO - 1 + shift_all < pos_limit) {
+#endif
             // the whole chunk (all but the last chunk of a row, and every position it takes is resolved): straight-line code, the
             // groups' dependent chains (Markstein steps, DPP tree levels) issued level by level
             constexpr int NG = NRM_CO / 256;

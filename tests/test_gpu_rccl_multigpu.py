@@ -89,7 +89,9 @@ for r in range(cfg["rounds"]):
 x, chain, rng = pt.shards.states()                                # all-gather over the communicator
 # what a boundary exchange costs on the engine's stream (HIP events around the grouped send / recv, one sample per even scan)
 e = pt.replicas
-e.timing_reset(True); pt.shards.run_scans(1, 16); bs = np.sort(e.timing_samples(3)); e.timing_reset(False)
+n_t = min(16, 2 ** cfg["rounds"])                   # (the index-process buffer holds one round of the run's last round: 2^rounds scans)
+e.timing_reset(True); pt.shards.run_scans(1, n_t); bs = np.sort(e.timing_samples(3)); e.timing_reset(False)
+pt.shards.reduce()
 pt.shards.barrier()
 mx = float(pt.shards.allreduce_max([float(rank)])[0])
 if mx != world - 1: ok = False; why.append("allreduce max %r" % mx)
