@@ -185,9 +185,9 @@ def test_the_rank_script_of_this_module_runs(tmp_path):
     device 0 over the stand-in (the only thing this run does NOT exercise is librccl itself).  Runs on every GPU box."""
     from test_gpu_rccl_peer import build_fakerccl
     fake = build_fakerccl()
-    res = _run_world(tmp_path, dict(explorer="slice", d=4096, N=128, rounds=2, seed=3, stand_in=fake), 2)
+    res = _run_world(tmp_path, dict(explorer="slice", d=4096, N=512, rounds=3, seed=3, stand_in=fake), 2)      # (the configurations of the real-RCCL tests at G = 2)
     _check(res, 2, "k_explore_slice8", stand_in=True)
-    res = _run_world(tmp_path, dict(explorer="ising", L=256, beta=1.0, N=16, rounds=2, seed=5, stand_in=fake), 2)
+    res = _run_world(tmp_path, dict(explorer="ising", L=256, beta=1.0, N=64, rounds=3, seed=5, stand_in=fake), 2)
     _check(res, 2, "k_explore_ising_spec", stand_in=True)
 
 
