@@ -148,12 +148,13 @@ def _run_world(tmp_path, cfg, world):
     return res
 
 
-def _check(res, world, kernel, stand_in=False):
+def _check(res, world, kernel, stand_in=False, require_swaps=True):
     assert all(r["ok"] for r in res), res
     assert all(r["n_ranks_seen"] == world for r in res), res
     assert all(("fakerccl" in r["transport_library"][0]) == stand_in for r in res), res
     assert all(r["kernel"].startswith(kernel) for r in res), res
-    assert sum(sum(r["boundary_swaps"]) for r in res) > 0, res       # replicas did cross rank boundaries
+    if require_swaps:
+        assert sum(sum(r["boundary_swaps"]) for r in res) > 0, res   # replicas did cross rank boundaries
     be = res[0]["boundary_exchange_us_min_median_max"]
     assert be and be[0] > 0, res[0]
     print("real RCCL, G = %d: %s v%s; boundary exchange min / median / max %.1f / %.1f / %.1f us on rank 0's stream; boundary swaps per rank %s"
@@ -185,10 +186,14 @@ def test_the_rank_script_of_this_module_runs(tmp_path):
     device 0 over the stand-in (the only thing this run does NOT exercise is librccl itself).  Runs on every GPU box."""
     from test_gpu_rccl_peer import build_fakerccl
     fake = build_fakerccl()
-    res = _run_world(tmp_path, dict(explorer="slice", d=4096, N=512, rounds=3, seed=3, stand_in=fake), 2)      # (the configurations of the real-RCCL tests at G = 2)
+    # (the stand-in moves at most 256 KiB per message, so the states' all-gather bounds chains x dimension per rank here; the real tests above
+    # run 256 chains per GPU at d = 4096)
+    res = _run_world(tmp_path, dict(explorer="slice", d=256, N=128, rounds=3, seed=3, stand_in=fake), 2)
     _check(res, 2, "k_explore_slice8", stand_in=True)
-    res = _run_world(tmp_path, dict(explorer="ising", L=256, beta=1.0, N=64, rounds=3, seed=5, stand_in=fake), 2)
-    _check(res, 2, "k_explore_ising_spec", stand_in=True)
+    res = _run_world(tmp_path, dict(explorer="slice", d=4096, N=8, rounds=3, seed=3, stand_in=fake), 2)        # C4's message size (8 chains: no swap is ever accepted)
+    _check(res, 2, "k_explore_slice8", stand_in=True, require_swaps=False)
+    res = _run_world(tmp_path, dict(explorer="ising", L=256, beta=1.0, N=8, rounds=3, seed=5, stand_in=fake), 2)
+    _check(res, 2, "k_explore_ising_spec", stand_in=True, require_swaps=False)
 
 
 @pytest.mark.skipif(N_GPUS < 2, reason="needs >= 2 GPUs on the node (%d visible)" % N_GPUS)
