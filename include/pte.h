@@ -75,7 +75,10 @@ enum {                                   /* pte_config.debug_kernel: which kerne
     PTE_KERNEL_SLICE_SEQUENTIAL = 1,     /* SliceSampler: the plain sequential kernel (exact fallback of the default one)  */
     /* 2, 5, 7 (and 8 = the default named explicitly): earlier SliceSampler generations, test build libpte_test.so only    */
     PTE_KERNEL_ISING_BITS       = 101,   /* IsingMetropolis: scalar bit-packed sweep, test build only                      */
-    PTE_KERNEL_ISING_BYTES      = 102    /* IsingMetropolis: scalar byte-lattice sweep (the kernel of base_length % 32 != 0) */
+    PTE_KERNEL_ISING_BYTES      = 102,   /* IsingMetropolis: scalar byte-lattice sweep (the kernel of base_length % 32 != 0) */
+    /* a FLAG, or-ed to any of the above: pte_run_scans launches explore and swap per scan (the loop of rounds 1-4) even where the whole
+     * call could run as ONE kernel with pairwise swap hand-shakes (pte_scan_loop_name); for A/B runs and the parity tests of the two forms */
+    PTE_KERNEL_TWO_LAUNCHES     = 0x1000
 };
 
 /* Mirrors the fields of `Inputs` (src/pt/Inputs.jl:9-102) and of the explorer
@@ -258,12 +261,21 @@ int pte_group_run_scans(pte_engine *const *engines, int32_t n_engines, int64_t f
 /* Name of the kernel that explores on this engine (e.g. "k_explore_slice8"), for profiles and bench.py. */
 const char *pte_kernel_name(const pte_engine *h);
 
+/* The form pte_run_scans takes on this engine -- the reference's `while next_scan!(pt)` loop, src/pt/pigeons.jl:46-55: "" = two launches
+ * per scan (explore, swap); otherwise the ONE kernel that runs all the scans of a call (e.g. "k_scans_slice8": workgroup c holds chain c,
+ * the DEO swap is a hand-shake between the two waves of a pair, no launch boundary and no grid-wide barrier per scan).  Chosen when one GPU
+ * holds the whole ladder, every workgroup is resident at once, the explorer has such a kernel and pte_config.debug_kernel does not carry
+ * PTE_KERNEL_TWO_LAUNCHES; results are bit-identical either way.  pte_timing_get(kernel = 4) times these launches. */
+const char *pte_scan_loop_name(const pte_engine *h);
+int pte_scan_loop_info(const pte_engine *h, int64_t *resident_limit, int64_t *timed_launches, int64_t *timed_scans);
+
 /* index process of the local slots: replica[scan][K], chain[scan][K] (global ids). */
 int pte_get_index_process_shard(const pte_engine *h, int64_t *replica, int64_t *chain, int64_t *n_scans);
 int pte_get_replica_ids(const pte_engine *h, int64_t *out /*K*/);
 
 /* Measurement hooks (bench.py): per-kernel HIP-event timing accumulated on the engine's stream
- * over pte_run_scans calls since the last reset.  kernel: 0 = explore, 1 = swap; 2 = k_init (create_replicas), timed once
+ * over pte_run_scans calls since the last reset.  kernel: 0 = explore, 1 = swap (both empty while pte_run_scans runs as one fused launch:
+ * 4 = that launch, pte_scan_loop_info says how many scans it held); 2 = k_init (create_replicas), timed once
  * at pte_create and not touched by pte_timing_reset; 3 = the boundary exchange of a chain-sharded engine (events around
  * ncclGroupStart .. ncclGroupEnd on the engine's stream: from "messages packed" to "messages landed", one sample per even scan).
  * enable: 0 off, 1 every kernel, 2 the explore kernels only (an event pair costs ~10 us of stream time per launch). */

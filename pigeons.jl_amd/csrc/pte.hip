@@ -98,9 +98,15 @@ struct pte_engine {
     std::vector<hipEvent_t> ev_pool;
     double init_ms = -1.0;            // duration of k_init (create_replicas), -1: not launched (Ising, TestSwapper)
     bool ev_ext = false, ev_ext_done = false;   // the open bracket's events ride on its ONE kernel launch (PTE_LAUNCH1)
-    double t_ms[4] = {0, 0, 0, 0};    // by kind: 0 explore, 1 swap, (2 = k_init: init_ms), 3 boundary exchange (ncclGroupStart .. ncclGroupEnd)
-    int64_t t_n[4] = {0, 0, 0, 0};
-    std::vector<float> t_samples[4];  // per-launch durations since the last reset (spread of the timed region)
+    double t_ms[5] = {0, 0, 0, 0, 0};    // by kind: 0 explore, 1 swap, (2 = k_init: init_ms), 3 boundary exchange (ncclGroupStart .. ncclGroupEnd), 4 the fused scan loop (one launch per pte_run_scans)
+    int64_t t_n[5] = {0, 0, 0, 0, 0};
+    std::vector<float> t_samples[5];  // per-launch durations since the last reset (spread of the timed region)
+    int64_t t_scans4 = 0;             // scans inside the timed launches of kind 4
+    // one launch per pte_run_scans (k_scans_*: pte_kernels.hpp "ScanLoop"): pairwise hand-shakes instead of a launch boundary per scan
+    bool fused_allowed = true;        // pte_config.debug_kernel & PTE_KERNEL_TWO_LAUNCHES clears it
+    int64_t fused_limit = -1;         // workgroups of the scan-loop kernel the device holds at once (-1: not asked yet, 0: not available)
+    unsigned long long *hs_flag = nullptr; double *hs_pub = nullptr;   // [K], [K][2][4]
+    unsigned long long hs_epoch = 0;  // epochs handed out so far (monotone: the flags are never reset)
 };
 
 namespace {
@@ -246,6 +252,8 @@ int check_device_error(pte_engine *h) {
     case ERR_SLICE_MAX_ITER: return fail(h, "Maximum number of iterations reached in slice_shrink! (chain %d, index %d)", err[1], err[2]);
     case ERR_AM_DENSITY: return fail(h, "AutoMALA can only be called on a configuration of positive density. (chain %d)", err[1]);
     case ERR_AM_STEP: return fail(h, "Could not find a positive step size (chain %d)", err[1]);
+    case ERR_HANDSHAKE_TIMEOUT: return fail(h, "pte_run_scans: chain %d waited 3 s for its swap partner inside the fused scan loop (a workgroup was not resident, or the device is shared); "
+                                               "set PTE_KERNEL_TWO_LAUNCHES in pte_config.debug_kernel for the launch-per-scan loop", err[1]);
     default: return fail(h, "device error %d", err[0]);
     }
 }
@@ -254,7 +262,7 @@ int check_device_error(pte_engine *h) {
 // on_launch: the bracket holds exactly ONE kernel launch, written with PTE_LAUNCH1 / DISPATCH_NLU*, which then carries the events
 void time_begin(pte_engine *h, int kernel, bool on_launch = false) {
     h->ev_open = false; h->ev_ext = false; h->ev_ext_done = false;
-    if (!h->timing || (h->timing == 2 && kernel != 0)) return;
+    if (!h->timing || (h->timing == 2 && kernel != 0 && kernel != 4)) return;
     pte_engine::Ev ev; ev.kernel = kernel;
     if (h->ev_pool.size() >= 2) {
         ev.a = h->ev_pool.back(); h->ev_pool.pop_back();
@@ -428,6 +436,78 @@ void boundary_active(const pte_engine *h, int even, int32_t active[2]) {
 
 int run_scans_sharded(pte_engine *h, int64_t first_scan, int64_t n_scans);
 
+// ---- one launch per pte_run_scans (k_scans_*; pte_kernels.hpp "ScanLoop") ----------------------------------------------------------------
+// Which engines: one GPU holds the whole ladder (world_size == 1), SliceSampler on the scaled-precision MVN path with the default kernel
+// generation, no Compose, and every workgroup of the call resident at once (the hand-shakes spin: a workgroup that waits for a GPU slot
+// would be waited for) -- asked of the runtime for the very instantiation that is launched.
+#ifdef PTE_DEV_FEW_NLU
+#define OCC_NLU_M(nlu, KERNEL, MM, out)                                                                        \
+    switch (nlu) {                                                                                              \
+    case 4: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<4, MM>, 64, 0); break;                   \
+    default: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<6, MM>, 64, 0); break;                  \
+    }
+#else
+#define OCC_NLU_M(nlu, KERNEL, MM, out)                                                                        \
+    switch (nlu) {                                                                                              \
+    case 0: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<0, MM>, 64, 0); break;                   \
+    case 1: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<1, MM>, 64, 0); break;                   \
+    case 2: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<2, MM>, 64, 0); break;                   \
+    case 3: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<3, MM>, 64, 0); break;                   \
+    case 4: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<4, MM>, 64, 0); break;                   \
+    case 5: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<5, MM>, 64, 0); break;                   \
+    default: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<6, MM>, 64, 0); break;                  \
+    }
+#endif
+
+// 0: k_scans_slice8, 1: k_scans_slice8_generic, 2: k_scans_slice8_lds10k -- the same choice launch_explorer_kind makes per scan
+int fused_slice_variant(const pte_engine *h) {
+    const bool fast_ok = h->cfg.slice_p > PTE_S8_BD && h->cfg.slice_p <= 20 && h->cfg.slice_max_iter >= PTE_S8_BS;
+    return h->K > PTE_S8_TWIN_FROM ? 2 : (fast_ok ? 0 : 1);
+}
+
+bool fused_scans_eligible(pte_engine *h, int64_t n_scans) {
+    if (!h->fused_allowed || h->world != 1 || n_scans < 1) return false;
+    if (h->cfg.explorer != PTE_EXPLORER_SLICE || h->cfg.explorer2 != PTE_EXPLORER_NONE || h->cfg.target != PTE_TARGET_MVN_SCALED_PRECISION || h->slice_impl != 8) return false;
+    // a recorder buffer that would overflow inside the call: the launch-per-scan loop reports it at the scan that overflows, as before
+    if ((h->cfg.record_flags & (PTE_RECORD_TRACES | PTE_RECORD_INDEX_PROCESS)) && h->scans_in_round + n_scans > h->cfg.max_scans_per_round) return false;
+    if (h->fused_limit < 0) {
+        int per_cu = 0, cus = 0;
+        const int v = fused_slice_variant(h);
+        if (v == 0) { OCC_NLU_M(h->nlu, k_scans_slice8, PTE_S8_BS, per_cu); }
+        else if (v == 1) { OCC_NLU_M(h->nlu, k_scans_slice8_generic, PTE_S8_BS, per_cu); }
+        else { OCC_NLU_M(h->nlu, k_scans_slice8_lds10k, PTE_S8_BS, per_cu); }
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess) cus = 0;
+        (void)hipGetLastError();
+        h->fused_limit = (int64_t)per_cu * (int64_t)cus;
+        if (h->fused_limit > 0 && h->K <= h->fused_limit && !h->hs_flag) {
+            if (dev_alloc(h, &h->hs_flag, (size_t)h->K) || dev_alloc(h, &h->hs_pub, (size_t)h->K * 8)) { h->fused_limit = 0; h->err.clear(); }
+            else hipStreamSynchronize(h->stream);
+        }
+    }
+    return h->K <= h->fused_limit && h->hs_flag != nullptr;
+}
+
+int run_scans_fused(pte_engine *h, int64_t first_scan, int64_t n_scans) {
+    const int64_t N = h->K;
+    SliceParams sp{h->cfg.slice_w, h->cfg.slice_p, h->cfg.slice_n_passes, h->cfg.slice_max_iter};
+    ScanLoop sl{first_scan, n_scans, h->scans_in_round, h->hs_epoch, h->hs_flag, h->hs_pub};
+    h->dev.compose_phase = 0; h->dev.trace_idx = h->scans_in_round;
+    const int v = fused_slice_variant(h);
+    time_begin(h, 4, true);
+    const bool timed = h->ev_open;
+    if (v == 0) { DISPATCH_NLU_M(h->nlu, k_scans_slice8, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, sl); }
+    else if (v == 1) { DISPATCH_NLU_M(h->nlu, k_scans_slice8_generic, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, sl); }
+    else { DISPATCH_NLU_M(h->nlu, k_scans_slice8_lds10k, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, sl); }
+    time_end(h);
+    if (timed) h->t_scans4 += n_scans;
+    HIP_OK(h, hipGetLastError());
+    h->hs_epoch += (unsigned long long)n_scans;
+    h->scans_in_round += n_scans;
+    int rc = check_device_error(h);
+    time_collect(h);
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -481,7 +561,7 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
         return fail(nullptr, "pte_create: the funnel path is implemented for AutoMALA / MALA / SliceSampler (and Compose of them); use the reference CPU path");
     if ((uses_grad || funnel) && (cfg->dim < 1 || cfg->dim > 1024))
         return fail(nullptr, "pte_create: AutoMALA / MALA (and every explorer of the funnel path) keep the replica in registers, dim must be in 1..1024 (got %lld)", (long long)cfg->dim);
-    if (funnel && cfg->debug_kernel != 0)
+    if (funnel && (cfg->debug_kernel & ~PTE_KERNEL_TWO_LAUNCHES) != 0)
         return fail(nullptr, "pte_create: debug_kernel %d is not available on the funnel path (one register-resident kernel serves it)", cfg->debug_kernel);
     if (cfg->explorer2 != PTE_EXPLORER_NONE) {           // Compose(first, second)
         auto composable = [&](int k) { return k == PTE_EXPLORER_SLICE || grad_based(k); };
@@ -497,7 +577,7 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     if ((cfg->record_flags & PTE_RECORD_TRACES_EXTENDED) && !(cfg->record_flags & PTE_RECORD_TRACES))
         return fail(nullptr, "pte_create: PTE_RECORD_TRACES_EXTENDED needs PTE_RECORD_TRACES");
     {   // debug_kernel: 0 = the default kernel of the explorer; anything else must exist in THIS build (no silent fall-through)
-        const int dk = cfg->debug_kernel;
+        const int dk = cfg->debug_kernel & ~PTE_KERNEL_TWO_LAUNCHES;      // (the flag bit chooses the scan loop's form, not the kernel generation)
         const bool slice = cfg->explorer == PTE_EXPLORER_SLICE || cfg->explorer2 == PTE_EXPLORER_SLICE;
         bool ok = dk == 0 || (slice && dk == PTE_KERNEL_SLICE_SEQUENTIAL) || (ising && dk == PTE_KERNEL_ISING_BYTES);
 #ifdef PTE_TEST_KERNELS
@@ -528,8 +608,10 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     const int64_t B = (d + 63) / 64;
     h->nlu = next_pow2_log(B > 0 ? B : 1);
     // pte_config.debug_kernel (validated above): which kernel generation explores; never read from the environment
-    if (cfg->explorer == PTE_EXPLORER_SLICE || cfg->explorer2 == PTE_EXPLORER_SLICE) h->slice_impl = cfg->debug_kernel == 0 ? 8 : cfg->debug_kernel;
-    if (cfg->explorer == PTE_EXPLORER_ISING_METROPOLIS) h->ising_impl = cfg->debug_kernel == PTE_KERNEL_ISING_BITS ? 1 : (cfg->debug_kernel == PTE_KERNEL_ISING_BYTES ? 2 : 0);
+    const int dk_kernel = cfg->debug_kernel & ~PTE_KERNEL_TWO_LAUNCHES;
+    h->fused_allowed = (cfg->debug_kernel & PTE_KERNEL_TWO_LAUNCHES) == 0;
+    if (cfg->explorer == PTE_EXPLORER_SLICE || cfg->explorer2 == PTE_EXPLORER_SLICE) h->slice_impl = dk_kernel == 0 ? 8 : dk_kernel;
+    if (cfg->explorer == PTE_EXPLORER_ISING_METROPOLIS) h->ising_impl = dk_kernel == PTE_KERNEL_ISING_BITS ? 1 : (dk_kernel == PTE_KERNEL_ISING_BYTES ? 2 : 0);
     EngineDev &e = h->dev;
     e.N = N; e.K = K; e.c0 = h->c0; e.d = d; e.ld = (d + 1) & ~(int64_t)1;
     e.sw = d;
@@ -744,6 +826,7 @@ int pte_run_scans(pte_engine *h, int64_t first_scan, int64_t n_scans) {
     if (!h) return 1;
     HIP_OK(h, hipSetDevice(h->cfg.device));
     if (h->world != 1) return run_scans_sharded(h, first_scan, n_scans);
+    if (fused_scans_eligible(h, n_scans)) return run_scans_fused(h, first_scan, n_scans);
     for (int64_t s = first_scan; s < first_scan + n_scans; ++s) {
         if (launch_explore(h, s)) return 1;
         if (launch_swap(h, s)) return 1;
@@ -1306,6 +1389,30 @@ const char *pte_kernel_name(const pte_engine *h) {
     }
 }
 
+// The form pte_run_scans takes on this engine: "" = two launches per scan (explore, swap); otherwise the name of the ONE kernel that runs
+// all the scans of a call (k_scans_*).  *resident_limit: workgroups of that kernel the device holds at once (0 when not available);
+// *timed_launches / *timed_scans: fused launches and the scans inside them since the last pte_timing_reset (pte_timing_get(kernel = 4) holds
+// their durations).
+const char *pte_scan_loop_name(const pte_engine *hc) {
+    pte_engine *h = const_cast<pte_engine *>(hc);
+    if (!h) return "";
+    hipSetDevice(h->cfg.device);
+    if (!fused_scans_eligible(h, 1)) return "";
+    switch (fused_slice_variant(h)) { case 0: return "k_scans_slice8"; case 1: return "k_scans_slice8_generic"; default: return "k_scans_slice8_lds10k"; }
+}
+int pte_scan_loop_info(const pte_engine *hc, int64_t *resident_limit, int64_t *timed_launches, int64_t *timed_scans) {
+    pte_engine *h = const_cast<pte_engine *>(hc);
+    if (!h) return 1;
+    hipSetDevice(h->cfg.device);
+    (void)fused_scans_eligible(h, 1);
+    hipStreamSynchronize(h->stream);
+    time_collect(h);
+    if (resident_limit) *resident_limit = h->fused_limit < 0 ? 0 : h->fused_limit;
+    if (timed_launches) *timed_launches = h->t_n[4];
+    if (timed_scans) *timed_scans = h->t_scans4;
+    return 0;
+}
+
 namespace {
 int refresh_funnel_stats(pte_engine *h) {
     const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
@@ -1434,12 +1541,13 @@ int pte_timing_reset(pte_engine *h, int enable) {
     hipStreamSynchronize(h->stream);
     time_collect(h);
     h->timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
-    for (int k = 0; k < 4; ++k) { h->t_ms[k] = 0.0; h->t_n[k] = 0; h->t_samples[k].clear(); }
+    for (int k = 0; k < 5; ++k) { h->t_ms[k] = 0.0; h->t_n[k] = 0; h->t_samples[k].clear(); }
+    h->t_scans4 = 0;
     return 0;
 }
 int pte_timing_get_samples(const pte_engine *hc, int kernel, double *out_ms, int64_t capacity, int64_t *n_out) {
     pte_engine *h = const_cast<pte_engine *>(hc);
-    if (!h || kernel < 0 || kernel > 3 || kernel == 2 || !n_out) return 1;
+    if (!h || kernel < 0 || kernel > 4 || kernel == 2 || !n_out) return 1;
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
     time_collect(h);
@@ -1450,7 +1558,7 @@ int pte_timing_get_samples(const pte_engine *hc, int kernel, double *out_ms, int
 }
 int pte_timing_get(const pte_engine *hc, int kernel, double *total_ms, int64_t *launches) {
     pte_engine *h = const_cast<pte_engine *>(hc);
-    if (!h || kernel < 0 || kernel > 3) return 1;
+    if (!h || kernel < 0 || kernel > 4) return 1;
     if (kernel == 2) {                                  // k_init: timed once, at pte_create
         if (total_ms) *total_ms = h->init_ms < 0 ? 0.0 : h->init_ms;
         if (launches) *launches = h->init_ms < 0 ? 0 : 1;

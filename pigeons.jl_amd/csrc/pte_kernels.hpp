@@ -548,6 +548,101 @@ __device__ __forceinline__ int64_t deo_partner(int64_t N, int even, int64_t c) {
     return (proposed == 0) ? 0 : (proposed == N + 1 ? N - 1 : proposed - 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// One launch per pte_run_scans (round 5): the scan loop `while next_scan!(pt)` (reference src/pt/pigeons.jl:46-55) inside ONE kernel
+// for shapes whose workgroups are all resident -- k_scans_* (pte_slice8.hpp).  Workgroup c holds chain c for the whole call; after its
+// explore step it takes part in the DEO swap of ITS pair only: communicate! needs nothing of the other N - 2 chains (swap.jl:6-26,
+// pair_swapper.jl:42-88: a pair's decision is a function of the two SwapStats), so there is no grid-wide barrier -- each wave publishes
+// {log ratio, uniform, slot} with a release store of its epoch and waits for its PARTNER'S epoch.  A launch is then no longer as long as
+// the slowest of N waves per scan: waves wait for neighbours only and fluctuations average out along the ladder (tools/sim_pairsync.py
+// replays recorded per-wave durations: x1.06 at the metric shape, where a device-scope barrier would give x1.014).
+//   * same arithmetic, same single rand(replica.rng), same recorder updates as k_swap: bit-identical (tests compare the two paths);
+//   * everything a replica owns (state row, rng, sum x^2, round-trip state) is written BEFORE the release store; the new holder reads it
+//     after its acquire -- agent scope, i.e. across the XCDs' L2s;
+//   * every chain publishes every scan (also the chain a graph leaves idle), so "partner has published epoch - 1" -- the condition under
+//     which the publish buffer of this parity, read by the same partner two scans ago, may be overwritten -- always becomes true;
+//   * every wait has a time-out (3 s on the 100 MHz clock): a workgroup that is not resident after all ends the call with an error
+//     instead of hanging the GPU.
+// ---------------------------------------------------------------------------------------------
+enum { ERR_HANDSHAKE_TIMEOUT = 9 };
+struct ScanLoop {
+    int64_t first_scan, n_scans;       // scan numbers first_scan .. first_scan + n_scans - 1 (DEO parity = iseven(scan); AutoMALA's scan == 1 rule)
+    int64_t scan_idx0;                 // scans of this round already run: row of index_process / traces the first scan writes
+    unsigned long long epoch0;         // hand-shake epochs of this call: epoch0 + 1 .. epoch0 + n_scans (monotone over the engine's life, never reset)
+    unsigned long long *flag;          // [K] the last epoch chain c has published
+    double *pub;                       // [K][2][4] {log ratio, uniform, slot, -} of chain c, double-buffered by the epoch's parity
+};
+
+__device__ __forceinline__ bool hs_wait(const unsigned long long *p, unsigned long long want) {
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(8);
+        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) return false;
+    }
+}
+
+// lane 0 of the wave that holds chain c (world_size == 1: local index == chain) after the explore step of scan number sl.first_scan + i:
+// swap_stat + the replica's recorders + hand-shake + decision.  Returns the slot chain c holds afterwards, -1 after a time-out.
+__device__ __forceinline__ int swap_handshake(const EngineDev &e, const ScanLoop &sl, int64_t i, int64_t c, int slot) {
+    const int64_t N = e.N;
+    const int even = ((sl.first_scan + i) % 2 == 0) ? 1 : 0;              // create_swap_graph(::DEO), DEO.jl:12
+    const int64_t scan_idx = sl.scan_idx0 + i;
+    const unsigned long long epoch = sl.epoch0 + 1ull + (unsigned long long)i;
+    const int64_t pc = deo_partner(N, even, c);
+    double lr = 0.0;
+    if (e.target != 1) {
+        lr = swap_log_ratio(e, slot, c, pc);
+        if (isnan(lr)) set_error(e, ERR_NAN_RATIO, (int)c, -1);
+    }
+    uint64_t seed = e.rng[2 * slot] + e.rng[2 * slot + 1];               // one rand(replica.rng) per replica
+    e.rng[2 * slot] = seed;
+    const double u = u52_to_unit(mix64(seed));
+    if (e.record_flags & 2u) {
+        e.index_process[scan_idx * N + slot] = (int32_t)c;
+        e.ip_replica[scan_idx * N + slot] = (int32_t)e.replica_id[slot];
+    }
+    if (e.record_flags & 1u) {     // RoundTripRecorder.jl:43-54
+        const bool is_ref = is_ref_chain(e, c), is_tgt = (c == e.rt_tgt_a || c == e.rt_tgt_b);
+        int64_t st = e.rt_state[slot];
+        if (st == 0 && is_ref) e.rt_state[slot] = 1;
+        else if (st == 1 && is_tgt) { e.rt_state[slot] = 2; e.rt_restarts[slot] += 1; }
+        else if (st == 2 && is_ref) { e.rt_state[slot] = 1; e.rt_trips[slot] += 1; }
+    }
+    if (pc == c) {                                                          // idle on this graph: publish the epoch only
+        __hip_atomic_store(&sl.flag[c], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return slot;
+    }
+    double *mine = sl.pub + ((c * 2 + (int64_t)(epoch & 1ull)) * 4);
+    if (!hs_wait(&sl.flag[pc], epoch - 1ull)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
+    mine[0] = lr; mine[1] = u; mine[2] = (double)slot;
+    __hip_atomic_store(&sl.flag[c], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (!hs_wait(&sl.flag[pc], epoch)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const double *theirs = sl.pub + ((pc * 2 + (int64_t)(epoch & 1ull)) * 4);
+    const double lr_p = theirs[0], u_p = theirs[1];
+    const int slot_p = (int)theirs[2];
+    const bool lower = c < pc;
+    const double uu = lower ? u : u_p;
+    bool do_swap;
+    if (e.target == 1) {
+        do_swap = uu < e.test_swapper_pr;                  // TestSwapper, pair_swapper.jl:135-138
+    } else {
+        const double ex = exp(lr + lr_p);
+        const double alpha = ex < 1.0 ? ex : 1.0;         // swap_acceptance_probability :88
+        do_swap = uu < alpha;                               // swap_decision :81-85
+        if (lower) {                                        // record_swap_stats! :59-66
+            e.swap_sum[c] += alpha; e.swap_n[c] += 1;
+            e.lsr_up[c] = dev_logaddexp(e.lsr_up[c], lr);
+            e.lsr_dn[c] = dev_logaddexp(e.lsr_dn[c], lr_p);
+            e.lsr_n[c] += 1;
+        }
+    }
+    if (do_swap) { e.chain_of_slot[slot_p] = (int32_t)c; e.slot_of_chain[c] = slot_p; return slot_p; }
+    return slot;
+}
+
 #ifndef PTE_TU_LANGEVIN
 __global__ __launch_bounds__(256) void k_swap_stats(EngineDev e, int even, int64_t scan_idx) {
     const int64_t cl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

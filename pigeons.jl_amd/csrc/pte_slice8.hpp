@@ -784,4 +784,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_TWIN_
     slice8_body<NLU, S8_BS, 256, 1>(e, sp);
 }
 
+// ---- one launch per pte_run_scans (pte_kernels.hpp, "ScanLoop"): workgroup c explores chain c and then takes part in the swap of its own
+// pair, for all the scans of the call.  Same body, same launch bounds as the per-scan kernels; grid = K workgroups, all resident (the
+// launcher checks the occupancy: pte.hip, fused_scans_limit).
+template <int NLU, int S8_BS, int WINDOW, int DBL_MODE>
+__device__ __forceinline__ void slice8_scan_loop(EngineDev e, const SliceParams &sp, const ScanLoop &sl) {
+    const int lane = lane_id();
+    const int64_t cl = blockIdx.x;
+    for (int64_t i = 0; i < sl.n_scans; ++i) {
+        e.trace_idx = sl.scan_idx0 + i;
+        slice8_body<NLU, S8_BS, WINDOW, DBL_MODE>(e, sp);
+        __syncthreads();                                   // every lane's stores of the explore step happen before lane 0's release
+        int slot = 0;
+        if (lane == 0) slot = swap_handshake(e, sl, i, cl, e.slot_of_chain[cl]);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        __syncthreads();                                   // ... and lane 0's acquire before every lane's loads of the next one
+        if (slot < 0) return;                              // (time-out: the error word is set, the host reports it)
+    }
+}
+template <int NLU, int S8_BS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES, PTE_S8_WAVES))) void k_scans_slice8(EngineDev e, SliceParams sp, ScanLoop sl) {
+    slice8_scan_loop<NLU, S8_BS, PTE_S7_WIN, PTE_S8_DBL_MODE>(e, sp, sl);
+}
+template <int NLU, int S8_BS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES, PTE_S8_WAVES))) void k_scans_slice8_generic(EngineDev e, SliceParams sp, ScanLoop sl) {
+    slice8_scan_loop<NLU, S8_BS, PTE_S7_WIN, 0>(e, sp, sl);
+}
+template <int NLU, int S8_BS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_TWIN_WAVES, PTE_S8_TWIN_WAVES))) void k_scans_slice8_lds10k(EngineDev e, SliceParams sp, ScanLoop sl) {
+    slice8_scan_loop<NLU, S8_BS, 256, 1>(e, sp, sl);
+}
+
 }  // namespace pte

@@ -15,6 +15,7 @@ EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA, EXPLORER_ISING_M
 RECORD_ROUND_TRIP, RECORD_INDEX_PROCESS, RECORD_ONLINE, RECORD_TRACES, RECORD_ENERGY_AC1, RECORD_TRACES_EXTENDED = 1, 2, 4, 8, 16, 32
 ABI_VERSION = 2
 KERNEL_DEFAULT, KERNEL_SLICE_SEQUENTIAL, KERNEL_ISING_BITS, KERNEL_ISING_BYTES = 0, 1, 101, 102
+KERNEL_TWO_LAUNCHES = 0x1000            # flag: explore + swap launched per scan even where pte_run_scans could be one kernel (pte_scan_loop_name)
 COMM_ID_BYTES = 128
 RNG_TAIL_LOG1P = 1                      # include/pte_rng_policy.h
 
@@ -64,7 +65,7 @@ EXPORTS = [
     "pte_get_online_log_density", "pte_get_energy_ac1", "pte_get_traces", "pte_set_variational_reference",
     "pte_comm_allow_library_override", "pte_comm_library", "pte_comm_unique_id", "pte_comm_init", "pte_comm_destroy", "pte_comm_info", "pte_comm_barrier",
     "pte_comm_allreduce", "pte_comm_allgather", "pte_group_run_scans", "pte_kernel_name",
-    "pte_set_rng_policy", "pte_get_rng_policy",
+    "pte_set_rng_policy", "pte_get_rng_policy", "pte_scan_loop_name", "pte_scan_loop_info",
 ]
 
 _libs = {}
@@ -162,8 +163,11 @@ def load(path=None):
     L.pte_get_rng_policy.argtypes = [C.c_int32, C.POINTER(C.c_uint32)]
     L.pte_kernel_name.argtypes = [vp]
     L.pte_kernel_name.restype = C.c_char_p
+    L.pte_scan_loop_name.argtypes = [vp]
+    L.pte_scan_loop_name.restype = C.c_char_p
+    L.pte_scan_loop_info.argtypes = [vp, ip, ip, ip]
     for name in EXPORTS:
-        if name not in ("pte_last_error", "pte_boundary_payload_bytes", "pte_get_stream", "pte_shard_message_bytes", "pte_kernel_name"):
+        if name not in ("pte_last_error", "pte_boundary_payload_bytes", "pte_get_stream", "pte_shard_message_bytes", "pte_kernel_name", "pte_scan_loop_name"):
             getattr(L, name).restype = C.c_int
     if _comm_override_allowed:
         L.pte_comm_allow_library_override(1)

@@ -224,6 +224,16 @@ class Engine:
     def kernel_name(self):
         return (self.L.pte_kernel_name(self.h) or b"").decode()
 
+    def scan_loop_name(self):
+        """"" = two launches per scan; else the ONE kernel that runs all the scans of a run_scans call (pte_scan_loop_name)"""
+        return (self.L.pte_scan_loop_name(self.h) or b"").decode()
+
+    def scan_loop_info(self):
+        """(workgroups of the fused kernel the device holds at once, fused launches timed, scans inside them) since the last timing_reset"""
+        a = np.zeros(1, dtype=np.int64); b = np.zeros(1, dtype=np.int64); c = np.zeros(1, dtype=np.int64)
+        self._chk(self.L.pte_scan_loop_info(self.h, _ip(a), _ip(b), _ip(c)))
+        return int(a[0]), int(b[0]), int(c[0])
+
     def explorer_stats(self):
         am = np.zeros(self.K); ss = np.zeros(self.K)
         an = np.zeros(self.K, dtype=np.int64); sn = np.zeros(self.K, dtype=np.int64)
