@@ -285,7 +285,7 @@ def extra_configs(P):
         e.run_scans(1, warm)
         torch.cuda.synchronize()
         t = time.perf_counter(); e.run_scans(1, scans); torch.cuda.synchronize(); dt = time.perf_counter() - t
-        out.append({"config": name, "kernel": e.kernel_name(), "ms_per_scan": dt / scans * 1e3, "replica_steps_per_s": inp.n_chains * scans / dt,
+        out.append({"config": name, "kernel": e.kernel_name(), "scan_loop": e.scan_loop_name() or "two launches per scan", "ms_per_scan": dt / scans * 1e3, "replica_steps_per_s": inp.n_chains * scans / dt,
                     "chains_per_gpu": inp.n_chains, "waves_per_simd": inp.n_chains / 1024.0})
         del pt, e
     return out
@@ -405,8 +405,13 @@ def main():
         dist.all_gather(ts, t)
         per_rank_ms = [float(x.item()) / K * 1e3 for x in ts]
         dt = max(float(x.item()) for x in ts)
-    ex_ms, ex_n = eng.timing(0)
-    samples = np.sort(eng.timing_samples(0))
+    # the dominant kernel of the timed region: the explore kernel (one launch per scan) -- or, where pte_run_scans runs as ONE kernel
+    # (pte_scan_loop_name: explore + pairwise swap hand-shakes for all K scans), that kernel: one launch holding K scans
+    scan_loop = eng.scan_loop_name() if world == 1 else ""
+    tkind = 4 if scan_loop else 0
+    ex_ms, ex_n = eng.timing(tkind)
+    samples = np.sort(eng.timing_samples(tkind))
+    scans_timed = eng.scan_loop_info()[2] if scan_loop else ex_n
     eng.timing_reset(False)
     # the same K scans once more WITHOUT HIP events in the stream (an event pair costs stream time per launch): the cross-check of
     # what the instrumentation costs the timed region above; `value` stays the instrumented, contract-timed pass
@@ -483,9 +488,13 @@ def main():
     # algorithmic HBM bytes of the dominant kernel per launch:
     #   explore (slice / iid): state read + write + rng r/w = 16 d + 32 B per replica; composite explore+swap: 24 d + 128
     bytes_per_replica = 16 * d + 32 if args.explorer == "slice" else 8 * d + 32
-    alg_bytes = bytes_per_replica * n_chains
+    scans_per_launch = max(scans_timed, 1) // max(ex_n, 1) if scan_loop else 1
+    if scan_loop:
+        bytes_per_replica += 96                     # the fused kernel also does the swap: 96 B per replica and scan (it reads the statistic, never the state)
+    alg_bytes = bytes_per_replica * n_chains * scans_per_launch
     ex_avg_ms = ex_ms / max(ex_n, 1)
-    kernel_name = eng.kernel_name()                # reported by the library (pte_kernel_name), not guessed
+    kernel_name = scan_loop or eng.kernel_name()   # reported by the library (pte_scan_loop_name / pte_kernel_name), not guessed
+    explore_kernel_name = eng.kernel_name()
     traffic = None
     traffic_source = None
     issue = None
@@ -493,7 +502,7 @@ def main():
            # this workload (PMC passes cannot run inside an unprofiled bench; the line names the file they come from)
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(kernel_name)
         if tj and d == 1024 and n_chains == 1024:
-            traffic = tj["fetch_bytes"] + tj["write_bytes"]
+            traffic = (tj["fetch_bytes"] + tj["write_bytes"]) * (scans_per_launch if tj.get("per_scan") else 1)      # per launch, like `achieved`
             traffic_source = "static: " + tj.get("source", "profiles/traffic.json")
             issue = tj.get("issue")                   # what actually bounds the kernel: instruction issue of one wave per replica
             if issue:
@@ -532,9 +541,12 @@ def main():
                      "frac_of_issue_floor": (issue or {}).get("frac_of_issue_floor"),
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "hbm_frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_source, "avg_launch_ms": ex_avg_ms, "launches": ex_n,
+                     "scans_per_launch": scans_per_launch, "avg_launch_ms_per_scan": ex_avg_ms / scans_per_launch, "explore_kernel": explore_kernel_name,
+                     "scan_loop": ("one launch per pte_run_scans: workgroup c holds chain c, pairwise release / acquire swap hand-shakes (no launch "
+                                   "boundary, no grid barrier per scan)") if scan_loop else "two launches per scan (explore, swap)",
                      "launch_ms_min_median_max": [float(samples[0]), float(samples[len(samples) // 2]), float(samples[-1])] if len(samples) else None,
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     "swap_kernel_avg_launch_ms": sw_ms / max(sw_n, 1),
+                     "swap_kernel_avg_launch_ms": (sw_ms / sw_n) if sw_n else None,      # (None: the swap is inside the fused scan loop)
                      "composite_explore_plus_swap": {
                          "bytes_per_replica_step": 24 * d + 128, "achieved_GBps": composite_bytes / 1e9,
                          "frac_of_6.29TBps": composite_bytes / 1e9 / HBM_ACHIEVABLE_GBS / world,
