@@ -573,11 +573,23 @@ struct ScanLoop {
     double *pub;                       // [K][2][4] {log ratio, uniform, slot, -} of chain c, double-buffered by the epoch's parity
 };
 
+// Which chain a workgroup of the scan loop holds.  Observed (not promised by HIP): consecutive workgroups are dealt round-robin over the 8
+// XCDs, workgroup b runs on XCD b mod 8, and each XCD has its own L2.  Dealing the chains out the other way round -- workgroup b holds chain
+// (b mod 8) * K/8 + b / 8 -- puts K/8 consecutive chains behind one L2, so a replica handed to the neighbouring chain is usually read through
+// the L2 it was written in (the guide: same-XCD placement is a speed bonus, never correctness -- the hand-shake below is the agent-scope one
+// for every pair).
+__device__ __forceinline__ int64_t scan_loop_chain(int64_t K) {
+    const int64_t b = blockIdx.x, g = b & 7, j = b >> 3, q = K >> 3, r = K & 7;
+    return g * q + (g < r ? g : r) + j;
+}
+
 __device__ __forceinline__ bool hs_wait(const unsigned long long *p, unsigned long long want) {
     if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     for (;;) {
+#ifndef PTE_HS_MEASURE_NO_SLEEP
         __builtin_amdgcn_s_sleep(8);
+#endif
         if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
         if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) return false;
     }
@@ -610,19 +622,34 @@ __device__ __forceinline__ int swap_handshake(const EngineDev &e, const ScanLoop
         else if (st == 1 && is_tgt) { e.rt_state[slot] = 2; e.rt_restarts[slot] += 1; }
         else if (st == 2 && is_ref) { e.rt_state[slot] = 1; e.rt_trips[slot] += 1; }
     }
-    if (pc == c) {                                                          // idle on this graph: publish the epoch only
-        __hip_atomic_store(&sl.flag[c], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (pc == c) {                                                          // idle on this graph: publish the epoch only (nobody reads this replica before the next scan's hand-shake)
+        __hip_atomic_store(&sl.flag[c], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return slot;
     }
     double *mine = sl.pub + ((c * 2 + (int64_t)(epoch & 1ull)) * 4);
     if (!hs_wait(&sl.flag[pc], epoch - 1ull)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
-    mine[0] = lr; mine[1] = u; mine[2] = (double)slot;
-    __hip_atomic_store(&sl.flag[c], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // {log ratio, uniform, slot}: device-coherent (sc1) stores / loads.  Then the hand-off proper, the form MI355X_MICROARCH.md
+    // ("Workgroup dispatch, XCD placement & inter-workgroup visibility") prescribes for plain payload stores: producer = agent-scope release
+    // (buffer_wbl2 sc1: the XCD's dirty L2 lines -- the state row this wave has just written -- reach memory) + an explicit s_waitcnt vmcnt(0)
+    // the compiler cannot drop + relaxed agent flag store; consumer = relaxed polls, ONE agent-scope acquire (buffer_inv sc1: this CU's vector
+    // L1), then plain loads.  Workgroup scope / buffer_inv sc0 is NOT an acquire for another CU's data, same XCD or not: a build that took
+    // that shortcut for same-XCD pairs read stale sum x^2 words at once (round 5).
+    __hip_atomic_store(&mine[0], lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&mine[1], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&mine[2], (double)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef PTE_HS_MEASURE_NO_FENCE     // measurement builds only (not coherent: wrong results): what the L2 write-back / L1 invalidate cost
+    __hip_atomic_store(&sl.flag[c], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!hs_wait(&sl.flag[pc], epoch)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&sl.flag[c], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!hs_wait(&sl.flag[pc], epoch)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
     const double *theirs = sl.pub + ((pc * 2 + (int64_t)(epoch & 1ull)) * 4);
-    const double lr_p = theirs[0], u_p = theirs[1];
-    const int slot_p = (int)theirs[2];
+    const double lr_p = __hip_atomic_load(&theirs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), u_p = __hip_atomic_load(&theirs[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int slot_p = (int)__hip_atomic_load(&theirs[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool lower = c < pc;
     const double uu = lower ? u : u_p;
     bool do_swap;
@@ -632,12 +659,14 @@ __device__ __forceinline__ int swap_handshake(const EngineDev &e, const ScanLoop
         const double ex = exp(lr + lr_p);
         const double alpha = ex < 1.0 ? ex : 1.0;         // swap_acceptance_probability :88
         do_swap = uu < alpha;                               // swap_decision :81-85
+#ifndef PTE_HS_MEASURE_NO_RECORD
         if (lower) {                                        // record_swap_stats! :59-66
             e.swap_sum[c] += alpha; e.swap_n[c] += 1;
             e.lsr_up[c] = dev_logaddexp(e.lsr_up[c], lr);
             e.lsr_dn[c] = dev_logaddexp(e.lsr_dn[c], lr_p);
             e.lsr_n[c] += 1;
         }
+#endif
     }
     if (do_swap) { e.chain_of_slot[slot_p] = (int32_t)c; e.slot_of_chain[c] = slot_p; return slot_p; }
     return slot;

@@ -52,7 +52,7 @@ constexpr int S8_BD = PTE_S8_BD;                 // doubling budget of a specula
 // spill reload (profiles/r04_slice8_round_loop.txt lists every lane instruction of the loop: the five of the chase) -- the 134 spilled
 // SGPRs of the resource table live in the prologue, the window refill and the exact sequential procedure.
 template <int NLU, int S8_BS, int WINDOW, int DBL_MODE>      // DBL_MODE: form of the budgeted doubling steps (0 selects, 1 EXEC masks, 2 v_cmpx + selects)
-__device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
+__device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp, const int64_t cl) {      // cl: the local chain this workgroup explores (blockIdx.x in the per-scan kernels)
     using namespace s7;
     constexpr int WIN = WINDOW, REFILL_AT = WINDOW - PTE_S7_MARGIN;
     // FAST: the instantiation for S8_BD < sp.p <= 20 and sp.max_iter >= S8_BS (the launcher checks; SliceSampler's defaults are p = 20,
@@ -80,7 +80,6 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
 #endif
     for (int i = lane; i < 256; i += 64) { s_we[i] = ZIG_WE[i]; s_ke[i] = ZIG_KE[i]; }
     __syncthreads();
-    const int64_t cl = blockIdx.x;
     if (cl >= e.K) return;
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];
@@ -764,11 +763,11 @@ __device__ __forceinline__ void slice8_body(EngineDev e, SliceParams sp) {
 #endif
 template <int NLU, int S8_BS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES, PTE_S8_WAVES))) void k_explore_slice8(EngineDev e, SliceParams sp) {
-    slice8_body<NLU, S8_BS, PTE_S7_WIN, PTE_S8_DBL_MODE>(e, sp);        // PTE_S8_DBL_MODE == 2 requires S8_BD < sp.p <= 20 and sp.max_iter >= S8_BS (launch_explore checks)
+    slice8_body<NLU, S8_BS, PTE_S7_WIN, PTE_S8_DBL_MODE>(e, sp, blockIdx.x);        // PTE_S8_DBL_MODE == 2 requires S8_BD < sp.p <= 20 and sp.max_iter >= S8_BS (launch_explore checks)
 }
 template <int NLU, int S8_BS>           // any p / max_iter (non-default SliceSampler(p = 1 .. 3, p > 20, max_iter < 9)): the select form tests it < p per step, the round keeps every validity test
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES, PTE_S8_WAVES))) void k_explore_slice8_generic(EngineDev e, SliceParams sp) {
-    slice8_body<NLU, S8_BS, PTE_S7_WIN, 0>(e, sp);
+    slice8_body<NLU, S8_BS, PTE_S7_WIN, 0>(e, sp, blockIdx.x);
 }
 #ifndef PTE_S8_TWIN_WAVES
 #define PTE_S8_TWIN_WAVES PTE_S8_WAVES
@@ -781,7 +780,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES
 #endif
 template <int NLU, int S8_BS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_TWIN_WAVES, PTE_S8_TWIN_WAVES))) void k_explore_slice8_lds10k(EngineDev e, SliceParams sp) {
-    slice8_body<NLU, S8_BS, 256, 1>(e, sp);
+    slice8_body<NLU, S8_BS, 256, 1>(e, sp, blockIdx.x);
 }
 
 // ---- one launch per pte_run_scans (pte_kernels.hpp, "ScanLoop"): workgroup c explores chain c and then takes part in the swap of its own
@@ -790,10 +789,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_TWIN_
 template <int NLU, int S8_BS, int WINDOW, int DBL_MODE>
 __device__ __forceinline__ void slice8_scan_loop(EngineDev e, const SliceParams &sp, const ScanLoop &sl) {
     const int lane = lane_id();
-    const int64_t cl = blockIdx.x;
+    const int64_t cl = scan_loop_chain(e.K);               // XCD-aware: consecutive chains share an L2 (pte_kernels.hpp)
     for (int64_t i = 0; i < sl.n_scans; ++i) {
         e.trace_idx = sl.scan_idx0 + i;
-        slice8_body<NLU, S8_BS, WINDOW, DBL_MODE>(e, sp);
+        slice8_body<NLU, S8_BS, WINDOW, DBL_MODE>(e, sp, cl);
         __syncthreads();                                   // every lane's stores of the explore step happen before lane 0's release
         int slot = 0;
         if (lane == 0) slot = swap_handshake(e, sl, i, cl, e.slot_of_chain[cl]);
