@@ -438,8 +438,8 @@ int run_scans_sharded(pte_engine *h, int64_t first_scan, int64_t n_scans);
 
 // ---- one launch per pte_run_scans (k_scans_*; pte_kernels.hpp "ScanLoop") ----------------------------------------------------------------
 // Which engines: one GPU holds the whole ladder (world_size == 1), SliceSampler on the scaled-precision MVN path with the default kernel
-// generation, no Compose, and every workgroup of the call resident at once (the hand-shakes spin: a workgroup that waits for a GPU slot
-// would be waited for) -- asked of the runtime for the very instantiation that is launched.
+// generation, no Compose, every workgroup of the call resident at once (the hand-shakes spin: a workgroup that waits for a GPU slot
+// would be waited for) -- asked of the runtime for the very instantiation that is launched -- and the shapes at which it was measured to win.
 #ifdef PTE_DEV_FEW_NLU
 #define OCC_NLU_M(nlu, KERNEL, MM, out)                                                                        \
     switch (nlu) {                                                                                              \
@@ -459,26 +459,31 @@ int run_scans_sharded(pte_engine *h, int64_t first_scan, int64_t n_scans);
     }
 #endif
 
-// 0: k_scans_slice8, 1: k_scans_slice8_generic, 2: k_scans_slice8_lds10k -- the same choice launch_explorer_kind makes per scan
+// 0: k_scans_slice8, 1: k_scans_slice8_generic -- the same choice launch_explorer_kind makes per scan
 int fused_slice_variant(const pte_engine *h) {
     const bool fast_ok = h->cfg.slice_p > PTE_S8_BD && h->cfg.slice_p <= 20 && h->cfg.slice_max_iter >= PTE_S8_BS;
-    return h->K > PTE_S8_TWIN_FROM ? 2 : (fast_ok ? 0 : 1);
+    return fast_ok ? 0 : 1;
 }
 
+// Measured on one box against the launch-per-scan loop (tools/r05_fused_shapes.sh, profiles/r05_fused_shapes.txt): at most ONE wave per SIMD
+// and rows of at most 16 KB -- 1024 chains: d = 512 x1.055, d = 1024 x1.03, d = 2048 x1.00, d = 4096 x0.99 (every release writes back the
+// XCD's dirty L2 lines, and 128 waves x 32 KB of freshly written rows are all of it); 2048 chains at d = 1024 x0.91 (a wave that polls shares
+// its SIMD with a wave that works, and the fences cost per resident workgroup).  Elsewhere the loop of rounds 1-4 stays.
 bool fused_scans_eligible(pte_engine *h, int64_t n_scans) {
     if (!h->fused_allowed || h->world != 1 || n_scans < 1) return false;
     if (h->cfg.explorer != PTE_EXPLORER_SLICE || h->cfg.explorer2 != PTE_EXPLORER_NONE || h->cfg.target != PTE_TARGET_MVN_SCALED_PRECISION || h->slice_impl != 8) return false;
+    if (h->d > 2048) return false;
     // a recorder buffer that would overflow inside the call: the launch-per-scan loop reports it at the scan that overflows, as before
     if ((h->cfg.record_flags & (PTE_RECORD_TRACES | PTE_RECORD_INDEX_PROCESS)) && h->scans_in_round + n_scans > h->cfg.max_scans_per_round) return false;
     if (h->fused_limit < 0) {
         int per_cu = 0, cus = 0;
         const int v = fused_slice_variant(h);
         if (v == 0) { OCC_NLU_M(h->nlu, k_scans_slice8, PTE_S8_BS, per_cu); }
-        else if (v == 1) { OCC_NLU_M(h->nlu, k_scans_slice8_generic, PTE_S8_BS, per_cu); }
-        else { OCC_NLU_M(h->nlu, k_scans_slice8_lds10k, PTE_S8_BS, per_cu); }
+        else { OCC_NLU_M(h->nlu, k_scans_slice8_generic, PTE_S8_BS, per_cu); }
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess) cus = 0;
         (void)hipGetLastError();
-        h->fused_limit = (int64_t)per_cu * (int64_t)cus;
+        // every workgroup resident (the hand-shakes spin) AND at most one wave per SIMD (4 SIMDs per CU)
+        h->fused_limit = (int64_t)std::min(per_cu, 4) * (int64_t)cus;
         if (h->fused_limit > 0 && h->K <= h->fused_limit && !h->hs_flag) {
             if (dev_alloc(h, &h->hs_flag, (size_t)h->K) || dev_alloc(h, &h->hs_pub, (size_t)h->K * 8)) { h->fused_limit = 0; h->err.clear(); }
             else hipStreamSynchronize(h->stream);
@@ -496,8 +501,7 @@ int run_scans_fused(pte_engine *h, int64_t first_scan, int64_t n_scans) {
     time_begin(h, 4, true);
     const bool timed = h->ev_open;
     if (v == 0) { DISPATCH_NLU_M(h->nlu, k_scans_slice8, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, sl); }
-    else if (v == 1) { DISPATCH_NLU_M(h->nlu, k_scans_slice8_generic, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, sl); }
-    else { DISPATCH_NLU_M(h->nlu, k_scans_slice8_lds10k, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, sl); }
+    else { DISPATCH_NLU_M(h->nlu, k_scans_slice8_generic, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, sl); }
     time_end(h);
     if (timed) h->t_scans4 += n_scans;
     HIP_OK(h, hipGetLastError());
@@ -1398,7 +1402,7 @@ const char *pte_scan_loop_name(const pte_engine *hc) {
     if (!h) return "";
     hipSetDevice(h->cfg.device);
     if (!fused_scans_eligible(h, 1)) return "";
-    switch (fused_slice_variant(h)) { case 0: return "k_scans_slice8"; case 1: return "k_scans_slice8_generic"; default: return "k_scans_slice8_lds10k"; }
+    return fused_slice_variant(h) == 0 ? "k_scans_slice8" : "k_scans_slice8_generic";
 }
 int pte_scan_loop_info(const pte_engine *hc, int64_t *resident_limit, int64_t *timed_launches, int64_t *timed_scans) {
     pte_engine *h = const_cast<pte_engine *>(hc);

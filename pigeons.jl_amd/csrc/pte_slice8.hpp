@@ -809,9 +809,4 @@ template <int NLU, int S8_BS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_WAVES, PTE_S8_WAVES))) void k_scans_slice8_generic(EngineDev e, SliceParams sp, ScanLoop sl) {
     slice8_scan_loop<NLU, S8_BS, PTE_S7_WIN, 0>(e, sp, sl);
 }
-template <int NLU, int S8_BS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PTE_S8_TWIN_WAVES, PTE_S8_TWIN_WAVES))) void k_scans_slice8_lds10k(EngineDev e, SliceParams sp, ScanLoop sl) {
-    slice8_scan_loop<NLU, S8_BS, 256, 1>(e, sp, sl);
-}
-
 }  // namespace pte

@@ -67,9 +67,8 @@ def _same(a, b):
     (1, 8, 4, 1, "k_scans_slice8"),               # a single chain: no partner ever
     (256, 1024, 3, 3, "k_scans_slice8"),          # BASELINE configs[1]
     (1024, 1024, 3, 1, "k_scans_slice8"),         # the metric configuration: one wave per SIMD
-    (1024, 4096, 2, 4, "k_scans_slice8"),         # what one of 8 GPUs holds of BASELINE configs[3]
-    (2048, 300, 3, 6, "k_scans_slice8"),          # two waves per SIMD: the last shape of the 512-draw kernel
-    (2500, 1024, 2, 9, "k_scans_slice8_lds10k"),  # the many-replica twin, still resident (4 waves per SIMD)
+    (1024, 2048, 2, 4, "k_scans_slice8"),         # the longest rows the fused loop takes (16 KB)
+    (1000, 300, 3, 6, "k_scans_slice8"),
 ])
 def test_fused_scan_loop_equals_launch_per_scan(P, N, d, rounds, seed, kernel):
     pa, a = _run(P, N, d, rounds, seed, two_launches=True)
@@ -138,6 +137,9 @@ def test_which_engines_run_the_fused_loop(P):
     assert mk(explorer=P.AutoMALA()).replicas.scan_loop_name() == ""
     assert mk(explorer=P.Compose(P.SliceSampler(), P.AutoMALA())).replicas.scan_loop_name() == ""
     assert mk(target=P.toy_mvn_target(64), n_chains=8192).replicas.scan_loop_name() == ""            # more workgroups than the GPU holds at once
+    assert mk(target=P.toy_mvn_target(64), n_chains=1025).replicas.scan_loop_name() == ""            # more than one wave per SIMD: measured slower (0.91x at 2048 chains)
+    assert mk(target=P.toy_mvn_target(64), n_chains=1024).replicas.scan_loop_name() == "k_scans_slice8"
+    assert mk(target=P.toy_mvn_target(4096), n_chains=8).replicas.scan_loop_name() == ""             # rows beyond 16 KB: measured slower (0.99x at d = 4096)
     seq = P.PT(P.Inputs(target=P.toy_mvn_target(8), n_chains=6, n_rounds=2, explorer=P.SliceSampler(), show_report=False, record=[P.round_trip]),
                debug_kernel=_lib.KERNEL_SLICE_SEQUENTIAL)
     assert seq.replicas.scan_loop_name() == "" and seq.replicas.kernel_name() == "k_explore_slice"
