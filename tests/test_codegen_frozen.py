@@ -47,6 +47,23 @@ def test_slice8_round_loop(cg, nlu):
     assert t["blocks"] <= 9, t                    # every extra block on the likely path is a branch a lone wave pays ~18-40 cycles for
 
 
+@pytest.mark.parametrize("nlu", [0, 4, 5])       # d = 2 (C1), d = 1024 (the metric, C2), d = 2048 (the longest rows the fused loop takes)
+def test_fused_scan_loop_round_loop(cg, nlu):
+    """k_scans_slice8<NLU, 9> (round 5: all the scans of a pte_run_scans call in one launch; the metric runs THIS kernel): the scan loop
+    around the body must not cost the round loop anything -- the same 301 instructions in 8 blocks, no spill, no scratch -- and the kernel must
+    keep two waves per SIMD's worth of registers (the launcher admits one: 1024 workgroups on 1024 SIMDs)."""
+    C, res, lines = cg
+    name, body = C.kernel_body(lines, "k_scans_slice8ILi%dELi9E" % nlu)
+    header = next(h for d, h in C.loop_headers(body) if d == 4)          # SCAN -> pass -> block -> round
+    t = C.totals(C.hot_path(body, header))
+    assert t["w"] == 0 and t["r"] == 0 and t["scratch"] == 0 and t["m"] == 0 and t["dyn"] == 5, t
+    assert t["instructions"] <= 310 and t["v"] <= 244 and t["s"] <= 58 and t["blocks"] <= 9, t
+    r = res["k_scans_slice8<%d, 9>" % nlu]
+    assert r["scratch_B_per_lane"] == 0 and r["spilled_vgpr"] == 0 and r["vgpr"] <= 256 and r["waves_per_simd"] >= 2, r
+    g = res["k_scans_slice8_generic<%d, 9>" % nlu]
+    assert g["scratch_B_per_lane"] == 0 and g["spilled_vgpr"] == 0 and g["waves_per_simd"] >= 2, g
+
+
 def test_slice8_resources(cg):
     """every instantiation of the default kernel and of its generic twin: no VGPR spill, no scratch, two waves per SIMD (2048 replicas resident)"""
     C, res, _ = cg
