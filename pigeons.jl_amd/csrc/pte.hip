@@ -465,21 +465,34 @@ int fused_slice_variant(const pte_engine *h) {
     return fast_ok ? 0 : 1;
 }
 
-// Measured on one box against the launch-per-scan loop (tools/r05_fused_shapes.sh, profiles/r05_fused_shapes.txt): at most ONE wave per SIMD
+// SliceSampler, measured on one box against the launch-per-scan loop (tools/r05_fused_shapes.sh, profiles/r05_fused_shapes.txt): at most ONE wave per SIMD
 // and rows of at most 16 KB -- 1024 chains: d = 512 x1.055, d = 1024 x1.03, d = 2048 x1.00, d = 4096 x0.99 (every release writes back the
 // XCD's dirty L2 lines, and 128 waves x 32 KB of freshly written rows are all of it); 2048 chains at d = 1024 x0.91 (a wave that polls shares
 // its SIMD with a wave that works, and the fences cost per resident workgroup).  Elsewhere the loop of rounds 1-4 stays.
+// 0: not a fused kind; 1: SliceSampler on the MVN path (k_scans_slice8*); 2: AutoMALA / MALA on the MVN or funnel path (k_scans_automala)
+int fused_kind(const pte_engine *h) {
+    if (h->cfg.explorer2 != PTE_EXPLORER_NONE) return 0;
+    if (h->cfg.explorer == PTE_EXPLORER_SLICE && h->cfg.target == PTE_TARGET_MVN_SCALED_PRECISION && h->slice_impl == 8) return h->d <= 2048 ? 1 : 0;
+    if ((h->cfg.explorer == PTE_EXPLORER_AUTOMALA || h->cfg.explorer == PTE_EXPLORER_MALA) &&
+        (h->cfg.target == PTE_TARGET_MVN_SCALED_PRECISION || h->cfg.target == PTE_TARGET_FUNNEL)) return h->d <= 512 ? 2 : 0;
+    return 0;
+}
+int langevin_E(const pte_engine *h) { return h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16; }
+
 bool fused_scans_eligible(pte_engine *h, int64_t n_scans) {
     if (!h->fused_allowed || h->world != 1 || n_scans < 1) return false;
-    if (h->cfg.explorer != PTE_EXPLORER_SLICE || h->cfg.explorer2 != PTE_EXPLORER_NONE || h->cfg.target != PTE_TARGET_MVN_SCALED_PRECISION || h->slice_impl != 8) return false;
-    if (h->d > 2048) return false;
+    const int kind = fused_kind(h);
+    if (kind == 0) return false;
     // a recorder buffer that would overflow inside the call: the launch-per-scan loop reports it at the scan that overflows, as before
     if ((h->cfg.record_flags & (PTE_RECORD_TRACES | PTE_RECORD_INDEX_PROCESS)) && h->scans_in_round + n_scans > h->cfg.max_scans_per_round) return false;
     if (h->fused_limit < 0) {
         int per_cu = 0, cus = 0;
-        const int v = fused_slice_variant(h);
-        if (v == 0) { OCC_NLU_M(h->nlu, k_scans_slice8, PTE_S8_BS, per_cu); }
-        else { OCC_NLU_M(h->nlu, k_scans_slice8_generic, PTE_S8_BS, per_cu); }
+        if (kind == 1) {
+            if (fused_slice_variant(h) == 0) { OCC_NLU_M(h->nlu, k_scans_slice8, PTE_S8_BS, per_cu); }
+            else { OCC_NLU_M(h->nlu, k_scans_slice8_generic, PTE_S8_BS, per_cu); }
+        } else {
+            per_cu = langevin_scan_loop_blocks_per_cu(langevin_E(h), h->cfg.target == PTE_TARGET_FUNNEL ? TGT_FUNNEL : TGT_MVN, h->d == 64 * (int64_t)langevin_E(h));
+        }
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess) cus = 0;
         (void)hipGetLastError();
         // every workgroup resident (the hand-shakes spin) AND at most one wave per SIMD (4 SIMDs per CU)
@@ -494,14 +507,28 @@ bool fused_scans_eligible(pte_engine *h, int64_t n_scans) {
 
 int run_scans_fused(pte_engine *h, int64_t first_scan, int64_t n_scans) {
     const int64_t N = h->K;
-    SliceParams sp{h->cfg.slice_w, h->cfg.slice_p, h->cfg.slice_n_passes, h->cfg.slice_max_iter};
     ScanLoop sl{first_scan, n_scans, h->scans_in_round, h->hs_epoch, h->hs_flag, h->hs_pub};
     h->dev.compose_phase = 0; h->dev.trace_idx = h->scans_in_round;
-    const int v = fused_slice_variant(h);
     time_begin(h, 4, true);
     const bool timed = h->ev_open;
-    if (v == 0) { DISPATCH_NLU_M(h->nlu, k_scans_slice8, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, sl); }
-    else { DISPATCH_NLU_M(h->nlu, k_scans_slice8_generic, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, sl); }
+    if (fused_kind(h) == 1) {
+        SliceParams sp{h->cfg.slice_w, h->cfg.slice_p, h->cfg.slice_n_passes, h->cfg.slice_max_iter};
+        if (fused_slice_variant(h) == 0) { DISPATCH_NLU_M(h->nlu, k_scans_slice8, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, sl); }
+        else { DISPATCH_NLU_M(h->nlu, k_scans_slice8_generic, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, sl); }
+    } else {
+        // the parameters launch_explorer_kind gives the per-scan kernel; use_mh (scan != 1, AutoMALA.jl:87,96-102) is decided per scan inside
+        AmParams ap{};
+        ap.mala = (h->cfg.explorer == PTE_EXPLORER_MALA) ? 1 : 0;
+        ap.step_size = ap.mala ? h->cfg.am_step_size : h->step_size; ap.n_refresh = h->am_n_refresh; ap.precond = h->cfg.am_preconditioner;
+        ap.p0 = h->cfg.am_p0; ap.p1 = h->cfg.am_p1;
+        ap.target_std = h->have_target_std ? h->d_target_std : nullptr;
+        ap.use_mh = 1;
+        ap.ref_prec = h->cfg.target_params[0]; ap.log3 = std::log(3.0);
+        const int E = langevin_E(h);
+        LangevinLaunch L{E, h->cfg.target == PTE_TARGET_FUNNEL ? TGT_FUNNEL : TGT_MVN, false, h->d == 64 * (int64_t)E, (unsigned)N, h->stream, false, nullptr, nullptr, &sl};
+        if (h->ev_open && h->ev_ext && !h->ev_ext_done) { L.ext = true; L.ev_a = h->events.back().a; L.ev_b = h->events.back().b; h->ev_ext_done = true; }
+        if (langevin_launch(L, h->dev, ap)) { time_end(h); return fail(h, "this build holds no fused Langevin-family kernel"); }
+    }
     time_end(h);
     if (timed) h->t_scans4 += n_scans;
     HIP_OK(h, hipGetLastError());
@@ -1402,6 +1429,7 @@ const char *pte_scan_loop_name(const pte_engine *hc) {
     if (!h) return "";
     hipSetDevice(h->cfg.device);
     if (!fused_scans_eligible(h, 1)) return "";
+    if (fused_kind(h) == 2) return "k_scans_automala";
     return fused_slice_variant(h) == 0 ? "k_scans_slice8" : "k_scans_slice8_generic";
 }
 int pte_scan_loop_info(const pte_engine *hc, int64_t *resident_limit, int64_t *timed_launches, int64_t *timed_scans) {

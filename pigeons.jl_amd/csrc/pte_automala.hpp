@@ -247,8 +247,17 @@ struct AmTarget {
 
 // SLICE = true instantiates the same prologue (reference-chain refresh, state load) and epilogue (swap statistics, recorders)
 // around the SliceSampler sweep instead of the Langevin refreshes: a separate kernel, so that neither pays for the other's registers.
+#ifndef PTE_AM_PERMUTE
+#define PTE_AM_PERMUTE 97                  // (a prime: coprime to every chain count it does not divide)
+#endif
+// Neighbouring chains do similar work (the slow ones -- most step-size trials -- sit next to the reference) and neighbouring
+// workgroups share a CU, whose FP64 pipe the four SIMDs contend for: a stride permutation of workgroup -> chain spreads the slow
+// chains over the chip.  Measured at C3, interleaved on one box: 0.231 -> 0.227 ms / scan (the same permutation makes the slice
+// kernel 2.5 % SLOWER -- it is not applied there).
+__device__ __forceinline__ int64_t am_chain_of_workgroup(int64_t K, int64_t wg) { return (K % PTE_AM_PERMUTE) ? (wg * PTE_AM_PERMUTE) % K : wg; }
+
 template <int E, int TGT, bool SLICE = false, bool FULL = false>
-__global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams ap) {
+__device__ __forceinline__ void automala_body(EngineDev e, AmParams ap, const int64_t wg) {      // wg: blockIdx.x
     constexpr int NLU = (E == 1 ? 0 : E == 2 ? 1 : E == 4 ? 2 : E == 8 ? 3 : 4);
     const int lane = lane_id();
     // the ziggurat tables of the momentum draws, staged once: a global gather per block of draws costs a memory round trip each time
@@ -259,14 +268,7 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         for (int i = lane; i < 256; i += 64) { s_wi[i] = ZIG_WI[i]; s_ki[i] = ZIG_KI[i]; s_fi[i] = ZIG_FI[i]; }
         __syncthreads();
     }
-    // Neighbouring chains do similar work (the slow ones -- most step-size trials -- sit next to the reference) and neighbouring
-    // workgroups share a CU, whose FP64 pipe the four SIMDs contend for: a stride permutation of workgroup -> chain spreads the slow
-    // chains over the chip.  Measured at C3, interleaved on one box: 0.231 -> 0.227 ms / scan (the same permutation makes the slice
-    // kernel 2.5 % SLOWER -- it is not applied there).
-#ifndef PTE_AM_PERMUTE
-#define PTE_AM_PERMUTE 97                  // (a prime: coprime to every chain count it does not divide)
-#endif
-    const int64_t cl = (e.K % PTE_AM_PERMUTE) ? ((int64_t)blockIdx.x * PTE_AM_PERMUTE) % e.K : (int64_t)blockIdx.x;
+    const int64_t cl = am_chain_of_workgroup(e.K, wg);
     if (cl >= e.K) return;
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];
@@ -639,6 +641,43 @@ __global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams a
         e.am_rev_sum[cl] += (double)rev_sum;       e.am_rev_n[cl] += rev_n;
     }
     record_after_explore(e, cl, c, slot, lane, lp_before, S, l2, l3);
+}
+
+template <int E, int TGT, bool SLICE = false, bool FULL = false>
+__global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams ap) {
+    automala_body<E, TGT, SLICE, FULL>(e, ap, blockIdx.x);
+}
+
+// (the body as a CALLED function in the scan loop: inlined, the loop's long-lived values -- the engine's ~70 pointers, the hand-shake words --
+// push 32 spill reloads into every step-size search loop; called, the body keeps the register allocation of the per-scan kernel)
+template <int E, int TGT, bool FULL>
+__device__ __attribute__((noinline)) void automala_body_called(const EngineDev &e, const AmParams &ap, const int64_t wg) {
+    automala_body<E, TGT, false, FULL>(e, ap, wg);
+}
+
+// One launch per pte_run_scans (pte_kernels.hpp "ScanLoop"; round 5): AutoMALA / MALA refreshes, then the pairwise swap hand-shake, for all
+// the scans of the call.  `scan != 1` (AutoMALA.jl:87,96-102: no MH step in the first scan of a round) is decided per scan inside.
+template <int E, int TGT, bool FULL>
+__global__ __launch_bounds__(64) void k_scans_automala(EngineDev e, AmParams ap, ScanLoop sl) {
+    const int lane = lane_id();
+    const int64_t cl = am_chain_of_workgroup(e.K, blockIdx.x);
+    for (int64_t i = 0; i < sl.n_scans; ++i) {
+#ifndef PTE_TEST_NO_E_COPY
+        e.trace_idx = sl.scan_idx0 + i;
+#endif
+        if (!ap.mala) ap.use_mh = (sl.first_scan + i != 1) ? 1 : 0;
+#ifdef PTE_AM_SCANS_INLINE
+        automala_body<E, TGT, false, FULL>(e, ap, blockIdx.x);
+#else
+        automala_body_called<E, TGT, FULL>(e, ap, blockIdx.x);
+#endif
+        __syncthreads();                                   // every lane's stores of the explore step happen before lane 0's release
+        int slot = 0;
+        if (lane == 0) slot = swap_handshake(e, sl, i, cl, e.slot_of_chain[cl]);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        __syncthreads();                                   // ... and lane 0's acquire before every lane's loads of the next one
+        if (slot < 0) return;
+    }
 }
 
 // Swap statistics of every slot recomputed from the stored states (pte_set_state on an interpolated path):

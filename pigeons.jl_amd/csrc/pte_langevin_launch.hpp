@@ -12,10 +12,42 @@ static inline void langevin_launch_one(K kernel, const LangevinLaunch &L, const 
     else hipLaunchKernelGGL(kernel, dim3(L.N), dim3(64), 0, L.stream, dev, ap);
 }
 
+template <typename K>
+static inline void langevin_launch_scans(K kernel, const LangevinLaunch &L, const EngineDev &dev, const AmParams &ap) {
+    if (L.ext) hipExtLaunchKernelGGL(kernel, dim3(L.N), dim3(64), 0, L.stream, L.ev_a, L.ev_b, 0, dev, ap, *L.scans);
+    else hipLaunchKernelGGL(kernel, dim3(L.N), dim3(64), 0, L.stream, dev, ap, *L.scans);
+}
+
+// the fused scan loop exists for the shapes one wave holds comfortably (E <= 8: d <= 512); the d > 512 instantiations spill and stay per scan
+#define AM_SCANS_ONE(EE, WHAT)                                                                                                   \
+    if (target == TGT_FUNNEL && full) { WHAT((k_scans_automala<EE, TGT_FUNNEL, true>)); }                                        \
+    else if (target == TGT_FUNNEL) { WHAT((k_scans_automala<EE, TGT_FUNNEL, false>)); }                                          \
+    else if (full) { WHAT((k_scans_automala<EE, TGT_MVN, true>)); }                                                              \
+    else { WHAT((k_scans_automala<EE, TGT_MVN, false>)); }
+
+int langevin_scan_loop_blocks_per_cu(int E, int target, bool full) {
+#ifdef PTE_DEV_NO_LANGEVIN
+    (void)E; (void)target; (void)full; return 0;
+#else
+    int n = 0;
+#define AM_OCC(KERNEL) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, KERNEL, 64, 0)
+    switch (E) { case 1: AM_SCANS_ONE(1, AM_OCC) break; case 2: AM_SCANS_ONE(2, AM_OCC) break; case 4: AM_SCANS_ONE(4, AM_OCC) break; case 8: AM_SCANS_ONE(8, AM_OCC) break; default: return 0; }
+#undef AM_OCC
+    return n;
+#endif
+}
+
 int langevin_launch(const LangevinLaunch &L, const EngineDev &dev, const AmParams &ap) {
 #ifdef PTE_DEV_NO_LANGEVIN      // development builds only (tools/build_variant.sh): three quarters of the compile time are these instantiations
     (void)L; (void)dev; (void)ap; return 1;
 #else
+    if (L.scans) {
+        const int target = L.target; const bool full = L.full;
+#define AM_GO(KERNEL) langevin_launch_scans(KERNEL, L, dev, ap)
+        switch (L.E) { case 1: AM_SCANS_ONE(1, AM_GO) break; case 2: AM_SCANS_ONE(2, AM_GO) break; case 4: AM_SCANS_ONE(4, AM_GO) break; case 8: AM_SCANS_ONE(8, AM_GO) break; default: return 1; }
+#undef AM_GO
+        return 0;
+    }
 #define AM_ONE(EE)                                                                                                              \
     if (L.slice) langevin_launch_one(k_explore_automala<EE, TGT_FUNNEL, true>, L, dev, ap);                                     \
     else if (L.target == TGT_FUNNEL && L.full) langevin_launch_one(k_explore_automala<EE, TGT_FUNNEL, false, true>, L, dev, ap); \

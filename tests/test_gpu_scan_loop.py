@@ -127,6 +127,47 @@ def test_fused_scan_loop_against_the_oracle_with_split_calls(P):
     np.testing.assert_allclose(x, xr, rtol=1e-12, atol=0)
 
 
+def _run_am(P, N, d, rounds, seed, two_launches, target="mvn", explorer=None, nv=0):
+    from pigeons_amd import _lib
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.online, P.energy_ac1]
+    kw = dict(n_chains=N, n_rounds=rounds, seed=seed, explorer=explorer or P.AutoMALA(), record=rec, show_report=False)
+    if target == "funnel":
+        kw.update(target=P.Funnel(d), reference=P.ScaledPrecisionNormalLogPotential(1 / 9., d))
+    else:
+        kw.update(target=P.toy_mvn_target(d))
+    if nv:
+        kw.update(n_chains_variational=nv)
+    pt = P.PT(P.Inputs(**kw), debug_kernel=_lib.KERNEL_TWO_LAUNCHES if two_launches else 0)
+    out = []
+    for _ in range(rounds):
+        assert P.next_round(pt)
+        red = P.run_one_round(pt); P.adapt(pt, red)
+        out.append([red.index_process.copy(), np.array(red.round_trip), red.swap_acceptance_pr[0].copy(), red.log_sum_ratio[0].copy(), red.log_sum_ratio[2].copy(),
+                    red.explorer_n_steps[0].copy(), red.explorer_acceptance_pr[0].copy(), np.array(red.am_factors[0]).copy(), np.array(red.reversibility_rate[0]).copy(),
+                    _grids(pt), np.array(red.online[0]).copy(), np.array(red.online[1]).copy(), np.array(red.energy_ac1[2]).copy()])
+    return pt, out
+
+
+@pytest.mark.parametrize("target,N,d,rounds,seed,explorer", [
+    ("funnel", 1024, 128, 3, 1, "automala"),      # BASELINE configs[2]
+    ("funnel", 8, 70, 5, 2, "automala"),          # ragged second block
+    ("mvn", 6, 10, 7, 1, "automala"),
+    ("mvn", 5, 512, 3, 3, "automala"),            # E = 8: the largest register layout the fused loop takes
+    ("mvn", 5, 64, 5, 4, "mala"),
+    ("funnel", 6, 8, 6, 5, "mala"),
+])
+def test_fused_langevin_scan_loop_equals_launch_per_scan(P, target, N, d, rounds, seed, explorer):
+    """AutoMALA / MALA: k_scans_automala (refreshes + pairwise swap hand-shake for all the scans of a call; the `scan != 1` rule of
+    AutoMALA.jl:87,96-102 decided per scan inside the kernel) against the launch-per-scan loop, bit for bit"""
+    ex = (lambda: P.AutoMALA()) if explorer == "automala" else (lambda: P.MALA())
+    pa, a = _run_am(P, N, d, rounds, seed, True, target, ex())
+    pb, b = _run_am(P, N, d, rounds, seed, False, target, ex())
+    assert pa.replicas.scan_loop_name() == "" and pb.replicas.scan_loop_name() == "k_scans_automala"
+    _same(a, b)
+    for x, y in zip(pa.replicas.states(), pb.replicas.states()):
+        assert np.array_equal(x, y)
+
+
 def test_which_engines_run_the_fused_loop(P):
     """the documented choice: SliceSampler on the MVN path with the default kernel generation, one engine, all workgroups resident"""
     from pigeons_amd import _lib
@@ -134,7 +175,8 @@ def test_which_engines_run_the_fused_loop(P):
                                                  record=[P.round_trip, P.log_sum_ratio]), **kw)))
     assert mk().replicas.scan_loop_name() == "k_scans_slice8"
     assert mk(explorer=P.ToyExplorer()).replicas.scan_loop_name() == ""
-    assert mk(explorer=P.AutoMALA()).replicas.scan_loop_name() == ""
+    assert mk(explorer=P.AutoMALA()).replicas.scan_loop_name() == "k_scans_automala"
+    assert mk(explorer=P.AutoMALA(), target=P.toy_mvn_target(600)).replicas.scan_loop_name() == ""   # d > 512: the spilling register layouts stay per scan
     assert mk(explorer=P.Compose(P.SliceSampler(), P.AutoMALA())).replicas.scan_loop_name() == ""
     assert mk(target=P.toy_mvn_target(64), n_chains=8192).replicas.scan_loop_name() == ""            # more workgroups than the GPU holds at once
     assert mk(target=P.toy_mvn_target(64), n_chains=1025).replicas.scan_loop_name() == ""            # more than one wave per SIMD: measured slower (0.91x at 2048 chains)
