@@ -26,13 +26,14 @@ static unsigned long long fnv(const void *p, size_t n, unsigned long long h) {
 int main(int argc, char **argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 8192, d = argc > 2 ? atoi(argv[2]) : 4096;
     const double sd = argc > 3 ? atof(argv[3]) : 1.7;
+    const size_t dyn_lds = argc > 4 ? (size_t)atoi(argv[4]) : 0;     // extra dynamic LDS per workgroup: caps the workgroups resident per CU (160 KB / (31 KB + this))
     double *x, *roots; unsigned long long *seeds;
     (void)hipMalloc(&x, (size_t)N * d * 8); (void)hipMalloc(&roots, (size_t)N * 8); (void)hipMalloc(&seeds, (size_t)N * 8);
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     float best = 1e30f, sum = 0; const int reps = 10;
     for (int rep = 0; rep < reps + 2; ++rep) {
         (void)hipEventRecord(a, 0);
-        hipLaunchKernelGGL(k, dim3((N + NRM_WPB - 1) / NRM_WPB), dim3(64 * NRM_WPB), 0, 0, x, seeds, roots, N, d, sd);
+        hipLaunchKernelGGL(k, dim3((N + NRM_WPB - 1) / NRM_WPB), dim3(64 * NRM_WPB), dyn_lds, 0, x, seeds, roots, N, d, sd);
         (void)hipEventRecord(b, 0); (void)hipEventSynchronize(b);
         float ms; (void)hipEventElapsedTime(&ms, a, b);
         if (rep >= 2) { if (ms < best) best = ms; sum += ms; }
@@ -45,6 +46,7 @@ int main(int argc, char **argv) {
     unsigned long long h = fnv(hx.data(), (size_t)N * d * 8, 0xcbf29ce484222325ull);
     h = fnv(hr.data(), (size_t)N * 8, h); h = fnv(hs.data(), (size_t)N * 8, h);
     const double bytes = (double)N * d * 8;
+    if (dyn_lds) printf("dynLDS=%zu ", dyn_lds);
     printf("N=%d d=%d sd=%g  best %.4f ms = %.0f GB/s   mean %.4f ms = %.0f GB/s   checksum %016llx\n", N, d, sd, best, bytes / best / 1e6, sum / reps, bytes / (sum / reps) / 1e6, h);
     return 0;
 }
