@@ -67,7 +67,18 @@ def compile_units(extra=(), force=False):
         return src, cmd, stem + ".s", open(stem + ".remarks").read()
 
     with ThreadPoolExecutor(len(jobs)) as ex:
-        return list(ex.map(run, jobs))
+        out = list(ex.map(run, jobs))
+    # prune: an assembly file is ~60 MB; keep what this call produced and anything younger than two hours
+    import time
+    keep = set(os.path.basename(stem) for _, _, stem in jobs)
+    for f in os.listdir(CACHE):
+        full = os.path.join(CACHE, f)
+        if f.rsplit(".", 1)[0] not in keep and time.time() - os.path.getmtime(full) > 7200:
+            try:
+                os.remove(full)
+            except OSError:
+                pass
+    return out
 
 
 _RES_KEYS = [("vgpr", r" VGPRs"), ("agpr", r"AGPRs"), ("sgpr", r"TotalSGPRs"), ("spilled_vgpr", r"VGPRs Spill"), ("spilled_sgpr", r"SGPRs Spill"),
