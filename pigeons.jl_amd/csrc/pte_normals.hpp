@@ -52,6 +52,10 @@ constexpr int NRM_EV_CAP = 128;             // entries of the event list (the li
 #else
 #define NRM_ATTR
 #endif
+#ifndef NRM_PRIO
+#define NRM_PRIO 4                          // > 0: wave priority by remaining work, in NRM_PRIO steps over the row (4: quarters; 0: off).  Measured, bit-identical
+                                            // (tools/ubench/normals_dev.hip): N = 8192, d = 4096 83.4 -> 81.0 us; N = 4096 50.2 -> 46.4; N = 32768 283 -> 288 (8 steps: 81.9 / 48.0)
+#endif
 #ifndef NRM_WPB
 #define NRM_WPB 4                           // waves (replicas) per workgroup; they share the ziggurat tables (10 KB)
 #endif
@@ -121,6 +125,15 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
     double *const out = L.out[wv];
     int64_t done = 0;                                       // outputs written so far (a multiple of 256 until the last group)
     while (done < d) {
+#if NRM_PRIO
+        // The issue arbiter favours the oldest wave of a SIMD, so the 4-5 waves that share one finish one after the other and the last of
+        // them runs its final chunks ALONE, at a lone wave's efficiency (stamps of tools/ubench/normals_dev.hip -DNRM_STAMP at N = 4096,
+        // d = 4096, every wave started within 1 us: first exit 24 us, median 33, last 45 -- for equal work).  Priority by REMAINING work
+        // (s_setprio 3 in the first quarter of the row ... 0 in the last) lets the laggards catch up: the waves of a SIMD end together
+        // and the SIMD stays saturated to the end.
+        { const int lvl = (int)((done * NRM_PRIO) / d);
+          switch (lvl) { case 0: __builtin_amdgcn_s_setprio(3); break; case 1: __builtin_amdgcn_s_setprio(2); break; case 2: __builtin_amdgcn_s_setprio(1); break; default: __builtin_amdgcn_s_setprio(0); break; } }
+#endif
         // ---- 1. positions base + 1 .. base + NRM_CP of the stream
 #ifdef NRM_PROF
         const unsigned long long pt0 = __builtin_readcyclecounter();
