@@ -56,6 +56,17 @@ constexpr int NRM_EV_CAP = 128;             // entries of the event list (the li
 #define NRM_PRIO 4                          // > 0: wave priority by remaining work, in NRM_PRIO steps over the row (4: quarters; 0: off).  Measured, bit-identical
                                             // (tools/ubench/normals_dev.hip): N = 8192, d = 4096 83.4 -> 81.0 us; N = 4096 50.2 -> 46.4; N = 32768 283 -> 288 (8 steps: 81.9 / 48.0)
 #endif
+// Round 5: the kernel is bound by a wave's DEPENDENCY CHAIN as much as by issue -- one row alone on its SIMD takes 32 us, each further wave of the
+// SIMD adds 5 (tools/ubench/normals_dev.hip, N = 1024 ... 5120 at d = 4096), and five waves per SIMD is all the LDS allows -- so latency taken out of
+// a chunk shows at every occupancy.  Both switches are bit-identical (checksum of the harness) and measured together with NRM_PRIO:
+// lone wave 31.7 -> 29.2 us per row, N = 8192 83.4 -> 79.4 us (3.21 -> 3.38 TB/s); per chunk of a lone wave: positions 2,365 -> 1,912 cycles,
+// events' bookkeeping + compaction 1,810 -> 1,416 (tools/ubench/normals_prof.hip).
+#ifndef NRM_COMPACT_ILP
+#define NRM_COMPACT_ILP 1                   // the compaction requests all the slots' values in one LDS round trip
+#endif
+#ifndef NRM_PIPE_POS
+#define NRM_PIPE_POS 1                      // slot j + 1's SplitMix64 evaluation and table read in flight while slot j is converted, stored and listed
+#endif
 #ifndef NRM_WPB
 #define NRM_WPB 4                           // waves (replicas) per workgroup; they share the ziggurat tables (10 KB)
 #endif
@@ -147,6 +158,33 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
 #endif
         uint64_t zc = base + (uint64_t)(lane + 1) * gamma;
         int n_ev = 0;                                       // uniform
+#if NRM_PIPE_POS
+        // software pipeline: the SplitMix64 evaluation and the table read of slot j + 1 are in flight while slot j is converted, stored and
+        // listed -- the uniform branch around the event list is a scheduling barrier, and behind it a slot used to wait for its own table
+        // read (~120 cycles of LDS latency x 9 slots: a lone wave spent 2,365 cycles per chunk here for 1,030 cycles of issue)
+        uint64_t raw_n = mix64(zc);
+        NrmWK t_n = L.wk[(uint32_t)raw_n & 0x1FFu];
+#pragma unroll
+        for (int j = 0; j < NRM_SLOTS; ++j) {
+            const uint64_t raw = raw_n;
+            const NrmWK t = t_n;
+            if (j + 1 < NRM_SLOTS) {
+                zc += g64;
+                raw_n = mix64(zc);
+                t_n = L.wk[(uint32_t)raw_n & 0x1FFu];
+            }
+            const uint32_t lo = (uint32_t)raw, hi = (uint32_t)(raw >> 32);
+            const uint64_t mb = ((uint64_t)((hi & 0x000FFFFFu) | 0x43300000u) << 32) | (lo & ~1u);
+            out[64 * j + lane] = (__longlong_as_double((long long)mb) - 4503599627370496.0) * t.w;
+            const bool slow = !(mb < t.k);
+            const uint64_t m = ballot64(slow);
+            if (m) {
+                const int at = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)n_ev));
+                if (slow) L.ev[wv][min(at, NRM_EV_CAP - 1)] = (unsigned short)(64 * j + lane);
+                n_ev += __popcll(m);
+            }
+        }
+#else
 #pragma unroll
         for (int j = 0; j < NRM_SLOTS; ++j) {              // (three slots issued together, no branch between them: the same, measured)
 #ifdef NRM_MEASURE_NO_MIX          // measurement builds only (wrong samples): what the SplitMix64 finaliser costs
@@ -172,6 +210,7 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
                 n_ev += __popcll(m);
             }
         }
+#endif
         int pos_limit = NRM_CP;                             // positions below this one are resolved (events beyond the list are not)
         __builtin_amdgcn_wave_barrier();
         if (n_ev >= NRM_MAX_EV) { n_ev = NRM_MAX_EV; pos_limit = L.ev[wv][NRM_MAX_EV - 1] + 1; }  // (essentially never: 9 events expected; later positions may hide unlisted events)
@@ -289,6 +328,23 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
         // mask -- makes a lone wave 16 % faster per chunk and the kernel at full occupancy 17 % SLOWER: measured in round 3 and dropped.)
         {
             int cum = 0;                                    // uniform: outputs before this slot
+#if NRM_COMPACT_ILP
+            // all the slots' values are requested in ONE LDS round trip (a slot's outputs land below the next slot's positions, so reading
+            // every slot first is the same function; the compiler cannot know and would keep read j + 1 behind write j): the kernel is bound
+            // by a wave's dependency chain as much as by issue (a lone wave's row takes 32 us, each further wave of the SIMD adds 5)
+            double vall[NRM_SLOTS];
+#pragma unroll
+            for (int j = 0; j < NRM_SLOTS; ++j) vall[j] = out[64 * j + lane];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < NRM_SLOTS; ++j) {
+                const double vj = vall[j];
+                const uint64_t keep = ballot64(vj == vj);
+                const int at = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(keep >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)keep, (unsigned)cum));
+                if (vj == vj) out[at] = vj;
+                cum += __popcll(keep);
+            }
+#else
 #pragma unroll
             for (int j = 0; j < NRM_SLOTS; ++j) {
                 const double vj = out[64 * j + lane];
@@ -297,6 +353,7 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
                 if (vj == vj) out[at] = vj;
                 cum += __popcll(keep);
             }
+#endif
         }
         __builtin_amdgcn_wave_barrier();
 #ifdef NRM_PROF
