@@ -14,7 +14,8 @@ def main():
     sub = sys.argv[1] if len(sys.argv) > 1 else "k_explore_slice8ILi4ELi9E"
     units = C.compile_units()
     name, body = C.kernel_body(C.asm_lines(units), sub)
-    header = next(h for d, h in C.loop_headers(body) if d == 3)
+    depth = 4 if "k_scans" in sub else 3              # (the fused kernels wrap the body in the scan loop: one level deeper)
+    header = next(h for d, h in C.loop_headers(body) if d == depth)
     hot = C.hot_path(body, header)
     hot_names = set(b["name"] for b in hot)
     for _, cmd, _, _ in units:
