@@ -247,6 +247,11 @@ function Pigeons.run_one_round!(pt::PT{<:Inputs{<:OnDevice}})
     return Pigeons.reduce_recorders!(pt, r)
 end
 
+# Which form pte_run_scans takes on this engine (round 5): "" = an explore and a swap launch per scan; otherwise the ONE kernel that runs all the
+# scans of the call ("k_scans_slice8", "k_scans_automala": workgroup c keeps chain c, the DEO swap of a pair is a hand-shake between its two
+# waves).  Results are bit-identical either way; `debug_kernel = PTE_KERNEL_TWO_LAUNCHES` (0x1000) in the config forces the per-scan loop.
+scan_loop_name(r::DeviceReplicas) = unsafe_string(ccall((:pte_scan_loop_name, libpte), Cstring, (Ptr{Cvoid},), r.handle))
+
 # adapt(pt, reduced_recorders) ran on the host (adapt_tempering: src/tempering/NonReversiblePT.jl:46-66, StabilizedPT.jl:53-65;
 # adapt_explorer: AutoMALA.jl:70-79, MALA.jl:63-69, Compose.jl:10-14; update_reference!: GaussianReference.jl:24-31): push the results
 function after_adapt!(pt)
