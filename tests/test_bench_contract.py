@@ -83,7 +83,7 @@ def test_single_gpu_line_has_the_contract_fields():
     assert h["k_explore_toy"]["bytes_per_launch"] == (8 * 4096 + 32) * 8192
     ki = h["k_init"]                                    # the average is an average (of the warm constructions); the minimum has its own key
     assert len(ki["launch_us_of_6_constructions"]) == 6 and ki["min_launch_us"] == min(ki["launch_us_of_6_constructions"])
-    assert abs(ki["avg_launch_us"] - sum(ki["launch_us_of_6_constructions"][1:]) / 5) < 1e-9 * ki["avg_launch_us"] and ki["min_launch_us"] <= ki["avg_launch_us"]
+    assert abs(ki["avg_launch_us"] - sum(sorted(ki["launch_us_of_6_constructions"])[:5]) / 5) < 1e-9 * ki["avg_launch_us"] and ki["min_launch_us"] <= ki["avg_launch_us"]
     x = j["extra_configs"]
     assert len(x) == 6 and all(c["ms_per_scan"] > 0 and c["kernel"] for c in x) and x[0]["config"].startswith("C1 ")
     assert {c["kernel"] for c in x} >= {"k_explore_slice8", "k_explore_slice8_lds10k", "k_explore_automala", "k_explore_ising_spec"}
