@@ -15,7 +15,8 @@ stream -- over the REAL library, one fresh process per GPU, G = 2, 4, 8 (as many
 
 On a 1-GPU box the module is collected and SKIPPED (torch.cuda.device_count() does not initialise HIP on this image; the launcher process
 never touches the GPU; the ranks are fresh children that exit non-zero on their own 300 s watchdog -- no re-exec anywhere).
-tools/scale8.sh runs this module before it times anything."""
+tools/scale8.sh runs this module before it times anything.  (The file name sorts it behind every other module: on the first multi-GPU box
+`pytest -x` should have run the whole single-GPU suite before it meets a transport nobody has been able to run yet.)"""
 import json
 import os
 import subprocess

@@ -19,4 +19,12 @@ for N in (512, 256, 768, 1024):
     cnt=np.bincount(key, minlength=8*8*16*4)
     dur=(o[:,1]-o[:,0])/100.0
     shared=cnt[key]>1
+    # which SIMDs of a CU hold the waves, and how long such waves run
+    cukey=key//4
+    pats={}
+    for ck in np.unique(cukey):
+        sel=cukey==ck
+        pat=tuple(sorted(simd[sel].tolist()))
+        pats.setdefault(pat,[]).append(dur[sel].mean())
+    print("N=%d SIMD patterns per CU: %s" % (N, {k:(len(v), round(float(np.mean(v)),1)) for k,v in sorted(pats.items(), key=lambda kv:-len(kv[1]))[:8]}))
     print("N=%d: waves per SIMD histogram (SIMDs with 1, 2, 3.. waves): %s; mean duration of waves alone on their SIMD %.1f us, sharing a SIMD %.1f us (%d waves); per-CU wave counts %s"%(N, np.bincount(cnt[cnt>0])[1:], dur[~shared].mean(), dur[shared].mean() if shared.any() else float('nan'), shared.sum(), np.bincount(np.bincount(key//4)[np.bincount(key//4)>0])[1:]))

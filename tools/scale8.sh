@@ -18,9 +18,9 @@ PY
 )
 echo "scale8: $NG GPU(s) visible, running up to $MAXG" | tee "$OUT/README.txt"
 # before anything is timed: the real librccl with real peers, G = 2 / 4 / 8, C4's and C5's payloads, bit-identical to one engine
-# (tests/test_gpu_rccl_multigpu.py; skipped on a 1-GPU box).  A failure here makes every number below meaningless: say so and stop.
+# (tests/test_zz_gpu_rccl_multigpu.py; skipped on a 1-GPU box).  A failure here makes every number below meaningless: say so and stop.
 if [ "$NG" -ge 2 ]; then
-  timeout 3000 python -m pytest tests/test_gpu_rccl_multigpu.py -m gpu -x -q -s > "$OUT/rccl_multigpu_tests.log" 2>&1 \
+  timeout 3000 python -m pytest tests/test_zz_gpu_rccl_multigpu.py -m gpu -x -q -s > "$OUT/rccl_multigpu_tests.log" 2>&1 \
     || { echo "FAILED: real-RCCL parity (see $OUT/rccl_multigpu_tests.log); not timing anything"; tail -30 "$OUT/rccl_multigpu_tests.log"; exit 1; }
   grep "real RCCL" "$OUT/rccl_multigpu_tests.log"
 fi
