@@ -530,7 +530,7 @@ def main():
                    "n_ranks_seen": ranks_seen, "boundary_swaps_per_rank": boundary, "ms_per_step_per_rank": per_rank_ms,
                    "chains_per_gpu": n_chains, "waves_per_simd": n_chains / 1024.0,      # one wave per replica, 1024 SIMDs per GPU
                    "transport_library": transport_library, "boundary_exchange": boundary_exchange, "parallelism_invariant": invariant,
-                   "env_overrides": {k: os.environ[k] for k in ("PTE_LIB", "PTE_RCCL_LIB", "PTE_BENCH_BACKEND") if os.environ.get(k)},
+                   "env_overrides": {k: os.environ[k] for k in ("PTE_RCCL_LIB", "PTE_BENCH_BACKEND") if os.environ.get(k)},      # ($PTE_LIB is not read any more: the bench runs the in-tree library)
                    **({"same_device_test_run": "every rank on HIP device 0 with an RCCL stand-in ($PTE_RCCL_LIB=%s): exercises the "
                        "multi-rank code path, NOT a measurement" % os.environ.get("PTE_RCCL_LIB", "")} if args.same_device else {})},
         "round_trip_rate": rt["round_trip_rate"] if rt else None, "n_round_trips": rt["n_round_trips"] if rt else None,

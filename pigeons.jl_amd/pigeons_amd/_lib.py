@@ -8,7 +8,15 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(_HERE)                       # .../pigeons.jl_amd
-LIB_PATH = os.environ.get("PTE_LIB") or os.path.join(PKG_ROOT, "lib", "libpte.so")   # PTE_LIB: a tuning build (tools/)
+LIB_PATH = os.path.join(PKG_ROOT, "lib", "libpte.so")   # the product never reads the environment for this (round 5: $PTE_LIB used to swap the whole
+                                                         # library silently); a development tool selects a tuning build with use_library(path)
+
+
+def use_library(path):
+    """tools/ only (tools/_variant.py: PTE_LIB=<path> python tools/<tool>.py): load this build of libpte instead of the in-tree product
+    library, from the next load() on.  Call it before the first engine is made."""
+    global LIB_PATH
+    LIB_PATH = path
 
 TARGET_MVN_SCALED_PRECISION, TARGET_TEST_SWAPPER, TARGET_FUNNEL, TARGET_ISING = 0, 1, 2, 3
 EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA, EXPLORER_ISING_METROPOLIS, EXPLORER_MALA = 0, 1, 2, 3, 4, 5

@@ -88,5 +88,5 @@ def test_single_gpu_line_has_the_contract_fields():
     assert len(x) == 6 and all(c["ms_per_scan"] > 0 and c["kernel"] for c in x) and x[0]["config"].startswith("C1 ")
     assert {c["kernel"] for c in x} >= {"k_explore_slice8", "k_explore_slice8_lds10k", "k_explore_automala", "k_explore_ising_spec"}
     assert j["config"]["chains_per_gpu"] == 1024 and j["config"]["waves_per_simd"] == 1.0
-    assert j["config"]["env_overrides"] == {k: os.environ[k] for k in ("PTE_LIB", "PTE_RCCL_LIB", "PTE_BENCH_BACKEND") if os.environ.get(k)}
+    assert j["config"]["env_overrides"] == {k: os.environ[k] for k in ("PTE_RCCL_LIB", "PTE_BENCH_BACKEND") if os.environ.get(k)}
     assert j["config"]["transport_library"] is None and j["config"]["parallelism_invariant"] is None       # (single GPU)

@@ -131,3 +131,20 @@ def test_inputs_defaults_match_reference(P):
     t = P.toy_mvn_target(7)
     assert (t.precision0, t.precision1, t.dim) == (1.0, 10.0, 7)
     assert math.isclose(P.analytic_lognormalization(t), -3.5 * math.log(10.0))
+
+
+def test_the_product_ignores_pte_lib(monkeypatch):
+    """$PTE_LIB used to swap the whole product library silently: the package does not read it any more; a development
+    tool opts in through tools/_variant.py -> _lib.use_library(path)."""
+    import importlib, os, sys
+    monkeypatch.setenv("PTE_LIB", "/nonexistent/libpte_other.so")
+    from pigeons_amd import _lib
+    importlib.reload(_lib)
+    try:
+        assert _lib.LIB_PATH.endswith(os.path.join("pigeons.jl_amd", "lib", "libpte.so"))
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+        import _variant
+        assert _variant.apply() == "/nonexistent/libpte_other.so" and _lib.LIB_PATH == "/nonexistent/libpte_other.so"
+    finally:
+        monkeypatch.delenv("PTE_LIB")
+        importlib.reload(_lib)

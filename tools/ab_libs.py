@@ -4,7 +4,8 @@ import hashlib, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
 import hashlib, os, sys
-sys.path[:0] = [%r, os.path.join(%r, "pigeons.jl_amd")]
+sys.path[:0] = [%r, os.path.join(%r, "pigeons.jl_amd"), os.path.join(%r, "tools")]
+import _variant; _variant.apply()          # PTE_LIB of the child's environment (tools/_variant.py)
 import numpy as np, pigeons_amd as P
 h = hashlib.sha256()
 for (N, d), expl, seed in [((96, 1024), P.SliceSampler(), 1), ((16, 4096), P.SliceSampler(), 2), ((40, 1024), P.SliceSampler(w=1.0), 3), ((64, 4096), P.ToyExplorer(), 4), ((33, 1024), P.ToyExplorer(), 5)]:
@@ -14,7 +15,7 @@ for (N, d), expl, seed in [((96, 1024), P.SliceSampler(), 1), ((16, 4096), P.Sli
         h.update(red.index_process.tobytes()); h.update(red.swap_acceptance_pr[0].tobytes())
     for a in pt.replicas.states(): h.update(np.ascontiguousarray(a).tobytes())
 print(h.hexdigest())
-''' % (ROOT, ROOT)
+''' % (ROOT, ROOT, ROOT)
 out = []
 for v in sys.argv[1:3]:
     env = dict(os.environ, PTE_LIB=os.path.join(ROOT, "build_variants", "libpte_v_%s.so" % v))

@@ -4,6 +4,7 @@ then ms / scan of the metric workload and of the C4 shard."""
 import os, sys, time, itertools
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pigeons.jl_amd")]
+import _variant; _variant.apply()          # PTE_LIB=<path>: a tuning build (tools/_variant.py); the product itself never reads the variable
 import numpy as np, torch
 import pigeons_amd as P
 from pigeons_amd.pt import reduce_recorders, adapt

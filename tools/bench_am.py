@@ -2,6 +2,7 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pigeons.jl_amd")]
+import _variant; _variant.apply()          # PTE_LIB=<path>: a tuning build (tools/_variant.py); the product itself never reads the variable
 import torch, pigeons_amd as P
 from pigeons_amd.pt import reduce_recorders, adapt
 d, N = int(os.environ.get("BV_D", "128")), int(os.environ.get("BV_N", "1024"))

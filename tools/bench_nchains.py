@@ -4,6 +4,7 @@ is the 1-GPU anchor of the north star's strong-scaling clause (8192 chains, 1 ->
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pigeons.jl_amd")]
+import _variant; _variant.apply()          # PTE_LIB=<path>: a tuning build (tools/_variant.py); the product itself never reads the variable
 import pigeons_amd as P
 for d, Ns, scans in ((1024, (256, 512, 1024, 2048, 4096, 8192), 16), (4096, (1024, 2048, 4096, 8192), 6)):
     for N in Ns:

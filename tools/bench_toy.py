@@ -2,6 +2,7 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pigeons.jl_amd")]
+import _variant; _variant.apply()          # PTE_LIB=<path>: a tuning build (tools/_variant.py); the product itself never reads the variable
 import pigeons_amd as P
 for N, d in ((8192, 4096), (8192, 1024), (1024, 1024))[:1 if os.environ.get('PTE_BENCH_TOY_ONLY_FIRST') else 3]:
     pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, record=[P.log_sum_ratio], n_rounds=20, show_report=False))

@@ -2,6 +2,7 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pigeons.jl_amd")]
+import _variant; _variant.apply()          # PTE_LIB=<path>: a tuning build (tools/_variant.py); the product itself never reads the variable
 import pigeons_amd as P
 d = int(os.environ.get("BT_D", "4096"))
 for N in (1024, 2048, 4096, 8192, 16384, 32768):
