@@ -25,7 +25,11 @@ def record(N, d, scans):
     _lib.LIB_PATH = os.path.join(ROOT, "build_variants", "libpte_v_waves.so")
     import pigeons_amd as P
     from pigeons_amd.pt import reduce_recorders, adapt
-    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=10, explorer=P.SliceSampler(), show_report=False, record=[P.round_trip, P.log_sum_ratio]))
+    if os.environ.get("PS_ISING"):               # PS_ISING=1: the C5 shape (d = lattice side)
+        pt = P.PT(P.Inputs(target=P.IsingLogPotential(1.0, d), n_chains=N, n_rounds=10, show_report=False, record=[P.round_trip, P.log_sum_ratio]), debug_kernel=_lib.KERNEL_TWO_LAUNCHES)
+    else:
+        pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=10, explorer=P.SliceSampler(), show_report=False, record=[P.round_trip, P.log_sum_ratio]),
+                  debug_kernel=_lib.KERNEL_TWO_LAUNCHES)       # (the stamps are the per-scan kernel's)
     e = pt.replicas
     e.run_scans(1, 8); adapt(pt, reduce_recorders(pt))
     e.run_scans(1, 8); adapt(pt, reduce_recorders(pt))
@@ -70,7 +74,7 @@ def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     d = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     scans = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-    cache = os.path.join(ROOT, "gpurun_out", "r05_wave_durations_N%d_d%d.npz" % (N, d))
+    cache = os.path.join(ROOT, "gpurun_out", "r05_wave_durations_%sN%d_d%d.npz" % ("ising_" if os.environ.get("PS_ISING") else "", N, d))
     if os.path.exists(cache) and os.environ.get("PAIRSYNC_REPLAY"):
         z = np.load(cache); T, span = z["T"], z["span"]
     else:
@@ -78,7 +82,7 @@ def main():
         os.makedirs(os.path.dirname(cache), exist_ok=True)
         np.savez_compressed(cache, T=T, span=span)
     S = T.shape[0]
-    print("toy_mvn_target(%d), %d chains, SliceSampler: %d scans recorded (PTE_PROFILE_WAVES build)" % (d, N, S))
+    print("%s, %d chains: %d scans recorded (PTE_PROFILE_WAVES build)" % (("Ising %d x %d, IsingMetropolis(3)" % (d, d)) if os.environ.get("PS_ISING") else "toy_mvn_target(%d), SliceSampler" % d, N, S))
     print("  per scan: launch span mean %.1f us; wave duration mean %.1f, max-over-waves mean %.1f us (mean wave = %.3f of the span)"
           % (span.mean(), T.mean(), T.max(axis=1).mean(), T.mean() / span.mean()))
     per_chain = T.mean(axis=0)
