@@ -232,6 +232,11 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
 #ifdef NRM_MEASURE_NO_EVENTS       // measurement builds only (wrong samples): every event taken as an accepted wedge, no exp
         if (in_pass) { e_pos = L.ev[wv][lane >> 1]; e_kind = 1; e_delta = 1; }
         if (false) {
+#elif defined(NRM_MEASURE_SHARED_EVENTS)   // measurement builds only (wrong samples): the upper bound of "one event pass per workgroup" -- wave 0 runs
+        // the pass (for its own events: a real handler would hold all four waves'), the others take theirs as accepted wedges, two barriers per chunk
+        __syncthreads();
+        if (wv != 0 && in_pass) { e_pos = L.ev[wv][lane >> 1]; e_kind = 1; e_delta = 1; }
+        if (wv == 0 && in_pass) {
 #else
         if (in_pass) {
 #endif
@@ -282,6 +287,9 @@ __device__ __forceinline__ double normals_row(NormalsLds &L, SeqRng &r, double *
 #ifdef NRM_PROF
         asm volatile("" :: "v"(e_kind), "v"(e_pos));
         const unsigned long long pt2 = __builtin_readcyclecounter();
+#endif
+#ifdef NRM_MEASURE_SHARED_EVENTS
+        __syncthreads();
 #endif
         // ---- 3. which events start an attempt (the events are sorted by position): an event does NOT iff the live event before it
         // consumed its position -- a wedge consumes the position right behind it, a tail the 2 x trials behind it
