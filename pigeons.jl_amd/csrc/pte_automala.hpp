@@ -643,8 +643,15 @@ __device__ __forceinline__ void automala_body(EngineDev e, AmParams ap, const in
     record_after_explore(e, cl, c, slot, lane, lp_before, S, l2, l3);
 }
 
+#ifndef PTE_AM_E16_ONE_WAVE
+#define PTE_AM_E16_ONE_WAVE 1
+#endif
 template <int E, int TGT, bool SLICE = false, bool FULL = false>
-__global__ __launch_bounds__(64) void k_explore_automala(EngineDev e, AmParams ap) {
+__global__ __launch_bounds__(64)
+#if PTE_AM_E16_ONE_WAVE
+__attribute__((amdgpu_waves_per_eu(1, (E >= 16 && !SLICE) ? 1 : 8)))      // E = 16 (d > 512): one wave per SIMD may use the whole unified register file -- spills go to AGPRs, not to scratch
+#endif
+void k_explore_automala(EngineDev e, AmParams ap) {
     automala_body<E, TGT, SLICE, FULL>(e, ap, blockIdx.x);
 }
 
