@@ -67,7 +67,14 @@ enum {                                   /* Inputs.record (src/pt/Inputs.jl:57-6
     PTE_RECORD_ONLINE        = 1u << 2,  /* online / _transformed_online (target chain mean, variance)     */
     PTE_RECORD_TRACES        = 1u << 3,  /* traces: [state; log density] of the target chain per scan (src/recorders/recorder.jl:27,39-43; src/pt/pigeons.jl:116-125) */
     PTE_RECORD_TRACES_EXTENDED = 1u << 5, /* with PTE_RECORD_TRACES: inputs.extended_traces, every chain is traced (src/pt/pigeons.jl:116) */
-    PTE_RECORD_ENERGY_AC1    = 1u << 4   /* energy_ac1: per-chain covariance of the log density before / after explore! (recorder.jl:113; pigeons.jl:134-143) */
+    PTE_RECORD_ENERGY_AC1    = 1u << 4,  /* energy_ac1: per-chain covariance of the log density before / after explore! (recorder.jl:113; pigeons.jl:134-143) */
+    PTE_RECORD_REFERENCE_REDUCTION = 1u << 6 /* swap_acceptance_pr / log_sum_ratio reduced the way the reference reduces them instead of by chain-keyed sums on the
+                                              * device: every replica's own Mean (mu += (x - mu) / n, src/recorders/recorders.jl:88-130 over OnlineStats) and LogSum
+                                              * (src/recorders/LogSum.jl:1-24) fitted in scan order, then merged over the binary tree on the replica index
+                                              * (all_reduce_deterministically, src/mpi_utils/Entangler.jl:188-251).  The device logs the two log ratios of every active pair and
+                                              * scan ([max_scans_per_round][n_chains][2] doubles); pte_reduce replays the fits and merges on the host, so the adapted schedule
+                                              * is the reference's to the last bit instead of to 1e-11.  Needs PTE_RECORD_INDEX_PROCESS (who held the lower chain) and
+                                              * world_size == 1.  Off by default: the values agree to ~1e-12 either way, and a round of 1024 x 1024 chain-scans logs 16 MB. */
 };
 
 enum {                                   /* pte_config.debug_kernel: which kernel generation explores (0 = the default)   */

@@ -234,6 +234,8 @@ int reset_recorders(pte_engine *h) {
     HIP_OK(h, hipMemsetAsync(e.eac, 0, sizeof(double) * 5 * N, h->stream));
     HIP_OK(h, hipMemsetAsync(e.eac_n, 0, sizeof(int64_t) * N, h->stream));
     HIP_OK(h, hipMemsetAsync(e.on_n, 0, 2 * sizeof(int64_t), h->stream));
+    if (e.swap_log)     // all-ones words = "this pair was idle at this scan" (no log ratio has that bit pattern: a NaN ratio is ERR_NAN_RATIO)
+        HIP_OK(h, hipMemsetAsync(e.swap_log, 0xFF, sizeof(double) * 2 * (size_t)(h->cfg.max_scans_per_round * h->K), h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));   // `ninf` must outlive the copies
     h->scans_in_round = 0;
     return 0;
@@ -607,6 +609,14 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
         return fail(nullptr, "pte_create: explorer %d is not implemented on the device", cfg->explorer);
     if ((cfg->record_flags & PTE_RECORD_TRACES_EXTENDED) && !(cfg->record_flags & PTE_RECORD_TRACES))
         return fail(nullptr, "pte_create: PTE_RECORD_TRACES_EXTENDED needs PTE_RECORD_TRACES");
+    if (cfg->record_flags & PTE_RECORD_REFERENCE_REDUCTION) {
+        if (!(cfg->record_flags & PTE_RECORD_INDEX_PROCESS))
+            return fail(nullptr, "pte_create: PTE_RECORD_REFERENCE_REDUCTION needs PTE_RECORD_INDEX_PROCESS (the replay asks which replica held the lower chain of a pair)");
+        if (cfg->world_size != 1)
+            return fail(nullptr, "pte_create: PTE_RECORD_REFERENCE_REDUCTION needs world_size == 1 (the log of a sharded engine is not gathered)");
+        if ((double)cfg->max_scans_per_round * (double)(cfg->n_chains + cfg->n_chains_variational) * 16.0 > 64e9)
+            return fail(nullptr, "pte_create: the swap log (max_scans_per_round x chains x 2 doubles) would exceed 64 GB");
+    }
     {   // debug_kernel: 0 = the default kernel of the explorer; anything else must exist in THIS build (no silent fall-through)
         const int dk = cfg->debug_kernel & ~PTE_KERNEL_TWO_LAUNCHES;      // (the flag bit chooses the scan loop's form, not the kernel generation)
         const bool slice = cfg->explorer == PTE_EXPLORER_SLICE || cfg->explorer2 == PTE_EXPLORER_SLICE;
@@ -693,6 +703,8 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.index_process, (size_t)ipcap, false);
     rc |= dev_alloc(h, &e.ip_replica, (size_t)ipcap, false);
     rc |= dev_alloc(h, &e.error, 4);
+    e.swap_log = nullptr;
+    if (cfg->record_flags & PTE_RECORD_REFERENCE_REDUCTION) rc |= dev_alloc(h, &e.swap_log, (size_t)(cfg->max_scans_per_round * K * 2), false);
     if (rc) return bail(1);
     e.nhp = h->d_nhp; e.sd = h->d_sd; e.nprec = h->d_nprec; e.beta = h->d_beta;
     e.ref_nhp = -0.5 * cfg->target_params[0];
@@ -867,6 +879,99 @@ int pte_run_scans(pte_engine *h, int64_t first_scan, int64_t n_scans) {
     return rc;
 }
 
+// PTE_RECORD_REFERENCE_REDUCTION: swap_acceptance_pr and log_sum_ratio reduced as the reference reduces them.  There every REPLICA owns a
+// GroupBy(chain pair => Mean) and a GroupBy(chain pair => LogSum) and fits them when it holds the lower chain of a swapping pair
+// (record_swap_stats!, src/swap/pair_swapper.jl:59-66); at the end of a round the replicas' recorders are merged over the binary tree on the
+// replica index -- spacing 1, 2, 4, ...: replica i takes replica i + s (all_reduce_deterministically, src/mpi_utils/Entangler.jl:188-251;
+// reduce_recorders!, src/recorders/recorders.jl:88-130).  Mean: fit mu += (1/n)(x - mu), merge mu += (n_b/n)(mu_b - mu) (OnlineStats);
+// LogSum: fit / merge by logaddexp (src/recorders/LogSum.jl:1-24; LogExpFunctions: max + log1p(exp(-|x - y|)), exp(-|x - y|) below -37).
+// The device keeps chain-keyed sums (one replica's worth of arithmetic per pair: no order to agree on, 1e-12 away); here the same numbers are
+// rebuilt from the log {lr of the lower chain's replica, lr of the upper's} per scan and pair, and index_process says whose recorder each fit went to.
+static inline double host_logaddexp(double x, double y) {
+    const double delta = (x == y) ? 0.0 : std::fabs(x - y);
+    const double m = (x > y) ? x : y, nd = -delta;
+    return m + ((nd <= -37.0) ? std::exp(nd) : std::log1p(std::exp(nd)));
+}
+static int reference_reduce(pte_engine *h, Snapshot &s) {
+    const int64_t N = h->K, T = s.n_scans;
+    if (T == 0) return 0;
+    std::vector<double> log((size_t)(T * N * 2));
+    HIP_OK(h, hipMemcpy(log.data(), h->dev.swap_log, sizeof(double) * log.size(), hipMemcpyDeviceToHost));
+    std::vector<int32_t> holder((size_t)(T * N));                         // [scan][chain] -> replica
+    for (int64_t t = 0; t < T; ++t)
+        for (int64_t slot = 0; slot < N; ++slot) holder[(size_t)(t * N + s.ip_chain[(size_t)(t * N + slot)])] = s.ip_replica[(size_t)(t * N + slot)];
+    struct Rec { double mu; int64_t n; double up, dn; };                  // one replica's Mean and two LogSums of ONE pair (their counts move together)
+    std::vector<Rec> rec((size_t)N);
+    for (int64_t c = 0; c + 1 < N; ++c) {
+        for (auto &r : rec) r = Rec{0.0, 0, -INFINITY, -INFINITY};
+        for (int64_t t = 0; t < T; ++t) {
+            const double *w = &log[(size_t)((t * N + c) * 2)];
+            uint64_t bits; std::memcpy(&bits, w, 8);
+            if (bits == ~0ull) continue;                                  // the pair was idle on this scan's graph
+            Rec &r = rec[(size_t)holder[(size_t)(t * N + c)]];
+            const double ex = std::exp(w[0] + w[1]), alpha = ex < 1.0 ? ex : 1.0;    // swap_acceptance_probability, pair_swapper.jl:88
+            r.n += 1;
+            r.mu = r.mu + (1.0 / (double)r.n) * (alpha - r.mu);
+            r.up = host_logaddexp(r.up, w[0]);
+            r.dn = host_logaddexp(r.dn, w[1]);
+        }
+        for (int64_t sp = 1; sp < N; sp *= 2)
+            for (int64_t i = 0; i + sp < N; i += 2 * sp) {
+                Rec &a = rec[(size_t)i]; const Rec &b = rec[(size_t)(i + sp)];
+                if (b.n == 0) continue;                                   // GroupBy merge: the key is absent on that side
+                if (a.n == 0) { a = b; continue; }
+                a.n += b.n;
+                a.mu = a.mu + ((double)b.n / (double)a.n) * (b.mu - a.mu);
+                a.up = host_logaddexp(a.up, b.up);
+                a.dn = host_logaddexp(a.dn, b.dn);
+            }
+        if (rec[0].n != s.swap_n[(size_t)c])
+            return fail(h, "PTE_RECORD_REFERENCE_REDUCTION: the log holds %lld swaps of pair %lld, the device counted %lld", (long long)rec[0].n, (long long)c, (long long)s.swap_n[(size_t)c]);
+        if (rec[0].n > 0) { s.swap_mean[(size_t)c] = rec[0].mu; s.lsr_up[(size_t)c] = rec[0].up; s.lsr_dn[(size_t)c] = rec[0].dn; }
+    }
+    // :online / :_transformed_online the same way, when the round's traces are there to replay them from (PTE_RECORD_TRACES: the target
+    // chains' [state; log density] per scan are exactly what explore! fits, src/pt/pigeons.jl:116-131): every replica's Mean and Variance
+    // (OnlineStats: mu += g (x - mu), s2 += g ((x - mu_new)(x - mu_old) - s2), g = 1/n; merge with g = n_b / n) per coordinate, tree-merged.
+    // Without traces the device's Welford sums of the target chains stand (one chain's worth of arithmetic: ~1e-16 relative away).
+    const uint32_t f = h->cfg.record_flags;
+    if ((f & PTE_RECORD_ONLINE) && (f & PTE_RECORD_TRACES) && s.traces_n == T) {
+        const EngineDev &e = h->dev;
+        const int64_t d = h->d, ntgt = (e.tgt_b != e.tgt_a) ? 2 : 1, rows = (f & PTE_RECORD_TRACES_EXTENDED) ? N : ntgt;
+        const int64_t tgt[2] = {e.tgt_a, e.tgt_b};
+        struct On { double mu, s2; int64_t n; };
+        std::vector<On> on((size_t)N);
+        for (int64_t i = 0; i <= d; ++i) {
+            for (auto &r : on) r = On{0.0, 0.0, 0};
+            for (int64_t t = 0; t < T; ++t)
+                for (int64_t w = 0; w < ntgt; ++w) {
+                    const int64_t row = (f & PTE_RECORD_TRACES_EXTENDED) ? tgt[w] : w;
+                    const double x = s.traces[(size_t)(((t * rows) + row) * (d + 1) + i)];
+                    On &r = on[(size_t)holder[(size_t)(t * N + tgt[w])]];
+                    const double mu0 = r.mu;
+                    r.n += 1;
+                    const double g = 1.0 / (double)r.n;
+                    r.mu = r.mu + g * (x - r.mu);
+                    r.s2 = r.s2 + g * ((x - r.mu) * (x - mu0) - r.s2);
+                }
+            for (int64_t sp = 1; sp < N; sp *= 2)
+                for (int64_t j = 0; j + sp < N; j += 2 * sp) {
+                    On &a = on[(size_t)j]; const On &b = on[(size_t)(j + sp)];
+                    if (b.n == 0) continue;
+                    if (a.n == 0) { a = b; continue; }
+                    a.n += b.n;
+                    const double g = (double)b.n / (double)a.n, delta = b.mu - a.mu;
+                    a.s2 = (a.s2 + g * (b.s2 - a.s2)) + delta * delta * g * (1.0 - g);
+                    a.mu = a.mu + g * (b.mu - a.mu);
+                }
+            if (on[0].n != s.on_n)
+                return fail(h, "PTE_RECORD_REFERENCE_REDUCTION: the traces hold %lld target-chain samples, the device counted %lld", (long long)on[0].n, (long long)s.on_n);
+            s.on_mean[(size_t)i] = on[0].mu;
+            s.on_var[(size_t)i] = on[0].n > 1 ? on[0].s2 * ((double)on[0].n / (double)(on[0].n - 1)) : 1.0;
+        }
+    }
+    return 0;
+}
+
 int pte_reduce(pte_engine *h) {
     if (!h) return 1;
     HIP_OK(h, hipSetDevice(h->cfg.device));
@@ -932,6 +1037,7 @@ int pte_reduce(pte_engine *h) {
         }
         s.on_mean.resize(d + 1);
     }
+    if (e.swap_log && reference_reduce(h, s)) return 1;
     for (int64_t i = 0; i < K; ++i)       // cor(CovMatrix)[1,2]: the Bessel factors cancel
         if (s.eac_n[i] > 1) s.eac_cor[i] = s.eac_raw[5 * i + 3] / std::sqrt(s.eac_raw[5 * i + 2] * s.eac_raw[5 * i + 4]);
     for (int64_t i = 0; i < K; ++i) {

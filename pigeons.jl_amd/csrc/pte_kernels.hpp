@@ -47,6 +47,7 @@ struct EngineDev {
     // recorders (reset every round)
     double *swap_sum;  int64_t *swap_n;                    // [N-1] swap_acceptance_pr
     double *lsr_up;    double *lsr_dn;   int64_t *lsr_n;   // [N-1] log_sum_ratio (c,c+1) / (c+1,c)
+    double *swap_log;                                      // null, or [max_scans][N][2] {log ratio of the lower chain's replica, of the upper's} per scan and pair, at the lower chain (PTE_RECORD_REFERENCE_REDUCTION)
     int64_t *rt_state; int64_t *rt_restarts; int64_t *rt_trips;   // [slot] round_trip
     double *expl_acc_sum; int64_t *expl_acc_n;             // [chain] explorer_acceptance_pr
     double *expl_steps_sum; int64_t *expl_steps_n;         // [chain] explorer_n_steps
@@ -527,6 +528,7 @@ __global__ __launch_bounds__(256) void k_swap(EngineDev e, int even, int64_t sca
                 e.lsr_up[c] = dev_logaddexp(e.lsr_up[c], lr);
                 e.lsr_dn[c] = dev_logaddexp(e.lsr_dn[c], lr_p);
                 e.lsr_n[c] += 1;
+                if (e.swap_log) { double *w = e.swap_log + (scan_idx * N + c) * 2; w[0] = lr; w[1] = lr_p; }
             }
         }
         if (do_swap) { e.chain_of_slot[slot] = (int32_t)pc; e.slot_of_chain[pc] = slot; }
@@ -665,6 +667,7 @@ __device__ __forceinline__ int swap_handshake(const EngineDev &e, const ScanLoop
             e.lsr_up[c] = dev_logaddexp(e.lsr_up[c], lr);
             e.lsr_dn[c] = dev_logaddexp(e.lsr_dn[c], lr_p);
             e.lsr_n[c] += 1;
+            if (e.swap_log) { double *w = e.swap_log + (scan_idx * N + c) * 2; w[0] = lr; w[1] = lr_p; }
         }
 #endif
     }

@@ -38,6 +38,7 @@ const TARGET_MVN, TARGET_TEST_SWAPPER, TARGET_FUNNEL, TARGET_ISING = Int32(0), I
 const EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA, EXPLORER_ISING, EXPLORER_MALA = Int32.((0, 1, 2, 3, 4, 5))
 const RECORD_ROUND_TRIP, RECORD_INDEX_PROCESS, RECORD_ONLINE, RECORD_TRACES, RECORD_ENERGY_AC1, RECORD_TRACES_EXTENDED =
     UInt32.((1, 2, 4, 8, 16, 32))
+const RECORD_REFERENCE_REDUCTION = UInt32(64)   # swap recorders reduced by per-replica Mean / LogSum fits + tree merge, replayed in pte_reduce (include/pte.h)
 
 # mirror of `pte_config` -- field order and types must match; pte_create checks struct_size and abi_version, so a layout
 # mismatch fails loudly instead of corrupting memory
@@ -144,6 +145,8 @@ function record_flags(inputs::Inputs, shared::Shared)
     (:traces in names && inputs.extended_traces) && (f |= RECORD_TRACES_EXTENDED)
     :energy_ac1 in names && (f |= RECORD_ENERGY_AC1)
     :disk in names && error("the disk recorder is not served by the device path (SURVEY.md 2: out of scope)")
+    # ENV["PIGEONS_MI355X_REFERENCE_REDUCTION"] = "1": the reference's own reduction arithmetic for the swap recorders (one engine only)
+    get(ENV, "PIGEONS_MI355X_REFERENCE_REDUCTION", "0") == "1" && (f |= RECORD_REFERENCE_REDUCTION | RECORD_INDEX_PROCESS)
     return f
 end
 

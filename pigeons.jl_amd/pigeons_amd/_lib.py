@@ -21,6 +21,7 @@ def use_library(path):
 TARGET_MVN_SCALED_PRECISION, TARGET_TEST_SWAPPER, TARGET_FUNNEL, TARGET_ISING = 0, 1, 2, 3
 EXPLORER_NONE, EXPLORER_TOY, EXPLORER_SLICE, EXPLORER_AUTOMALA, EXPLORER_ISING_METROPOLIS, EXPLORER_MALA = 0, 1, 2, 3, 4, 5
 RECORD_ROUND_TRIP, RECORD_INDEX_PROCESS, RECORD_ONLINE, RECORD_TRACES, RECORD_ENERGY_AC1, RECORD_TRACES_EXTENDED = 1, 2, 4, 8, 16, 32
+RECORD_REFERENCE_REDUCTION = 64      # swap_acceptance_pr / log_sum_ratio by per-replica Mean / LogSum fits and the binary-tree merge, replayed in pte_reduce (include/pte.h)
 ABI_VERSION = 2
 KERNEL_DEFAULT, KERNEL_SLICE_SEQUENTIAL, KERNEL_ISING_BITS, KERNEL_ISING_BYTES = 0, 1, 101, 102
 KERNEL_TWO_LAUNCHES = 0x1000            # flag: explore + swap launched per scan even where pte_run_scans could be one kernel (pte_scan_loop_name)

@@ -10,10 +10,14 @@ TP.RTOL = float(os.environ.get("LP_RTOL", "1e-6"))        # the north star's tol
 from pigeons_amd import _lib
 N, d, R = 1024, 1024, 4
 pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=R, explorer=P.SliceSampler(), seed=11, record=[P.round_trip, P.index_process, P.log_sum_ratio, P.online], show_report=False),
-          debug_kernel=_lib.KERNEL_TWO_LAUNCHES if os.environ.get("LP_TWO") else 0)
+          debug_kernel=_lib.KERNEL_TWO_LAUNCHES if os.environ.get("LP_TWO") else 0, reference_reduction=bool(os.environ.get("LP_REFRED")))
 ref = O.OraclePT(n_chains=N, dim=d, seed=11, record_online=1, explorer=O.EXPLORER_SLICE, n_threads=max(1, len(os.sched_getaffinity(0))))
 print(pt.replicas.scan_loop_name() or "two launches per scan", "rtol", TP.RTOL)
 t = time.time()
+if os.environ.get("LP_REFRED"):              # LP_REFRED=1: PTE_RECORD_REFERENCE_REDUCTION -- swap recorders, schedule, stepping stone EQUAL to the oracle's, not close
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_reference_reduction import _exact_round
+    _check_round = lambda P, pt, ref: (_exact_round(P, pt, ref), np.testing.assert_array_equal(pt.replicas.states()[0], ref.states()[0]))
 for r in range(R):
     _check_round(P, pt, ref)
     print("round", r + 1, "ok (fused scan loop vs oracle: index process, chains, RNG counters, recorders, schedule, states)", round(time.time() - t), "s", flush=True)
