@@ -73,8 +73,9 @@ enum {                                   /* Inputs.record (src/pt/Inputs.jl:57-6
                                               * (src/recorders/LogSum.jl:1-24) fitted in scan order, then merged over the binary tree on the replica index
                                               * (all_reduce_deterministically, src/mpi_utils/Entangler.jl:188-251).  The device logs the two log ratios of every active pair and
                                               * scan ([max_scans_per_round][n_chains][2] doubles); pte_reduce replays the fits and merges on the host, so the adapted schedule
-                                              * is the reference's to the last bit instead of to 1e-11.  Needs PTE_RECORD_INDEX_PROCESS (who held the lower chain) and
-                                              * world_size == 1.  Off by default: the values agree to ~1e-12 either way, and a round of 1024 x 1024 chain-scans logs 16 MB. */
+                                              * is the reference's to the last bit instead of to 1e-11.  Needs PTE_RECORD_INDEX_PROCESS (who held the lower chain).  A
+                                              * chain-shard replays the pairs whose lower chain it owns (log and index rows are local; the tree runs over the global
+                                              * replica index).  With PTE_RECORD_TRACES the online statistics are rebuilt the same way.  Off by default: the values agree to ~1e-12 either way, and a round of 1024 x 1024 chain-scans logs 16 MB. */
 };
 
 enum {                                   /* pte_config.debug_kernel: which kernel generation explores (0 = the default)   */

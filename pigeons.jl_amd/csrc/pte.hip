@@ -612,8 +612,6 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     if (cfg->record_flags & PTE_RECORD_REFERENCE_REDUCTION) {
         if (!(cfg->record_flags & PTE_RECORD_INDEX_PROCESS))
             return fail(nullptr, "pte_create: PTE_RECORD_REFERENCE_REDUCTION needs PTE_RECORD_INDEX_PROCESS (the replay asks which replica held the lower chain of a pair)");
-        if (cfg->world_size != 1)
-            return fail(nullptr, "pte_create: PTE_RECORD_REFERENCE_REDUCTION needs world_size == 1 (the log of a sharded engine is not gathered)");
         if ((double)cfg->max_scans_per_round * (double)(cfg->n_chains + cfg->n_chains_variational) * 16.0 > 64e9)
             return fail(nullptr, "pte_create: the swap log (max_scans_per_round x chains x 2 doubles) would exceed 64 GB");
     }
@@ -893,22 +891,24 @@ static inline double host_logaddexp(double x, double y) {
     return m + ((nd <= -37.0) ? std::exp(nd) : std::log1p(std::exp(nd)));
 }
 static int reference_reduce(pte_engine *h, Snapshot &s) {
-    const int64_t N = h->K, T = s.n_scans;
+    // A chain-shard replays ITS pairs (those whose lower chain it owns) by itself: the log and index_process rows of a pair live with its lower
+    // chain, and the merge tree runs over the GLOBAL replica index whichever shard a replica visited.
+    const int64_t K = h->K, N = h->N, c0 = h->c0, T = s.n_scans, pairs = (c0 + K < N) ? K : K - 1;
     if (T == 0) return 0;
-    std::vector<double> log((size_t)(T * N * 2));
+    std::vector<double> log((size_t)(T * K * 2));
     HIP_OK(h, hipMemcpy(log.data(), h->dev.swap_log, sizeof(double) * log.size(), hipMemcpyDeviceToHost));
-    std::vector<int32_t> holder((size_t)(T * N));                         // [scan][chain] -> replica
+    std::vector<int32_t> holder((size_t)(T * K));                         // [scan][local chain] -> replica
     for (int64_t t = 0; t < T; ++t)
-        for (int64_t slot = 0; slot < N; ++slot) holder[(size_t)(t * N + s.ip_chain[(size_t)(t * N + slot)])] = s.ip_replica[(size_t)(t * N + slot)];
+        for (int64_t slot = 0; slot < K; ++slot) holder[(size_t)(t * K + (s.ip_chain[(size_t)(t * K + slot)] - c0))] = s.ip_replica[(size_t)(t * K + slot)];
     struct Rec { double mu; int64_t n; double up, dn; };                  // one replica's Mean and two LogSums of ONE pair (their counts move together)
     std::vector<Rec> rec((size_t)N);
-    for (int64_t c = 0; c + 1 < N; ++c) {
+    for (int64_t c = 0; c < pairs; ++c) {
         for (auto &r : rec) r = Rec{0.0, 0, -INFINITY, -INFINITY};
         for (int64_t t = 0; t < T; ++t) {
-            const double *w = &log[(size_t)((t * N + c) * 2)];
+            const double *w = &log[(size_t)((t * K + c) * 2)];
             uint64_t bits; std::memcpy(&bits, w, 8);
             if (bits == ~0ull) continue;                                  // the pair was idle on this scan's graph
-            Rec &r = rec[(size_t)holder[(size_t)(t * N + c)]];
+            Rec &r = rec[(size_t)holder[(size_t)(t * K + c)]];
             const double ex = std::exp(w[0] + w[1]), alpha = ex < 1.0 ? ex : 1.0;    // swap_acceptance_probability, pair_swapper.jl:88
             r.n += 1;
             r.mu = r.mu + (1.0 / (double)r.n) * (alpha - r.mu);
@@ -926,7 +926,7 @@ static int reference_reduce(pte_engine *h, Snapshot &s) {
                 a.dn = host_logaddexp(a.dn, b.dn);
             }
         if (rec[0].n != s.swap_n[(size_t)c])
-            return fail(h, "PTE_RECORD_REFERENCE_REDUCTION: the log holds %lld swaps of pair %lld, the device counted %lld", (long long)rec[0].n, (long long)c, (long long)s.swap_n[(size_t)c]);
+            return fail(h, "PTE_RECORD_REFERENCE_REDUCTION: the log holds %lld swaps of pair %lld, the device counted %lld", (long long)rec[0].n, (long long)(c0 + c), (long long)s.swap_n[(size_t)c]);
         if (rec[0].n > 0) { s.swap_mean[(size_t)c] = rec[0].mu; s.lsr_up[(size_t)c] = rec[0].up; s.lsr_dn[(size_t)c] = rec[0].dn; }
     }
     // :online / :_transformed_online the same way, when the round's traces are there to replay them from (PTE_RECORD_TRACES: the target
@@ -934,10 +934,11 @@ static int reference_reduce(pte_engine *h, Snapshot &s) {
     // (OnlineStats: mu += g (x - mu), s2 += g ((x - mu_new)(x - mu_old) - s2), g = 1/n; merge with g = n_b / n) per coordinate, tree-merged.
     // Without traces the device's Welford sums of the target chains stand (one chain's worth of arithmetic: ~1e-16 relative away).
     const uint32_t f = h->cfg.record_flags;
-    if ((f & PTE_RECORD_ONLINE) && (f & PTE_RECORD_TRACES) && s.traces_n == T) {
-        const EngineDev &e = h->dev;
-        const int64_t d = h->d, ntgt = (e.tgt_b != e.tgt_a) ? 2 : 1, rows = (f & PTE_RECORD_TRACES_EXTENDED) ? N : ntgt;
-        const int64_t tgt[2] = {e.tgt_a, e.tgt_b};
+    const EngineDev &e = h->dev;
+    const bool owns_targets = e.tgt_a >= c0 && e.tgt_a < c0 + K && e.tgt_b >= c0 && e.tgt_b < c0 + K;
+    if ((f & PTE_RECORD_ONLINE) && (f & PTE_RECORD_TRACES) && s.traces_n == T && owns_targets) {
+        const int64_t d = h->d, ntgt = (e.tgt_b != e.tgt_a) ? 2 : 1, rows = (f & PTE_RECORD_TRACES_EXTENDED) ? K : ntgt;
+        const int64_t tgt[2] = {e.tgt_a - c0, e.tgt_b - c0};
         struct On { double mu, s2; int64_t n; };
         std::vector<On> on((size_t)N);
         for (int64_t i = 0; i <= d; ++i) {
@@ -946,7 +947,7 @@ static int reference_reduce(pte_engine *h, Snapshot &s) {
                 for (int64_t w = 0; w < ntgt; ++w) {
                     const int64_t row = (f & PTE_RECORD_TRACES_EXTENDED) ? tgt[w] : w;
                     const double x = s.traces[(size_t)(((t * rows) + row) * (d + 1) + i)];
-                    On &r = on[(size_t)holder[(size_t)(t * N + tgt[w])]];
+                    On &r = on[(size_t)holder[(size_t)(t * K + tgt[w])]];
                     const double mu0 = r.mu;
                     r.n += 1;
                     const double g = 1.0 / (double)r.n;
@@ -1176,7 +1177,7 @@ int pte_swap_finish(pte_engine *h, int64_t scan, const double *nbr_stats, int32_
     HIP_OK(h, hipMemsetAsync(h->dev.bflag, 0, 2 * sizeof(int32_t), h->stream));
     const unsigned block = 256, grid = (unsigned)((K + block - 1) / block);
     time_begin(h, 1);
-    hipLaunchKernelGGL(k_swap_decide, dim3(grid), dim3(block), 0, h->stream, h->dev, even);
+    hipLaunchKernelGGL(k_swap_decide, dim3(grid), dim3(block), 0, h->stream, h->dev, even, h->scans_in_round);
     time_end(h);
     HIP_OK(h, hipGetLastError());
     h->slot_cur ^= 1;                                   // the decide kernel wrote the new chain -> slot map
@@ -1255,7 +1256,7 @@ int pte_shard_scan_finish(pte_engine *h, int64_t scan) {
     time_begin(h, 1);
     hipLaunchKernelGGL(k_boundary_stats_in, dim3(1), dim3(64), 0, h->stream, h->dev, (int)active[0], (int)active[1],
                        (const double *)h->msg_recv[0], (const double *)h->msg_recv[1]);
-    hipLaunchKernelGGL(k_swap_decide, dim3(grid), dim3(block), 0, h->stream, h->dev, even);
+    hipLaunchKernelGGL(k_swap_decide, dim3(grid), dim3(block), 0, h->stream, h->dev, even, h->scans_in_round);
     h->slot_cur ^= 1;                                   // the decide kernel wrote the new chain -> slot map
     h->dev.slot_of_chain = h->slot_map[h->slot_cur];
     h->dev.slot_of_chain_alt = h->slot_map[h->slot_cur ^ 1];

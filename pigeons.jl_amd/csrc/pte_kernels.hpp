@@ -47,7 +47,7 @@ struct EngineDev {
     // recorders (reset every round)
     double *swap_sum;  int64_t *swap_n;                    // [N-1] swap_acceptance_pr
     double *lsr_up;    double *lsr_dn;   int64_t *lsr_n;   // [N-1] log_sum_ratio (c,c+1) / (c+1,c)
-    double *swap_log;                                      // null, or [max_scans][N][2] {log ratio of the lower chain's replica, of the upper's} per scan and pair, at the lower chain (PTE_RECORD_REFERENCE_REDUCTION)
+    double *swap_log;                                      // null, or [max_scans][K][2] {log ratio of the lower chain's replica, of the upper's} per scan and pair, at the lower chain (PTE_RECORD_REFERENCE_REDUCTION)
     int64_t *rt_state; int64_t *rt_restarts; int64_t *rt_trips;   // [slot] round_trip
     double *expl_acc_sum; int64_t *expl_acc_n;             // [chain] explorer_acceptance_pr
     double *expl_steps_sum; int64_t *expl_steps_n;         // [chain] explorer_n_steps
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256) void k_swap_stats(EngineDev e, int even, int64
 #endif
 
 #ifndef PTE_TU_LANGEVIN
-__global__ __launch_bounds__(256) void k_swap_decide(EngineDev e, int even) {
+__global__ __launch_bounds__(256) void k_swap_decide(EngineDev e, int even, int64_t scan_idx) {
     const int64_t cl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (cl >= e.K) return;
     const int64_t N = e.N, c = e.c0 + cl;
@@ -733,6 +733,7 @@ __global__ __launch_bounds__(256) void k_swap_decide(EngineDev e, int even) {
                 e.lsr_up[cl] = dev_logaddexp(e.lsr_up[cl], lr);
                 e.lsr_dn[cl] = dev_logaddexp(e.lsr_dn[cl], lr_p);
                 e.lsr_n[cl] += 1;
+                if (e.swap_log) { double *w = e.swap_log + (scan_idx * e.K + cl) * 2; w[0] = lr; w[1] = lr_p; }
             }
         }
         if (do_swap) {

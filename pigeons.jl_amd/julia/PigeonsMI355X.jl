@@ -145,7 +145,7 @@ function record_flags(inputs::Inputs, shared::Shared)
     (:traces in names && inputs.extended_traces) && (f |= RECORD_TRACES_EXTENDED)
     :energy_ac1 in names && (f |= RECORD_ENERGY_AC1)
     :disk in names && error("the disk recorder is not served by the device path (SURVEY.md 2: out of scope)")
-    # ENV["PIGEONS_MI355X_REFERENCE_REDUCTION"] = "1": the reference's own reduction arithmetic for the swap recorders (one engine only)
+    # ENV["PIGEONS_MI355X_REFERENCE_REDUCTION"] = "1": the reference's own reduction arithmetic for the swap recorders (and :online when :traces is recorded)
     get(ENV, "PIGEONS_MI355X_REFERENCE_REDUCTION", "0") == "1" && (f |= RECORD_REFERENCE_REDUCTION | RECORD_INDEX_PROCESS)
     return f
 end

@@ -308,7 +308,7 @@ class PT:
     debug_kernel           pte_config.debug_kernel (0 = the default kernel)
     reference_reduction    PTE_RECORD_REFERENCE_REDUCTION: swap_acceptance_pr / log_sum_ratio from per-replica Mean / LogSum fits merged over
                            the replica-index tree (src/recorders/recorders.jl:88-130, src/mpi_utils/Entangler.jl:188-251) instead of the
-                           device's chain-keyed sums -- the adapted schedule then equals the oracle's bit for bit.  One engine only.
+                           device's chain-keyed sums -- the adapted schedule then equals the oracle's bit for bit (chain-shards replay their own pairs).
     """
 
     def __init__(self, inputs: Inputs, n_shards=1, rank=0, world=1, dist_device=None, engine_factory=None, device_messages=False,
@@ -344,8 +344,6 @@ class PT:
         if "energy_ac1" in names:
             flags |= _lib.RECORD_ENERGY_AC1
         if reference_reduction:
-            if n_shards != 1 or world != 1:
-                raise NotImplementedError("reference_reduction replays ONE engine's swap log (n_shards = world = 1)")
             flags |= _lib.RECORD_REFERENCE_REDUCTION | _lib.RECORD_INDEX_PROCESS
         kw = dict(device=inputs.device, n_chains=N, n_chains_variational=n_var, seed=inputs.seed, record_flags=flags,
                   max_scans_per_round=2 ** inputs.n_rounds)

@@ -63,6 +63,38 @@ def test_recorders_and_schedule_equal_the_oracle_bit_for_bit(P, kind, N, d, roun
     assert np.array_equal(chain, cr) and np.array_equal(rng, rr)
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(device_messages=True), dict(transport="group")])
+@pytest.mark.parametrize("kind,N,d,G,rounds", [("slice", 8, 40, 2, 7), ("slice", 12, 100, 4, 6), ("toy", 9, 5, 3, 8), ("slice", 16, 30, 8, 6), ("toy", 6, 3, 6, 7)])
+def test_chain_shards_replay_their_own_pairs(P, kind, N, d, G, rounds, kw):
+    """a chain-shard holds the log and the index_process rows of the pairs whose lower chain it owns -- everything the replay of those pairs
+    needs; the merge tree runs over the GLOBAL replica index, so G shards give the oracle's numbers exactly like one engine does"""
+    exp = {"toy": P.ToyExplorer(), "slice": P.SliceSampler()}[kind]
+    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=exp, seed=4, show_report=False,
+                       record=[P.round_trip, P.index_process, P.log_sum_ratio, P.online, P.traces]), n_shards=G, reference_reduction=True, **kw)
+    ref = O.OraclePT(n_chains=N, dim=d, seed=4, explorer={"toy": O.EXPLORER_TOY, "slice": O.EXPLORER_SLICE}[kind], record_online=1, record_traces=1)
+    for _ in range(rounds):
+        red = _exact_round(P, pt, ref)
+        if np.array_equal(red.traces, ref.traces()):
+            assert np.array_equal(red.online[0], ref.online()[0]) and np.array_equal(red.online[1], ref.online()[1])
+    assert pt.shards.n_boundary_swaps > 0
+
+
+@pytest.mark.parametrize("kind,nf,nv,d,rounds", [("slice", 6, 5, 4, 8), ("slice", 4, 4, 70, 6), ("toy", 3, 7, 9, 7)])
+def test_two_legs(P, kind, nf, nv, d, rounds):
+    """StabilizedPT (two legs sharing the target, src/tempering/StabilizedPT.jl): two target chains fit the same online statistics, the
+    pair between the legs never swaps; both barriers and the concatenated schedule equal the oracle's"""
+    ex = {"slice": P.SliceSampler(), "toy": P.ToyExplorer()}[kind]
+    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=nf, n_chains_variational=nv, variational=None, n_rounds=rounds, explorer=ex,
+                       record=[P.round_trip, P.index_process, P.log_sum_ratio, P.online, P.traces], show_report=False), reference_reduction=True)
+    ref = O.OraclePT(n_chains=nf, n_chains_variational=nv, dim=d, explorer={"slice": O.EXPLORER_SLICE, "toy": O.EXPLORER_TOY}[kind],
+                     record_online=1, record_traces=1)
+    for _ in range(rounds):
+        red = _exact_round(P, pt, ref)
+        assert P.global_barrier_variational(pt) == ref.global_barrier_variational()
+        if np.array_equal(red.traces, ref.traces()):
+            assert np.array_equal(red.online[0], ref.online()[0]) and np.array_equal(red.online[1], ref.online()[1])
+
+
 def test_ising(P):
     L, N, rounds = 8, 9, 8
     pt = P.PT(P.Inputs(target=P.IsingLogPotential(0.7, L), n_chains=N, n_rounds=rounds, seed=3,
@@ -138,7 +170,3 @@ def test_the_flag_has_its_preconditions(P):
     from pigeons_amd.engine import Engine
     with pytest.raises(Exception, match="INDEX_PROCESS"):
         Engine(n_chains=4, dim=3, record_flags=_lib.RECORD_REFERENCE_REDUCTION, explorer=_lib.EXPLORER_SLICE)
-    with pytest.raises(Exception, match="world_size == 1"):
-        Engine(n_chains=4, dim=3, record_flags=_lib.RECORD_REFERENCE_REDUCTION | _lib.RECORD_INDEX_PROCESS, explorer=_lib.EXPLORER_SLICE, world_size=2, rank=0)
-    with pytest.raises(NotImplementedError):
-        P.PT(P.Inputs(target=P.toy_mvn_target(3), n_chains=4, n_rounds=3, explorer=P.SliceSampler(), show_report=False), n_shards=2, reference_reduction=True)
