@@ -45,6 +45,10 @@ def parse_args():
     ap.add_argument("--dim", type=int, default=None)
     ap.add_argument("--chains", type=int, default=None, help="chains per GPU (weak) / in total (strong)")
     ap.add_argument("--explorer", default="slice", choices=["slice", "toy"])
+    ap.add_argument("--prepare", type=int, default=64,
+                    help="untimed preparation of the synthetic input before --warmup: this many scans from the initial states, reduce + schedule "
+                         "adaptation, this many scans again (the states of a run in progress: a schedule change is followed by ~20 scans "
+                         "that cost 2 %% more, tools/bench_equilibration.py).  0 = the order of rounds 1-5: warm-up, then the adaptation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed hbm_kernels / extra_configs blocks")
     ap.add_argument("--same-device", action="store_true",
@@ -389,10 +393,17 @@ def main():
     # warmup: W scans (first RCCL transfers open their connections here: at least two even scans per boundary whatever --warmup says),
     # then one reduce + schedule adaptation
     W_run = max(W, 4) if world > 1 else W
+    prep = max(args.prepare, 0)
+    if prep:                            # the synthetic input = the replicas of a run in progress (untimed, declared in config.preparation): the reduce +
+        runner.run_scans(1, prep)       # adaptation every round ends with happens HERE, and the states settle under the adapted ladder, so
+        adapt(pt, reduce_recorders(pt)) # that the K timed scans are scans of the steady loop and not the ~20-scan transient after a schedule
+        runner.run_scans(1, prep)       # change (+0.3 ms in total at the metric shape whatever ran before: tools/bench_equilibration.py)
     eng.timing_reset(True)              # the swap kernels' duration is taken during the warmup scans ...
     runner.run_scans(1, W_run)
     sw_ms, sw_n = eng.timing(1)
-    adapt(pt, reduce_recorders(pt))
+    red = reduce_recorders(pt)          # (empties the recorders: lp_evals below counts the passes from here on)
+    if not prep:
+        adapt(pt, red)
 
     eng.timing_reset(2)                 # ... the timed region carries HIP events around the dominant (explore) kernel only
     sync()
@@ -529,6 +540,9 @@ def main():
                    "sharding": ("chains sharded over %d GPUs, boundary replicas only; transport: %s" % (world, transport)) if world > 1 else "single GPU",
                    "n_ranks_seen": ranks_seen, "boundary_swaps_per_rank": boundary, "ms_per_step_per_rank": per_rank_ms,
                    "chains_per_gpu": n_chains, "waves_per_simd": n_chains / 1024.0,      # one wave per replica, 1024 SIMDs per GPU
+                   "preparation": ("untimed, before --warmup: %d scans from the initial states, reduce + schedule adaptation, %d scans under the adapted "
+                                   "schedule; then %d warm-up scans, then the %d timed scans (no adaptation in between)" % (prep, prep, W_run, K)) if prep else
+                                  "none: %d warm-up scans from the initial states, reduce + schedule adaptation, then the %d timed scans" % (W_run, K),
                    "transport_library": transport_library, "boundary_exchange": boundary_exchange, "parallelism_invariant": invariant,
                    "env_overrides": {k: os.environ[k] for k in ("PTE_RCCL_LIB", "PTE_BENCH_BACKEND") if os.environ.get(k)},      # ($PTE_LIB is not read any more: the bench runs the in-tree library)
                    **({"same_device_test_run": "every rank on HIP device 0 with an RCCL stand-in ($PTE_RCCL_LIB=%s): exercises the "

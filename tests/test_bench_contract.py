@@ -75,6 +75,7 @@ def test_single_gpu_line_has_the_contract_fields():
     lr = j["long_run"]
     assert lr["steps"] == 256 and lr["value"] > 0 and abs(lr["value"] - 1024 * 256 / (lr["ms_per_step"] * 256e-3)) < 1e-6 * lr["value"]
     assert 0.6 * j["ms_per_step"] < lr["ms_per_step"] < 1.25 * j["ms_per_step"]      # (the 3-scan region carries its ramp: it may be the slower one)
+    assert "64 scans from the initial states" in j["config"]["preparation"]          # the untimed preparation of the input is declared in the line
     assert r["traffic"] is None or str(r["traffic_source"]).startswith("static: profiles/")
     assert r["instruction_issue"] is None or str(r["instruction_issue"]["source"]).startswith("static: profiles/")
     h = j["hbm_kernels"]
