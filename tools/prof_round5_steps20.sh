@@ -7,7 +7,7 @@ O = sys.argv[1]
 con = sqlite3.connect(os.path.join(O, "stats_results.db"))
 rows = con.execute("select name, (end-start)/1e6 from kernels where name like '%k_scans%' order by start").fetchall()
 print("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --round-trip-rounds 0   (the driver's step counts)")
-print("# dispatches of the fused scan loop, in order: warm-up (5 scans), TIMED region (20 scans, HIP events riding on the launch), the same 20 scans without events, long_run (256 scans)")
+print("# dispatches of the fused scan loop, in order: preparation (64 scans, then 64 after the adaptation), warm-up (5 scans), TIMED region (20 scans, HIP events riding on the launch), the same 20 scans without events, long_run (256 scans)")
 for n, ms in rows: print("%-90s %10.3f ms" % (n[:90], ms))
 j = json.loads([l for l in open(os.path.join(O, "stats.log")) if l.startswith("{")][-1]); r = j["roofline"]
 print("# bench line of the same process: roofline.kernel %s, avg_launch_ms %.3f over %d launch(es) of %d scans = %.4f ms per scan; ms_per_step %.4f; long_run %.4f ms per step" % (r["kernel"], r["avg_launch_ms"], r["launches"], r["scans_per_launch"], r["avg_launch_ms_per_scan"], j["ms_per_step"], j["long_run"]["ms_per_step"]))
