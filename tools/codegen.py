@@ -68,12 +68,11 @@ def compile_units(extra=(), force=False):
 
     with ThreadPoolExecutor(len(jobs)) as ex:
         out = list(ex.map(run, jobs))
-    # prune: an assembly file is ~60 MB; keep what this call produced and anything younger than two hours
-    import time
+    # prune: an assembly file is 15-40 MB (and build/ travels with every gpurun snapshot); keep what this call produced, nothing else
     keep = set(os.path.basename(stem) for _, _, stem in jobs)
     for f in os.listdir(CACHE):
         full = os.path.join(CACHE, f)
-        if f.rsplit(".", 1)[0] not in keep and time.time() - os.path.getmtime(full) > 7200:
+        if not extra and f.rsplit(".", 1)[0] not in keep:
             try:
                 os.remove(full)
             except OSError:

@@ -8,7 +8,7 @@ from test_gpu_parity import _check_round
 TP.RTOL = float(os.environ.get("LP_RTOL", "1e-6"))        # the north star's tolerance for floating-point recorders (the suite asserts 1e-9 over rounds 1-2;
                                                            # log_sum_ratio of round 3 differs by 7e-9 in 2 % of the pairs: ocml vs glibc exp / log1p under cancellation)
 from pigeons_amd import _lib
-N, d, R = 1024, 1024, 4
+N, d, R = 1024, 1024, int(os.environ.get("LP_ROUNDS", "4"))
 pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=R, explorer=P.SliceSampler(), seed=11, record=[P.round_trip, P.index_process, P.log_sum_ratio, P.online], show_report=False),
           debug_kernel=_lib.KERNEL_TWO_LAUNCHES if os.environ.get("LP_TWO") else 0, reference_reduction=bool(os.environ.get("LP_REFRED")))
 ref = O.OraclePT(n_chains=N, dim=d, seed=11, record_online=1, explorer=O.EXPLORER_SLICE, n_threads=max(1, len(os.sched_getaffinity(0))))
