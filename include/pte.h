@@ -86,7 +86,11 @@ enum {                                   /* pte_config.debug_kernel: which kerne
     PTE_KERNEL_ISING_BYTES      = 102,   /* IsingMetropolis: scalar byte-lattice sweep (the kernel of base_length % 32 != 0) */
     /* a FLAG, or-ed to any of the above: pte_run_scans launches explore and swap per scan (the loop of rounds 1-4) even where the whole
      * call could run as ONE kernel with pairwise swap hand-shakes (pte_scan_loop_name); for A/B runs and the parity tests of the two forms */
-    PTE_KERNEL_TWO_LAUNCHES     = 0x1000
+    PTE_KERNEL_TWO_LAUNCHES     = 0x1000,
+    /* a FLAG: where the one-kernel scan loop has a form with several consecutive chains per workgroup (their pairs shake hands through
+     * LDS; pte_scan_loop_name ends in "_wg"), use the form with one chain per workgroup instead; bit-identical, for A/B runs and tests */
+    PTE_KERNEL_SCAN_LOOP_ONE_CHAIN = 0x2000,
+    PTE_KERNEL_FLAG_BITS        = 0x3000
 };
 
 /* Mirrors the fields of `Inputs` (src/pt/Inputs.jl:9-102) and of the explorer
@@ -273,7 +277,9 @@ const char *pte_kernel_name(const pte_engine *h);
  * per scan (explore, swap); otherwise the ONE kernel that runs all the scans of a call (e.g. "k_scans_slice8": workgroup c holds chain c,
  * the DEO swap is a hand-shake between the two waves of a pair, no launch boundary and no grid-wide barrier per scan).  Chosen when one GPU
  * holds the whole ladder, every workgroup is resident at once, the explorer has such a kernel and pte_config.debug_kernel does not carry
- * PTE_KERNEL_TWO_LAUNCHES; results are bit-identical either way.  pte_timing_get(kernel = 4) times these launches. */
+ * PTE_KERNEL_TWO_LAUNCHES; results are bit-identical either way.  A name ending in "_wg" (AutoMALA / MALA) is the form with several
+ * consecutive chains per workgroup, whose inner pairs shake hands through LDS (PTE_KERNEL_SCAN_LOOP_ONE_CHAIN selects the other form).
+ * pte_timing_get(kernel = 4) times these launches. */
 const char *pte_scan_loop_name(const pte_engine *h);
 int pte_scan_loop_info(const pte_engine *h, int64_t *resident_limit, int64_t *timed_launches, int64_t *timed_scans);
 

@@ -104,6 +104,8 @@ struct pte_engine {
     int64_t t_scans4 = 0;             // scans inside the timed launches of kind 4
     // one launch per pte_run_scans (k_scans_*: pte_kernels.hpp "ScanLoop"): pairwise hand-shakes instead of a launch boundary per scan
     bool fused_allowed = true;        // pte_config.debug_kernel & PTE_KERNEL_TWO_LAUNCHES clears it
+    bool fused_wg_allowed = true;     // ... & PTE_KERNEL_SCAN_LOOP_ONE_CHAIN clears it
+    int fused_wg = 1;                 // chains (waves) per workgroup of the scan-loop kernel this engine launches
     int64_t fused_limit = -1;         // workgroups of the scan-loop kernel the device holds at once (-1: not asked yet, 0: not available)
     unsigned long long *hs_flag = nullptr; double *hs_pub = nullptr;   // [K], [K][2][4]
     unsigned long long hs_epoch = 0;  // epochs handed out so far (monotone: the flags are never reset)
@@ -443,21 +445,21 @@ int run_scans_sharded(pte_engine *h, int64_t first_scan, int64_t n_scans);
 // generation, no Compose, every workgroup of the call resident at once (the hand-shakes spin: a workgroup that waits for a GPU slot
 // would be waited for) -- asked of the runtime for the very instantiation that is launched -- and the shapes at which it was measured to win.
 #ifdef PTE_DEV_FEW_NLU
-#define OCC_NLU_M(nlu, KERNEL, MM, out)                                                                        \
+#define OCC_NLU_MB(nlu, KERNEL, MM, BLOCK, out)                                                                        \
     switch (nlu) {                                                                                              \
-    case 4: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<4, MM>, 64, 0); break;                   \
-    default: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<6, MM>, 64, 0); break;                  \
+    case 4: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<4, MM>, BLOCK, 0); break;                   \
+    default: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<6, MM>, BLOCK, 0); break;                  \
     }
 #else
-#define OCC_NLU_M(nlu, KERNEL, MM, out)                                                                        \
+#define OCC_NLU_MB(nlu, KERNEL, MM, BLOCK, out)                                                                        \
     switch (nlu) {                                                                                              \
-    case 0: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<0, MM>, 64, 0); break;                   \
-    case 1: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<1, MM>, 64, 0); break;                   \
-    case 2: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<2, MM>, 64, 0); break;                   \
-    case 3: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<3, MM>, 64, 0); break;                   \
-    case 4: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<4, MM>, 64, 0); break;                   \
-    case 5: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<5, MM>, 64, 0); break;                   \
-    default: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<6, MM>, 64, 0); break;                  \
+    case 0: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<0, MM>, BLOCK, 0); break;                   \
+    case 1: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<1, MM>, BLOCK, 0); break;                   \
+    case 2: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<2, MM>, BLOCK, 0); break;                   \
+    case 3: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<3, MM>, BLOCK, 0); break;                   \
+    case 4: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<4, MM>, BLOCK, 0); break;                   \
+    case 5: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<5, MM>, BLOCK, 0); break;                   \
+    default: hipOccupancyMaxActiveBlocksPerMultiprocessor(&out, KERNEL<6, MM>, BLOCK, 0); break;                  \
     }
 #endif
 
@@ -471,6 +473,7 @@ int fused_slice_variant(const pte_engine *h) {
 // and rows of at most 16 KB -- 1024 chains: d = 512 x1.055, d = 1024 x1.03, d = 2048 x1.00, d = 4096 x0.99 (every release writes back the
 // XCD's dirty L2 lines, and 128 waves x 32 KB of freshly written rows are all of it); 2048 chains at d = 1024 x0.91 (a wave that polls shares
 // its SIMD with a wave that works, and the fences cost per resident workgroup).  Elsewhere the loop of rounds 1-4 stays.
+#define OCC_NLU_M(nlu, KERNEL, MM, out) OCC_NLU_MB(nlu, KERNEL, MM, 64, out)
 // 0: not a fused kind; 1: SliceSampler on the MVN path (k_scans_slice8*); 2: AutoMALA / MALA on the MVN or funnel path (k_scans_automala)
 int fused_kind(const pte_engine *h) {
     if (h->cfg.explorer2 != PTE_EXPLORER_NONE) return 0;
@@ -499,6 +502,15 @@ bool fused_scans_eligible(pte_engine *h, int64_t n_scans) {
         (void)hipGetLastError();
         // every workgroup resident (the hand-shakes spin) AND at most one wave per SIMD (4 SIMDs per CU)
         h->fused_limit = (int64_t)std::min(per_cu, 4) * (int64_t)cus;
+        // the form with several consecutive chains per workgroup (intra-workgroup pairs shake hands through LDS), where the build has it and
+        // the chains fit with one such workgroup per compute unit
+        h->fused_wg = 1;
+        if (kind == 2 && h->fused_wg_allowed) {
+            const int wgn = langevin_scan_wg();
+            const int per_cu_wg = wgn > 1 && wgn <= 4 ? langevin_scan_loop_blocks_per_cu(langevin_E(h), h->cfg.target == PTE_TARGET_FUNNEL ? TGT_FUNNEL : TGT_MVN, h->d == 64 * (int64_t)langevin_E(h), wgn) : 0;
+            (void)hipGetLastError();
+            if (per_cu_wg >= 1 && h->K <= (int64_t)wgn * cus) { h->fused_wg = wgn; h->fused_limit = std::max(h->fused_limit, (int64_t)wgn * cus); }
+        }
         if (h->fused_limit > 0 && h->K <= h->fused_limit && !h->hs_flag) {
             if (dev_alloc(h, &h->hs_flag, (size_t)h->K) || dev_alloc(h, &h->hs_pub, (size_t)h->K * 8)) { h->fused_limit = 0; h->err.clear(); }
             else hipStreamSynchronize(h->stream);
@@ -527,7 +539,7 @@ int run_scans_fused(pte_engine *h, int64_t first_scan, int64_t n_scans) {
         ap.use_mh = 1;
         ap.ref_prec = h->cfg.target_params[0]; ap.log3 = std::log(3.0);
         const int E = langevin_E(h);
-        LangevinLaunch L{E, h->cfg.target == PTE_TARGET_FUNNEL ? TGT_FUNNEL : TGT_MVN, false, h->d == 64 * (int64_t)E, (unsigned)N, h->stream, false, nullptr, nullptr, &sl};
+        LangevinLaunch L{E, h->cfg.target == PTE_TARGET_FUNNEL ? TGT_FUNNEL : TGT_MVN, false, h->d == 64 * (int64_t)E, (unsigned)N, h->stream, false, nullptr, nullptr, &sl, h->fused_wg};
         if (h->ev_open && h->ev_ext && !h->ev_ext_done) { L.ext = true; L.ev_a = h->events.back().a; L.ev_b = h->events.back().b; h->ev_ext_done = true; }
         if (langevin_launch(L, h->dev, ap)) { time_end(h); return fail(h, "this build holds no fused Langevin-family kernel"); }
     }
@@ -594,7 +606,7 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
         return fail(nullptr, "pte_create: the funnel path is implemented for AutoMALA / MALA / SliceSampler (and Compose of them); use the reference CPU path");
     if ((uses_grad || funnel) && (cfg->dim < 1 || cfg->dim > 1024))
         return fail(nullptr, "pte_create: AutoMALA / MALA (and every explorer of the funnel path) keep the replica in registers, dim must be in 1..1024 (got %lld)", (long long)cfg->dim);
-    if (funnel && (cfg->debug_kernel & ~PTE_KERNEL_TWO_LAUNCHES) != 0)
+    if (funnel && (cfg->debug_kernel & ~PTE_KERNEL_FLAG_BITS) != 0)
         return fail(nullptr, "pte_create: debug_kernel %d is not available on the funnel path (one register-resident kernel serves it)", cfg->debug_kernel);
     if (cfg->explorer2 != PTE_EXPLORER_NONE) {           // Compose(first, second)
         auto composable = [&](int k) { return k == PTE_EXPLORER_SLICE || grad_based(k); };
@@ -616,7 +628,7 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
             return fail(nullptr, "pte_create: the swap log (max_scans_per_round x chains x 2 doubles) would exceed 64 GB");
     }
     {   // debug_kernel: 0 = the default kernel of the explorer; anything else must exist in THIS build (no silent fall-through)
-        const int dk = cfg->debug_kernel & ~PTE_KERNEL_TWO_LAUNCHES;      // (the flag bit chooses the scan loop's form, not the kernel generation)
+        const int dk = cfg->debug_kernel & ~PTE_KERNEL_FLAG_BITS;      // (the flag bit chooses the scan loop's form, not the kernel generation)
         const bool slice = cfg->explorer == PTE_EXPLORER_SLICE || cfg->explorer2 == PTE_EXPLORER_SLICE;
         bool ok = dk == 0 || (slice && dk == PTE_KERNEL_SLICE_SEQUENTIAL) || (ising && dk == PTE_KERNEL_ISING_BYTES);
 #ifdef PTE_TEST_KERNELS
@@ -647,8 +659,9 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     const int64_t B = (d + 63) / 64;
     h->nlu = next_pow2_log(B > 0 ? B : 1);
     // pte_config.debug_kernel (validated above): which kernel generation explores; never read from the environment
-    const int dk_kernel = cfg->debug_kernel & ~PTE_KERNEL_TWO_LAUNCHES;
+    const int dk_kernel = cfg->debug_kernel & ~PTE_KERNEL_FLAG_BITS;
     h->fused_allowed = (cfg->debug_kernel & PTE_KERNEL_TWO_LAUNCHES) == 0;
+    h->fused_wg_allowed = (cfg->debug_kernel & PTE_KERNEL_SCAN_LOOP_ONE_CHAIN) == 0;
     if (cfg->explorer == PTE_EXPLORER_SLICE || cfg->explorer2 == PTE_EXPLORER_SLICE) h->slice_impl = dk_kernel == 0 ? 8 : dk_kernel;
     if (cfg->explorer == PTE_EXPLORER_ISING_METROPOLIS) h->ising_impl = dk_kernel == PTE_KERNEL_ISING_BITS ? 1 : (dk_kernel == PTE_KERNEL_ISING_BYTES ? 2 : 0);
     EngineDev &e = h->dev;
@@ -1536,7 +1549,7 @@ const char *pte_scan_loop_name(const pte_engine *hc) {
     if (!h) return "";
     hipSetDevice(h->cfg.device);
     if (!fused_scans_eligible(h, 1)) return "";
-    if (fused_kind(h) == 2) return "k_scans_automala";
+    if (fused_kind(h) == 2) return h->fused_wg > 1 ? "k_scans_automala_wg" : "k_scans_automala";
     return fused_slice_variant(h) == 0 ? "k_scans_slice8" : "k_scans_slice8_generic";
 }
 int pte_scan_loop_info(const pte_engine *hc, int64_t *resident_limit, int64_t *timed_launches, int64_t *timed_scans) {

@@ -256,7 +256,9 @@ struct AmTarget {
 // kernel 2.5 % SLOWER -- it is not applied there).
 __device__ __forceinline__ int64_t am_chain_of_workgroup(int64_t K, int64_t wg) { return (K % PTE_AM_PERMUTE) ? (wg * PTE_AM_PERMUTE) % K : wg; }
 
-template <int E, int TGT, bool SLICE = false, bool FULL = false>
+// DIRECT (the scan loop with several chains per workgroup, k_scans_automala_wg): `wg` IS the local chain, and the table staging ends in a
+// wave-level wait instead of a workgroup barrier -- every wave writes all the (identical) entries itself, so it only has to see its own stores
+template <int E, int TGT, bool SLICE = false, bool FULL = false, bool DIRECT = false>
 __device__ __forceinline__ void automala_body(EngineDev e, AmParams ap, const int64_t wg) {      // wg: blockIdx.x
     constexpr int NLU = (E == 1 ? 0 : E == 2 ? 1 : E == 4 ? 2 : E == 8 ? 3 : 4);
     const int lane = lane_id();
@@ -266,9 +268,10 @@ __device__ __forceinline__ void automala_body(EngineDev e, AmParams ap, const in
     __shared__ double s_fi[256];
     if (!SLICE) {
         for (int i = lane; i < 256; i += 64) { s_wi[i] = ZIG_WI[i]; s_ki[i] = ZIG_KI[i]; s_fi[i] = ZIG_FI[i]; }
-        __syncthreads();
+        if constexpr (DIRECT) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
     }
-    const int64_t cl = am_chain_of_workgroup(e.K, wg);
+    const int64_t cl = DIRECT ? wg : am_chain_of_workgroup(e.K, wg);
     if (cl >= e.K) return;
     const int64_t c = e.c0 + cl;
     const int slot = e.slot_of_chain[cl];
@@ -683,6 +686,49 @@ __global__ __launch_bounds__(64) void k_scans_automala(EngineDev e, AmParams ap,
         if (lane == 0) slot = swap_handshake(e, sl, i, cl, e.slot_of_chain[cl]);
         slot = __builtin_amdgcn_readfirstlane(slot);
         __syncthreads();                                   // ... and lane 0's acquire before every lane's loads of the next one
+        if (slot < 0) return;
+    }
+}
+
+// The same loop with PTE_SCAN_WG consecutive chains per workgroup, one per wave (pte_kernels.hpp, ScanWg): three of four pairs shake hands
+// through LDS.  Workgroup b holds the chain GROUP the XCD-aware dealing gives it (scan_loop_group); the stride permutation of the per-scan
+// kernel does not apply (it would tear the pairs apart).
+#ifndef PTE_SCAN_WG
+#define PTE_SCAN_WG 4
+#endif
+#ifndef PTE_AM_WG_PERMUTE
+#define PTE_AM_WG_PERMUTE 0          // measured at C3: 0.2000 against 0.1979-0.1986 ms per scan -- the XCD-aware dealing of consecutive groups wins
+#endif
+template <int E, int TGT, bool FULL>
+__device__ __attribute__((noinline)) void automala_body_called_direct(const EngineDev &e, const AmParams &ap, const int64_t cl) {
+    automala_body<E, TGT, false, FULL, true>(e, ap, cl);
+}
+template <int E, int TGT, bool FULL>
+__global__ __launch_bounds__(64 * PTE_SCAN_WG) void k_scans_automala_wg(EngineDev e, AmParams ap, ScanLoop sl) {
+    constexpr int NW = PTE_SCAN_WG;
+    __shared__ ScanWg<NW> wg;
+    const int lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (threadIdx.x < NW) wg.flag[threadIdx.x] = sl.epoch0;          // "has published every epoch up to the last call's"
+    __syncthreads();
+#if PTE_AM_WG_PERMUTE       // the per-scan kernel's stride permutation, over the GROUPS: neighbouring groups do similar work (the slow chains sit next to the reference)
+    const int64_t G = (e.K + NW - 1) / NW;
+    const int64_t cl = am_chain_of_workgroup(G, blockIdx.x) * NW + w;
+#else
+    const int64_t cl = scan_loop_group((e.K + NW - 1) / NW) * NW + w;
+#endif
+    if (cl >= e.K) return;
+    for (int64_t i = 0; i < sl.n_scans; ++i) {
+        e.trace_idx = sl.scan_idx0 + i;
+        if (!ap.mala) ap.use_mh = (sl.first_scan + i != 1) ? 1 : 0;
+        automala_body_called_direct<E, TGT, FULL>(e, ap, cl);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // every lane's stores of the explore step are out before lane 0 publishes
+        __builtin_amdgcn_wave_barrier();
+        int slot = 0;
+        if (lane == 0) slot = swap_handshake<NW>(e, sl, i, cl, e.slot_of_chain[cl], &wg);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        asm volatile("" ::: "memory");                                      // (lane 0's acquire precedes the other lanes' loads in program order: one wave)
+        __builtin_amdgcn_wave_barrier();
         if (slot < 0) return;
     }
 }

@@ -28,9 +28,11 @@ struct AmParams {
 // one launch of k_explore_automala<E, target, slice mode, whole blocks>: N workgroups of one wave on `stream`; `ext`: the launch carries
 // the start / stop events (hipExtLaunchKernelGGL: the kernel's own begin and end, see PTE_LAUNCH1 in pte.hip)
 struct LangevinLaunch { int E; int target; bool slice; bool full; unsigned N; hipStream_t stream; bool ext; hipEvent_t ev_a, ev_b;
-                        const ScanLoop *scans = nullptr; };     // scans != nullptr: k_scans_automala, all the scans of a pte_run_scans call in one launch
+                        const ScanLoop *scans = nullptr;        // scans != nullptr: k_scans_automala, all the scans of a pte_run_scans call in one launch
+                        int scan_wg = 1; };                      // ... > 1: k_scans_automala_wg, that many consecutive chains (waves) per workgroup (must equal langevin_scan_wg())
 int langevin_launch(const LangevinLaunch &L, const EngineDev &dev, const AmParams &ap);     // 0, or 1 if this build holds no such kernel
-int langevin_scan_loop_blocks_per_cu(int E, int target, bool full);                          // occupancy of k_scans_automala<E, target, full> (0: not in this build)
+int langevin_scan_loop_blocks_per_cu(int E, int target, bool full, int scan_wg = 1);         // occupancy of k_scans_automala[_wg]<E, target, full> (0: not in this build)
+int langevin_scan_wg();                                                                      // PTE_SCAN_WG of the Langevin translation unit
 void langevin_refresh_funnel_stats(int E, unsigned N, hipStream_t stream, const EngineDev &dev, double log3);      // k_refresh_funnel_stats<E>
 int langevin_set_rng_policy(unsigned policy);                                                // the translation unit's own copy of g_rng_policy (hipError_t as int)
 

@@ -585,6 +585,12 @@ __device__ __forceinline__ int64_t scan_loop_chain(int64_t K) {
     return g * q + (g < r ? g : r) + j;
 }
 
+// ... and which GROUP of consecutive chains, when a workgroup holds several (G groups): the same dealing over the groups
+__device__ __forceinline__ int64_t scan_loop_group(int64_t G) {
+    const int64_t b = blockIdx.x, g = b & 7, j = b >> 3, q = G >> 3, r = G & 7;
+    return g * q + (g < r ? g : r) + j;
+}
+
 __device__ __forceinline__ bool hs_wait(const unsigned long long *p, unsigned long long want) {
     if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
@@ -599,7 +605,23 @@ __device__ __forceinline__ bool hs_wait(const unsigned long long *p, unsigned lo
 
 // lane 0 of the wave that holds chain c (world_size == 1: local index == chain) after the explore step of scan number sl.first_scan + i:
 // swap_stat + the replica's recorders + hand-shake + decision.  Returns the slot chain c holds afterwards, -1 after a time-out.
-__device__ __forceinline__ int swap_handshake(const EngineDev &e, const ScanLoop &sl, int64_t i, int64_t c, int slot) {
+// NW > 1 (round 5, late): a workgroup of the scan loop holds NW CONSECUTIVE chains, one per wave, so NW - 1 of every NW pairs have both
+// waves on ONE compute unit: they shake hands through the workgroup's LDS (`ScanWg`) under workgroup-scope fences -- the waves of a workgroup
+// share their CU's vector L1, nothing has to be written back or invalidated -- and only the pairs that straddle two workgroups pay the
+// agent-scope hand-off below.  Every chain keeps BOTH of its flags (LDS and global) current every scan: the partner of the next scan looks
+// at the one it shares with this chain.
+template <int NW> struct ScanWg { unsigned long long flag[NW]; double pub[NW][2][4]; };
+__device__ __forceinline__ bool hs_wait_lds(unsigned long long *p, unsigned long long want) {
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) return true;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) return true;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) return false;
+    }
+}
+template <int NW = 1>
+__device__ __forceinline__ int swap_handshake(const EngineDev &e, const ScanLoop &sl, int64_t i, int64_t c, int slot, ScanWg<NW> *wg = nullptr) {
     const int64_t N = e.N;
     const int even = ((sl.first_scan + i) % 2 == 0) ? 1 : 0;              // create_swap_graph(::DEO), DEO.jl:12
     const int64_t scan_idx = sl.scan_idx0 + i;
@@ -626,8 +648,30 @@ __device__ __forceinline__ int swap_handshake(const EngineDev &e, const ScanLoop
     }
     if (pc == c) {                                                          // idle on this graph: publish the epoch only (nobody reads this replica before the next scan's hand-shake)
         __hip_atomic_store(&sl.flag[c], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (NW > 1) __hip_atomic_store(&wg->flag[c % NW], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return slot;
     }
+    double lr_p, u_p; int slot_p;
+    bool near = false;
+    if constexpr (NW > 1) near = (pc / NW == c / NW);
+    if (near) {
+        if constexpr (NW > 1) {
+            const int w = (int)(c % NW), pw = (int)(pc % NW), par = (int)(epoch & 1ull);
+            if (!hs_wait_lds(&wg->flag[pw], epoch - 1ull)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
+            __hip_atomic_store(&wg->pub[w][par][0], lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&wg->pub[w][par][1], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&wg->pub[w][par][2], (double)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // this wave's row / statistics stores have reached the L2 (through the L1 both waves share)
+            __hip_atomic_store(&wg->flag[w], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&sl.flag[c], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (for the partner of the next scan, if it lives in another workgroup)
+            if (!hs_wait_lds(&wg->flag[pw], epoch)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            lr_p = __hip_atomic_load(&wg->pub[pw][par][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            u_p = __hip_atomic_load(&wg->pub[pw][par][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            slot_p = (int)__hip_atomic_load(&wg->pub[pw][par][2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    } else {
     double *mine = sl.pub + ((c * 2 + (int64_t)(epoch & 1ull)) * 4);
     if (!hs_wait(&sl.flag[pc], epoch - 1ull)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
     // {log ratio, uniform, slot}: device-coherent (sc1) stores / loads.  Then the hand-off proper, the form MI355X_MICROARCH.md
@@ -646,12 +690,14 @@ __device__ __forceinline__ int swap_handshake(const EngineDev &e, const ScanLoop
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&sl.flag[c], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (NW > 1) __hip_atomic_store(&wg->flag[c % NW], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (for the partner of the next scan: a wave of this workgroup)
     if (!hs_wait(&sl.flag[pc], epoch)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
     const double *theirs = sl.pub + ((pc * 2 + (int64_t)(epoch & 1ull)) * 4);
-    const double lr_p = __hip_atomic_load(&theirs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), u_p = __hip_atomic_load(&theirs[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int slot_p = (int)__hip_atomic_load(&theirs[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lr_p = __hip_atomic_load(&theirs[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); u_p = __hip_atomic_load(&theirs[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    slot_p = (int)__hip_atomic_load(&theirs[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const bool lower = c < pc;
     const double uu = lower ? u : u_p;
     bool do_swap;

@@ -14,8 +14,9 @@ static inline void langevin_launch_one(K kernel, const LangevinLaunch &L, const 
 
 template <typename K>
 static inline void langevin_launch_scans(K kernel, const LangevinLaunch &L, const EngineDev &dev, const AmParams &ap) {
-    if (L.ext) hipExtLaunchKernelGGL(kernel, dim3(L.N), dim3(64), 0, L.stream, L.ev_a, L.ev_b, 0, dev, ap, *L.scans);
-    else hipLaunchKernelGGL(kernel, dim3(L.N), dim3(64), 0, L.stream, dev, ap, *L.scans);
+    const unsigned wg = (unsigned)(L.scan_wg > 1 ? L.scan_wg : 1), grid = (L.N + wg - 1) / wg;
+    if (L.ext) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wg), 0, L.stream, L.ev_a, L.ev_b, 0, dev, ap, *L.scans);
+    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wg), 0, L.stream, dev, ap, *L.scans);
 }
 
 // the fused scan loop exists for the shapes one wave holds comfortably (E <= 8: d <= 512); the d > 512 instantiations spill and stay per scan
@@ -24,12 +25,25 @@ static inline void langevin_launch_scans(K kernel, const LangevinLaunch &L, cons
     else if (target == TGT_FUNNEL) { WHAT((k_scans_automala<EE, TGT_FUNNEL, false>)); }                                          \
     else if (full) { WHAT((k_scans_automala<EE, TGT_MVN, true>)); }                                                              \
     else { WHAT((k_scans_automala<EE, TGT_MVN, false>)); }
+#define AM_SCANS_WG_ONE(EE, WHAT)                                                                                                \
+    if (target == TGT_FUNNEL && full) { WHAT((k_scans_automala_wg<EE, TGT_FUNNEL, true>)); }                                     \
+    else if (target == TGT_FUNNEL) { WHAT((k_scans_automala_wg<EE, TGT_FUNNEL, false>)); }                                       \
+    else if (full) { WHAT((k_scans_automala_wg<EE, TGT_MVN, true>)); }                                                           \
+    else { WHAT((k_scans_automala_wg<EE, TGT_MVN, false>)); }
 
-int langevin_scan_loop_blocks_per_cu(int E, int target, bool full) {
+int langevin_scan_wg() { return PTE_SCAN_WG; }
+int langevin_scan_loop_blocks_per_cu(int E, int target, bool full, int scan_wg) {
 #ifdef PTE_DEV_NO_LANGEVIN
-    (void)E; (void)target; (void)full; return 0;
+    (void)E; (void)target; (void)full; (void)scan_wg; return 0;
 #else
     int n = 0;
+    if (scan_wg > 1) {
+        if (scan_wg != PTE_SCAN_WG) return 0;
+#define AM_OCC(KERNEL) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, KERNEL, 64 * PTE_SCAN_WG, 0)
+        switch (E) { case 1: AM_SCANS_WG_ONE(1, AM_OCC) break; case 2: AM_SCANS_WG_ONE(2, AM_OCC) break; case 4: AM_SCANS_WG_ONE(4, AM_OCC) break; case 8: AM_SCANS_WG_ONE(8, AM_OCC) break; default: return 0; }
+#undef AM_OCC
+        return n;
+    }
 #define AM_OCC(KERNEL) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, KERNEL, 64, 0)
     switch (E) { case 1: AM_SCANS_ONE(1, AM_OCC) break; case 2: AM_SCANS_ONE(2, AM_OCC) break; case 4: AM_SCANS_ONE(4, AM_OCC) break; case 8: AM_SCANS_ONE(8, AM_OCC) break; default: return 0; }
 #undef AM_OCC
@@ -44,6 +58,11 @@ int langevin_launch(const LangevinLaunch &L, const EngineDev &dev, const AmParam
     if (L.scans) {
         const int target = L.target; const bool full = L.full;
 #define AM_GO(KERNEL) langevin_launch_scans(KERNEL, L, dev, ap)
+        if (L.scan_wg > 1) {
+            if (L.scan_wg != PTE_SCAN_WG) return 1;
+            switch (L.E) { case 1: AM_SCANS_WG_ONE(1, AM_GO) break; case 2: AM_SCANS_WG_ONE(2, AM_GO) break; case 4: AM_SCANS_WG_ONE(4, AM_GO) break; case 8: AM_SCANS_WG_ONE(8, AM_GO) break; default: return 1; }
+            return 0;
+        }
         switch (L.E) { case 1: AM_SCANS_ONE(1, AM_GO) break; case 2: AM_SCANS_ONE(2, AM_GO) break; case 4: AM_SCANS_ONE(4, AM_GO) break; case 8: AM_SCANS_ONE(8, AM_GO) break; default: return 1; }
 #undef AM_GO
         return 0;

@@ -24,6 +24,8 @@ RECORD_ROUND_TRIP, RECORD_INDEX_PROCESS, RECORD_ONLINE, RECORD_TRACES, RECORD_EN
 RECORD_REFERENCE_REDUCTION = 64      # swap_acceptance_pr / log_sum_ratio by per-replica Mean / LogSum fits and the binary-tree merge, replayed in pte_reduce (include/pte.h)
 ABI_VERSION = 2
 KERNEL_DEFAULT, KERNEL_SLICE_SEQUENTIAL, KERNEL_ISING_BITS, KERNEL_ISING_BYTES = 0, 1, 101, 102
+KERNEL_SCAN_LOOP_ONE_CHAIN = 0x2000     # flag: the one-kernel scan loop with ONE chain per workgroup even where the form with several (LDS hand-shakes) exists
+KERNEL_FLAG_BITS = 0x3000
 KERNEL_TWO_LAUNCHES = 0x1000            # flag: explore + swap launched per scan even where pte_run_scans could be one kernel (pte_scan_loop_name)
 COMM_ID_BYTES = 128
 RNG_TAIL_LOG1P = 1                      # include/pte_rng_policy.h

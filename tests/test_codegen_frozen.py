@@ -104,6 +104,16 @@ def test_automala_config3_leapfrog_loops(cg):
     assert max(L["v"] for L in inner.values()) >= 400            # the leapfrog bodies are among them (the test looks at the right loops)
 
 
+def test_fused_automala_loops_keep_the_per_scan_allocation(cg):
+    """k_scans_automala / k_scans_automala_wg (C3 runs the second: four chains per workgroup): the body is a CALLED function, so the scan loop's
+    own long-lived values never reach the step-size search loops; no VGPR spill in either kernel, one workgroup of four waves per compute unit"""
+    C, res, _ = cg
+    for k in ("k_scans_automala<2, 2, false>", "k_scans_automala_wg<2, 2, false>"):
+        r = res[k]
+        assert r["spilled_vgpr"] == 0 and r["waves_per_simd"] >= 1 and r["lds_B"] <= 6656, (k, r)
+        assert r["scratch_B_per_lane"] <= 700, (k, r)          # the engine's argument block handed to the called body by reference
+
+
 def test_ising_word_loop(cg):
     """k_explore_ising_spec<false> (C5: 256 x 256): per 32-site word the likely path is 6 blocks (round 3: 12), 204 VALU + 52 scalar + 4 LDS
     instructions, spill-free; no scratch anywhere in the kernel."""

@@ -127,7 +127,7 @@ def test_fused_scan_loop_against_the_oracle_with_split_calls(P):
     np.testing.assert_allclose(x, xr, rtol=1e-12, atol=0)
 
 
-def _run_am(P, N, d, rounds, seed, two_launches, target="mvn", explorer=None, nv=0):
+def _run_am(P, N, d, rounds, seed, two_launches, target="mvn", explorer=None, nv=0, flags=0):
     from pigeons_amd import _lib
     rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.online, P.energy_ac1]
     kw = dict(n_chains=N, n_rounds=rounds, seed=seed, explorer=explorer or P.AutoMALA(), record=rec, show_report=False)
@@ -137,7 +137,7 @@ def _run_am(P, N, d, rounds, seed, two_launches, target="mvn", explorer=None, nv
         kw.update(target=P.toy_mvn_target(d))
     if nv:
         kw.update(n_chains_variational=nv)
-    pt = P.PT(P.Inputs(**kw), debug_kernel=_lib.KERNEL_TWO_LAUNCHES if two_launches else 0)
+    pt = P.PT(P.Inputs(**kw), debug_kernel=(_lib.KERNEL_TWO_LAUNCHES if two_launches else 0) | flags)
     out = []
     for _ in range(rounds):
         assert P.next_round(pt)
@@ -155,17 +155,25 @@ def _run_am(P, N, d, rounds, seed, two_launches, target="mvn", explorer=None, nv
     ("mvn", 5, 512, 3, 3, "automala"),            # E = 8: the largest register layout the fused loop takes
     ("mvn", 5, 64, 5, 4, "mala"),
     ("funnel", 6, 8, 6, 5, "mala"),
+    ("mvn", 13, 20, 7, 6, "automala"),            # three full workgroups of four chains + one wave alone
+    ("mvn", 2, 33, 6, 7, "automala"),             # one pair, one workgroup
+    ("funnel", 37, 16, 6, 8, "automala"),
+    ("mvn", 1, 8, 4, 9, "automala"),              # a single chain: nobody to shake hands with
 ])
 def test_fused_langevin_scan_loop_equals_launch_per_scan(P, target, N, d, rounds, seed, explorer):
-    """AutoMALA / MALA: k_scans_automala (refreshes + pairwise swap hand-shake for all the scans of a call; the `scan != 1` rule of
-    AutoMALA.jl:87,96-102 decided per scan inside the kernel) against the launch-per-scan loop, bit for bit"""
+    """AutoMALA / MALA: the one-kernel scan loops (refreshes + pairwise swap hand-shake for all the scans of a call; the `scan != 1` rule of
+    AutoMALA.jl:87,96-102 decided per scan inside the kernel) against the launch-per-scan loop, bit for bit -- both forms: k_scans_automala_wg
+    (four consecutive chains per workgroup, three of four pairs shake hands through LDS; the default) and k_scans_automala (one chain per
+    workgroup, every pair through the agent-scope hand-off)"""
+    from pigeons_amd import _lib
     ex = (lambda: P.AutoMALA()) if explorer == "automala" else (lambda: P.MALA())
     pa, a = _run_am(P, N, d, rounds, seed, True, target, ex())
     pb, b = _run_am(P, N, d, rounds, seed, False, target, ex())
-    assert pa.replicas.scan_loop_name() == "" and pb.replicas.scan_loop_name() == "k_scans_automala"
-    _same(a, b)
-    for x, y in zip(pa.replicas.states(), pb.replicas.states()):
-        assert np.array_equal(x, y)
+    pc, c = _run_am(P, N, d, rounds, seed, False, target, ex(), flags=_lib.KERNEL_SCAN_LOOP_ONE_CHAIN)
+    assert pa.replicas.scan_loop_name() == "" and pb.replicas.scan_loop_name() == "k_scans_automala_wg" and pc.replicas.scan_loop_name() == "k_scans_automala"
+    _same(a, b); _same(a, c)
+    for x, y, z in zip(pa.replicas.states(), pb.replicas.states(), pc.replicas.states()):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
 
 
 def test_which_engines_run_the_fused_loop(P):
@@ -175,7 +183,7 @@ def test_which_engines_run_the_fused_loop(P):
                                                  record=[P.round_trip, P.log_sum_ratio]), **kw)))
     assert mk().replicas.scan_loop_name() == "k_scans_slice8"
     assert mk(explorer=P.ToyExplorer()).replicas.scan_loop_name() == ""
-    assert mk(explorer=P.AutoMALA()).replicas.scan_loop_name() == "k_scans_automala"
+    assert mk(explorer=P.AutoMALA()).replicas.scan_loop_name() == "k_scans_automala_wg"
     assert mk(explorer=P.AutoMALA(), target=P.toy_mvn_target(600)).replicas.scan_loop_name() == ""   # d > 512: the spilling register layouts stay per scan
     assert mk(explorer=P.Compose(P.SliceSampler(), P.AutoMALA())).replicas.scan_loop_name() == ""
     assert mk(target=P.toy_mvn_target(64), n_chains=8192).replicas.scan_loop_name() == ""            # more workgroups than the GPU holds at once
