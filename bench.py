@@ -272,26 +272,32 @@ def invariance_check(P, d, total_chains, explorer_name, rank, world, local_rank,
 def extra_configs(P):
     """ms / scan (explore + swap, wall clock around pte_run_scans, states resident) of the other BASELINE configs at their per-GPU
     shapes, and the 1-GPU anchor of the strong-scaling clause -- untimed for the headline, so that every config has a driver-visible
-    number.  A handful of scans each."""
+    number.  A handful of scans each, prepared as a run in progress: rounds 1 .. r of the algorithm itself (2, 4, ... 2^r scans, reduce +
+    adaptation after each: schedule; AutoMALA: step size and preconditioner), then the timed scans.  What a fresh engine costs is another
+    regime, and C3's cost moves with the adapted step size and preconditioner (tools/diag_regimes.py: from zeros with the untuned step size
+    0.23-0.24 ms per scan, rounds 3-8 0.19-0.23, adapted every 16 scans 0.17-0.20): the line times round 7 (128 scans) after rounds 1-6."""
     import torch
+    from pigeons_amd.pt import reduce_recorders, adapt
     rec = [P.round_trip, P.log_sum_ratio]
     cfgs = [
-        ("C1 toy_mvn_target(2), n_chains=10, SliceSampler (the reference's quickstart: launch bound)", lambda: P.Inputs(target=P.toy_mvn_target(2), n_chains=10, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 8, 256),
-        ("C2 toy_mvn_target(1024), n_chains=256, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(1024), n_chains=256, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 4, 16),
-        ("C3 funnel d=128, n_chains=1024, AutoMALA", lambda: P.Inputs(target=P.Funnel(128), reference=P.ScaledPrecisionNormalLogPotential(1 / 9., 128), n_chains=1024, explorer=P.AutoMALA(), record=rec, n_rounds=8, show_report=False), 4, 32),
+        ("C1 toy_mvn_target(2), n_chains=10, SliceSampler (the reference's quickstart: launch bound)", lambda: P.Inputs(target=P.toy_mvn_target(2), n_chains=10, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 5, 256),
+        ("C2 toy_mvn_target(1024), n_chains=256, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(1024), n_chains=256, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 3, 16),
+        ("C3 funnel d=128, n_chains=1024, AutoMALA", lambda: P.Inputs(target=P.Funnel(128), reference=P.ScaledPrecisionNormalLogPotential(1 / 9., 128), n_chains=1024, explorer=P.AutoMALA(), record=rec, n_rounds=8, show_report=False), 6, 128),
         ("C4 shard: toy_mvn_target(4096), 1024 of 8192 chains, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(4096), n_chains=1024, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 2, 8),
         ("C4 on ONE GPU (strong-scaling anchor): toy_mvn_target(4096), n_chains=8192, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(4096), n_chains=8192, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 1, 4),
-        ("C5 shard: Ising 256x256, 512 of 4096 chains, IsingMetropolis(3 sweeps)", lambda: P.Inputs(target=P.IsingLogPotential(1.0, 256), n_chains=512, record=rec, n_rounds=8, show_report=False), 4, 8),
+        ("C5 shard: Ising 256x256, 512 of 4096 chains, IsingMetropolis(3 sweeps)", lambda: P.Inputs(target=P.IsingLogPotential(1.0, 256), n_chains=512, record=rec, n_rounds=8, show_report=False), 2, 8),
     ]
     out = []
-    for name, mk, warm, scans in cfgs:
+    for name, mk, rounds, scans in cfgs:
         inp = mk()
         pt = P.PT(inp)
         e = pt.replicas
-        e.run_scans(1, warm)
+        for r in range(1, rounds + 1):
+            e.run_scans(1, 2 ** r); adapt(pt, reduce_recorders(pt))
         torch.cuda.synchronize()
         t = time.perf_counter(); e.run_scans(1, scans); torch.cuda.synchronize(); dt = time.perf_counter() - t
         out.append({"config": name, "kernel": e.kernel_name(), "scan_loop": e.scan_loop_name() or "two launches per scan", "ms_per_scan": dt / scans * 1e3, "replica_steps_per_s": inp.n_chains * scans / dt,
+                    "preparation": "rounds 1..%d of the algorithm (%d scans, adapted after each round); then %d timed scans" % (rounds, 2 ** (rounds + 1) - 2, scans),
                     "chains_per_gpu": inp.n_chains, "waves_per_simd": inp.n_chains / 1024.0})
         del pt, e
     return out

@@ -13,6 +13,9 @@
 #pragma once
 #include "pte_slice2.hpp"
 
+#ifndef PTE_ISING_FILTER_MIN
+#define PTE_ISING_FILTER_MIN 1e-13          // beta * beta_target above which the thresholds decide (see k_explore_ising)
+#endif
 namespace pte {
 
 struct IsingParams { int L; int n_steps; double beta_target; };
@@ -87,7 +90,14 @@ __global__ __launch_bounds__(64) void k_explore_ising(EngineDev e, IsingParams i
     // |delta| = 4 or 8: guard-banded thresholds for `rand > accept_ratio`
     const double r4 = exp(-4.0 * bb), r8 = exp(-8.0 * bb);
     const double r4lo = r4 * (1.0 - 1e-9), r4hi = r4 * (1.0 + 1e-9), r8lo = r8 * (1.0 - 1e-9), r8hi = r8 * (1.0 + 1e-9);
-    const bool filter_ok = bb > 1e-6;       // below: the two log potentials may round equal -> always decide exactly
+    // When may a proposal with delta < 0 be decided by comparing the uniform with the guard-banded thresholds?  The reference evaluates
+    // exp(lp(S + delta) - lp(S)) with lp(S) = fl(beta * fl(bt * S)): the two roundings put a relative error of <= 2^-51 S / |delta| on the
+    // exponent (1.5e-11 at 256 x 256, 2.4e-10 at 1024 x 1024: inside the 1e-9 band whatever beta is), and what the filter ALSO assumes --
+    // that a uniform is drawn at all, i.e. that this ratio is < 1 in floating point -- holds while 4 beta bt is well above 2^-53.  Below the
+    // limit every decision takes the exact arithmetic (one full recount of the lattice per decision: ~1 us).  (Rounds 3-5 had 1e-6 here,
+    // and the second chain of a ladder adapted on a handful of scans does get there: 2.6e-7 after round 2 of C5 -- 207 ms per scan for that
+    // round instead of 3.8, tools/diag_regimes.py.)
+    const bool filter_ok = bb > PTE_ISING_FILTER_MIN;
 
     // 64 buffered uniforms of the replica's stream
     double unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma));
@@ -204,7 +214,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_bits(EngineDev e, IsingPar
         const unsigned r4lo_h = hi32(r4l), r4hi_h = hi32(r4h), r8lo_h = hi32(r8l), r8hi_h = hi32(r8h);
         const unsigned long long r4lo = ((unsigned long long)r4lo_h << 32) | lo32(r4l), r4hi = ((unsigned long long)r4hi_h << 32) | lo32(r4h);
         const unsigned long long r8lo = ((unsigned long long)r8lo_h << 32) | lo32(r8l), r8hi = ((unsigned long long)r8hi_h << 32) | lo32(r8h);
-        const bool filter_ok = bb > 1e-6;
+        const bool filter_ok = bb > PTE_ISING_FILTER_MIN;
         double unit = u52_to_unit(mix64(seed + (uint64_t)(lane + 1) * gamma));
         int p = 0;
         for (int k = 0; k < ip.n_steps; ++k) {
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(64) void k_explore_ising_spec(EngineDev e, IsingPar
         const unsigned r4lo_h = hi32(r4l), r4hi_h = hi32(r4h), r8lo_h = hi32(r8l), r8hi_h = hi32(r8h);
         const unsigned long long r4lo = ((unsigned long long)r4lo_h << 32) | lo32(r4l), r4hi = ((unsigned long long)r4hi_h << 32) | lo32(r4h);
         const unsigned long long r8lo = ((unsigned long long)r8lo_h << 32) | lo32(r8l), r8hi = ((unsigned long long)r8hi_h << 32) | lo32(r8h);
-        const bool filter_ok = bb > 1e-6;
+        const bool filter_ok = bb > PTE_ISING_FILTER_MIN;
         // this lane's hypothesis (lk, lc, lb): quad lk of a 16-site chunk (sites 4 lk .. 4 lk + 3), lc uniforms consumed
         // since the chunk started, left neighbour of the quad's first site now lb; 2 (4 lk + 1) hypotheses per quad = 56 lanes
         const int lk = (lane >= 2) + (lane >= 12) + (lane >= 30);

@@ -708,6 +708,25 @@ def test_ising_parity(P, L, N, rounds, beta, seed):
         assert np.array_equal(x, xr) and np.array_equal(chain, cr) and np.array_equal(rng, rr)
 
 
+@pytest.mark.parametrize("L", [8, 32, 64])           # the byte kernel, the one-word-per-row and the general instantiation of the speculative kernel
+def test_ising_ladders_with_tiny_betas(P, L):
+    """the second chain of a ladder adapted on a handful of scans sits at beta ~ 1e-7 (C5 after its round 2: 2.6e-7): the guard-banded
+    thresholds decide there too (valid while 4 beta beta_target >> 2^-53: PTE_ISING_FILTER_MIN = 1e-13; rounds 3-5 sent every decision
+    of such a chain through the exact arithmetic with a recount of the lattice, 207 ms per scan at 256 x 256), and below the limit the
+    exact arithmetic still takes over -- states, chains and RNG counters equal the oracle's either way"""
+    betas = np.array([0.0, 1e-18, 3e-16, 5e-14, 2e-13, 1e-11, 2.6e-7, 5e-6, 3e-3, 0.2, 0.6, 1.0])
+    N = len(betas)
+    pt = P.PT(P.Inputs(target=P.IsingLogPotential(1.0, L), n_chains=N, n_rounds=6, seed=5, record=[P.round_trip, P.index_process], show_report=False))
+    ref = O.OraclePT(target=O.TARGET_ISING, explorer=O.EXPLORER_ISING, dim=L * L, p0=1.0, n_chains=N, seed=5, slice_n_passes=3)
+    pt.replicas.set_schedule(betas); ref.set_schedule(betas)
+    ref.begin_round()
+    for k in range(3):
+        pt.replicas.run_scans(1 + 8 * k, 8); ref.run_scans(8)
+        x, chain, rng = pt.replicas.states()
+        xr, cr, rr = ref.states()
+        assert np.array_equal(chain, cr) and np.array_equal(rng, rr) and np.array_equal(x, xr)
+
+
 def test_ising_sharded_equals_single(P):
     mk = lambda: P.Inputs(target=P.IsingLogPotential(1.0, 8), n_chains=8, n_rounds=5, show_report=False,
                           record=[P.round_trip, P.index_process, P.log_sum_ratio])
