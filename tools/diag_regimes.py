@@ -1,5 +1,5 @@
 """ms / scan of C5 (Ising 256 x 256, 512 chains) and C3 (funnel d = 128, 1024 chains, AutoMALA) along a run: by chunk of scans, before and after
-schedule / explorer adaptations -- which regime does a "handful of scans" measure?  Usage: python tools/diag_regimes.py [ising|funnel]"""
+schedule / explorer adaptations -- which regime does a "handful of scans" measure?  Usage: python tools/diag_regimes.py [ising|funnel|slice]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pigeons.jl_amd")]
@@ -16,6 +16,9 @@ rec = [P.round_trip, P.log_sum_ratio]
 if which == "ising":
     mk = lambda: P.PT(P.Inputs(target=P.IsingLogPotential(1.0, 256), n_chains=512, record=rec, n_rounds=12, show_report=False))
     chunk = 4
+elif which == "slice":
+    mk = lambda: P.PT(P.Inputs(target=P.toy_mvn_target(1024), n_chains=1024, explorer=P.SliceSampler(), record=rec, n_rounds=12, show_report=False))
+    chunk = 8
 else:
     mk = lambda: P.PT(P.Inputs(target=P.Funnel(128), reference=P.ScaledPrecisionNormalLogPotential(1 / 9., 128), n_chains=1024, explorer=P.AutoMALA(), record=rec, n_rounds=12, show_report=False))
     chunk = 16
