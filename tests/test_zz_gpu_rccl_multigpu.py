@@ -78,7 +78,8 @@ else:
         if time.time() - t0 > 120: raise SystemExit("rank %d: no communicator id after 120 s" % rank)
         time.sleep(0.01)
     cid = open(idfile, "rb").read()
-pt = P.PT(mk(), rank=rank, world=world, comm_id=cid)            # RcclShard: pte_comm_init (collective) inside
+REFRED = bool(cfg.get("refred"))                                  # PTE_RECORD_REFERENCE_REDUCTION: every rank replays the pairs whose lower chain it owns
+pt = P.PT(mk(), rank=rank, world=world, comm_id=cid, reference_reduction=REFRED)            # RcclShard: pte_comm_init (collective) inside
 assert type(pt.shards).__name__ == "RcclShard", type(pt.shards).__name__
 ok = pt.shards.n_ranks_seen == world and pt.replicas.comm_info()[0] == 1
 why = [] if ok else ["n_ranks_seen %r" % pt.shards.n_ranks_seen]
@@ -101,7 +102,7 @@ kernel = pt.replicas.kernel_name()
 pt.replicas.comm_destroy()
 # the single engine on rank 0: after the sharded run's last collective, so that a failure here cannot leave a peer inside one
 if rank == 0:
-    one = P.PT(mk())
+    one = P.PT(mk(), reference_reduction=REFRED)
     for r in range(cfg["rounds"]):
         P.next_round(one); ra = P.run_one_round(one); P.adapt(one, ra)
         ip, rt, sw, ls, st, gr = sharded[r]
@@ -195,6 +196,8 @@ def test_the_rank_script_of_this_module_runs(tmp_path):
     _check(res, 2, "k_explore_slice8", stand_in=True, require_swaps=False)
     res = _run_world(tmp_path, dict(explorer="ising", L=256, beta=1.0, N=8, rounds=3, seed=5, stand_in=fake), 2)
     _check(res, 2, "k_explore_ising_spec", stand_in=True, require_swaps=False)
+    res = _run_world(tmp_path, dict(explorer="slice", d=64, N=32, rounds=5, seed=2, refred=True, stand_in=fake), 2)      # the reference's reduction replayed per rank
+    _check(res, 2, "k_explore_slice8", stand_in=True)
 
 
 @pytest.mark.skipif(N_GPUS < 2, reason="needs >= 2 GPUs on the node (%d visible)" % N_GPUS)
