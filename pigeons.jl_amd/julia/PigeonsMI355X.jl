@@ -252,7 +252,9 @@ end
 
 # Which form pte_run_scans takes on this engine (round 5): "" = an explore and a swap launch per scan; otherwise the ONE kernel that runs all the
 # scans of the call ("k_scans_slice8", "k_scans_automala": workgroup c keeps chain c, the DEO swap of a pair is a hand-shake between its two
-# waves).  Results are bit-identical either way; `debug_kernel = PTE_KERNEL_TWO_LAUNCHES` (0x1000) in the config forces the per-scan loop.
+# waves; "k_scans_automala_wg": four consecutive chains per workgroup, inner pairs shake hands through LDS).  Results are bit-identical
+# either way; `debug_kernel = PTE_KERNEL_TWO_LAUNCHES` (0x1000) in the config forces the per-scan loop, `PTE_KERNEL_SCAN_LOOP_ONE_CHAIN`
+# (0x2000) the one-chain-per-workgroup form of the one-kernel loop.
 scan_loop_name(r::DeviceReplicas) = unsafe_string(ccall((:pte_scan_loop_name, libpte), Cstring, (Ptr{Cvoid},), r.handle))
 
 # adapt(pt, reduced_recorders) ran on the host (adapt_tempering: src/tempering/NonReversiblePT.jl:46-66, StabilizedPT.jl:53-65;
