@@ -44,6 +44,35 @@ def test_config_struct_matches_header(P):
     assert list(cfg.target_params)[:2] == [1.0, 10.0]
 
 
+def test_enum_mirrors_match_the_header():
+    """every enumerator of include/pte.h that the Python side (pigeons_amd/_lib.py) and the Julia glue (julia/PigeonsMI355X.jl) mirror by value"""
+    import re
+    from pigeons_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "pte.h")).read()
+    vals = {}
+    for name, expr in re.findall(r"^\s*(PTE_[A-Z0-9_]+)\s*=\s*(1u\s*<<\s*\d+|0x[0-9a-fA-F]+|\d+)", hdr, re.M):
+        m = re.fullmatch(r"1u\s*<<\s*(\d+)", expr)
+        vals[name] = (1 << int(m.group(1))) if m else int(expr, 0)
+    pairs = {"PTE_TARGET_MVN_SCALED_PRECISION": _lib.TARGET_MVN_SCALED_PRECISION, "PTE_TARGET_TEST_SWAPPER": _lib.TARGET_TEST_SWAPPER,
+             "PTE_TARGET_FUNNEL": _lib.TARGET_FUNNEL, "PTE_TARGET_ISING": _lib.TARGET_ISING,
+             "PTE_EXPLORER_NONE": _lib.EXPLORER_NONE, "PTE_EXPLORER_TOY": _lib.EXPLORER_TOY, "PTE_EXPLORER_SLICE": _lib.EXPLORER_SLICE,
+             "PTE_EXPLORER_AUTOMALA": _lib.EXPLORER_AUTOMALA, "PTE_EXPLORER_MALA": _lib.EXPLORER_MALA,
+             "PTE_RECORD_ROUND_TRIP": _lib.RECORD_ROUND_TRIP, "PTE_RECORD_INDEX_PROCESS": _lib.RECORD_INDEX_PROCESS, "PTE_RECORD_ONLINE": _lib.RECORD_ONLINE,
+             "PTE_RECORD_TRACES": _lib.RECORD_TRACES, "PTE_RECORD_ENERGY_AC1": _lib.RECORD_ENERGY_AC1, "PTE_RECORD_TRACES_EXTENDED": _lib.RECORD_TRACES_EXTENDED,
+             "PTE_RECORD_REFERENCE_REDUCTION": _lib.RECORD_REFERENCE_REDUCTION,
+             "PTE_KERNEL_SLICE_SEQUENTIAL": _lib.KERNEL_SLICE_SEQUENTIAL, "PTE_KERNEL_ISING_BITS": _lib.KERNEL_ISING_BITS, "PTE_KERNEL_ISING_BYTES": _lib.KERNEL_ISING_BYTES,
+             "PTE_KERNEL_TWO_LAUNCHES": _lib.KERNEL_TWO_LAUNCHES, "PTE_KERNEL_SCAN_LOOP_ONE_CHAIN": _lib.KERNEL_SCAN_LOOP_ONE_CHAIN, "PTE_KERNEL_FLAG_BITS": _lib.KERNEL_FLAG_BITS}
+    for name, py in pairs.items():
+        assert name in vals, name
+        assert vals[name] == py, (name, vals[name], py)
+    assert vals["PTE_KERNEL_FLAG_BITS"] == vals["PTE_KERNEL_TWO_LAUNCHES"] | vals["PTE_KERNEL_SCAN_LOOP_ONE_CHAIN"]
+    jl = open(os.path.join(ROOT, "pigeons.jl_amd", "julia", "PigeonsMI355X.jl")).read()
+    m = re.search(r"const RECORD_ROUND_TRIP, RECORD_INDEX_PROCESS, RECORD_ONLINE, RECORD_TRACES, RECORD_ENERGY_AC1, RECORD_TRACES_EXTENDED =\s*UInt32\.\(\(([^)]*)\)\)", jl)
+    assert [int(x) for x in m.group(1).split(",")] == [vals[k] for k in ("PTE_RECORD_ROUND_TRIP", "PTE_RECORD_INDEX_PROCESS", "PTE_RECORD_ONLINE", "PTE_RECORD_TRACES",
+                                                                           "PTE_RECORD_ENERGY_AC1", "PTE_RECORD_TRACES_EXTENDED")]
+    assert re.search(r"const RECORD_REFERENCE_REDUCTION = UInt32\((\d+)\)", jl).group(1) == str(vals["PTE_RECORD_REFERENCE_REDUCTION"])
+
+
 def test_no_cpu_fallback(P):
     import torch
     if torch.cuda.is_available():
