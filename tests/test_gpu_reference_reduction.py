@@ -48,6 +48,7 @@ def _exact_round(P, pt, ref):
     ("slice", 2, 33, 6, 5),        # one pair
     ("toy", 16, 128, 7, 3),
     ("toy", 37, 5, 8, 9),
+    ("slice", 64, 8, 10, 6),       # 2046 scans: every replica visits most pairs; the last round replays 1024 scans
 ])
 def test_recorders_and_schedule_equal_the_oracle_bit_for_bit(P, kind, N, d, rounds, seed, two_launches):
     from pigeons_amd import _lib
