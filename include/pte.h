@@ -75,7 +75,8 @@ enum {                                   /* Inputs.record (src/pt/Inputs.jl:57-6
                                               * scan ([max_scans_per_round][n_chains][2] doubles); pte_reduce replays the fits and merges on the host, so the adapted schedule
                                               * is the reference's to the last bit instead of to 1e-11.  Needs PTE_RECORD_INDEX_PROCESS (who held the lower chain).  A
                                               * chain-shard replays the pairs whose lower chain it owns (log and index rows are local; the tree runs over the global
-                                              * replica index).  With PTE_RECORD_TRACES the online statistics are rebuilt the same way.  Off by default: the values agree to ~1e-12 either way, and a round of 1024 x 1024 chain-scans logs 16 MB. */
+                                              * replica index).  With PTE_RECORD_TRACES the online statistics are rebuilt the same way, and AutoMALA's am_factors (the
+                                              * exponent of every step-size search is logged: the step size adapts on their mean) always.  Off by default: the values agree to ~1e-12 either way, and a round of 1024 x 1024 chain-scans logs 16 MB. */
 };
 
 enum {                                   /* pte_config.debug_kernel: which kernel generation explores (0 = the default)   */

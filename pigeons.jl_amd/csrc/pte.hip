@@ -236,6 +236,8 @@ int reset_recorders(pte_engine *h) {
     HIP_OK(h, hipMemsetAsync(e.eac, 0, sizeof(double) * 5 * N, h->stream));
     HIP_OK(h, hipMemsetAsync(e.eac_n, 0, sizeof(int64_t) * N, h->stream));
     HIP_OK(h, hipMemsetAsync(e.on_n, 0, 2 * sizeof(int64_t), h->stream));
+    if (e.am_log)       // 0x7f7f = "no search here"
+        HIP_OK(h, hipMemsetAsync(e.am_log, 0x7F, sizeof(int16_t) * (size_t)(h->cfg.max_scans_per_round * h->K * e.am_log_cap), h->stream));
     if (e.swap_log)     // all-ones words = "this pair was idle at this scan" (no log ratio has that bit pattern: a NaN ratio is ERR_NAN_RATIO)
         HIP_OK(h, hipMemsetAsync(e.swap_log, 0xFF, sizeof(double) * 2 * (size_t)(h->cfg.max_scans_per_round * h->K), h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));   // `ninf` must outlive the copies
@@ -716,6 +718,13 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.error, 4);
     e.swap_log = nullptr;
     if (cfg->record_flags & PTE_RECORD_REFERENCE_REDUCTION) rc |= dev_alloc(h, &e.swap_log, (size_t)(cfg->max_scans_per_round * K * 2), false);
+    e.am_log = nullptr; e.am_log_cap = 0;
+    if ((cfg->record_flags & PTE_RECORD_REFERENCE_REDUCTION) && (cfg->explorer == PTE_EXPLORER_AUTOMALA || cfg->explorer2 == PTE_EXPLORER_AUTOMALA)) {
+        // AutoMALA searches a step size twice per refresh at most (forward, and backward for the reversibility check): am_factors' fits
+        const int nref = cfg->am_base_n_refresh * (int)std::ceil(std::pow((double)(d > 0 ? d : 1), cfg->am_exponent_n_refresh));
+        e.am_log_cap = 2 * nref;
+        rc |= dev_alloc(h, &e.am_log, (size_t)(cfg->max_scans_per_round * K * e.am_log_cap), false);
+    }
     if (rc) return bail(1);
     e.nhp = h->d_nhp; e.sd = h->d_sd; e.nprec = h->d_nprec; e.beta = h->d_beta;
     e.ref_nhp = -0.5 * cfg->target_params[0];
@@ -942,6 +951,37 @@ static int reference_reduce(pte_engine *h, Snapshot &s) {
             return fail(h, "PTE_RECORD_REFERENCE_REDUCTION: the log holds %lld swaps of pair %lld, the device counted %lld", (long long)rec[0].n, (long long)(c0 + c), (long long)s.swap_n[(size_t)c]);
         if (rec[0].n > 0) { s.swap_mean[(size_t)c] = rec[0].mu; s.lsr_up[(size_t)c] = rec[0].up; s.lsr_dn[(size_t)c] = rec[0].dn; }
     }
+    // am_factors (AutoMALA.jl:277: one fit of 2^exponent per step-size search, keyed by the chain) the same way -- it is what the step size
+    // adapts on (AutoMALA.jl:70-79), i.e. what decides whether the NEXT round's states equal the reference's or sit an ulp away
+    if (h->dev.am_log) {
+        const int cap = h->dev.am_log_cap;
+        std::vector<int16_t> al((size_t)(T * K * cap));
+        HIP_OK(h, hipMemcpy(al.data(), h->dev.am_log, sizeof(int16_t) * al.size(), hipMemcpyDeviceToHost));
+        struct Mn { double mu; int64_t n; };
+        std::vector<Mn> mn((size_t)N);
+        for (int64_t c = 0; c < K; ++c) {
+            for (auto &r : mn) r = Mn{0.0, 0};
+            for (int64_t t = 0; t < T; ++t) {
+                Mn &r = mn[(size_t)holder[(size_t)(t * K + c)]];
+                const int16_t *a = &al[(size_t)((t * K + c) * cap)];
+                for (int j = 0; j < cap && a[j] != (int16_t)0x7F7F; ++j) {
+                    r.n += 1;
+                    r.mu = r.mu + (1.0 / (double)r.n) * (std::ldexp(1.0, (int)a[j]) - r.mu);
+                }
+            }
+            for (int64_t sp = 1; sp < N; sp *= 2)
+                for (int64_t i = 0; i + sp < N; i += 2 * sp) {
+                    Mn &a = mn[(size_t)i]; const Mn &b = mn[(size_t)(i + sp)];
+                    if (b.n == 0) continue;
+                    if (a.n == 0) { a = b; continue; }
+                    a.n += b.n;
+                    a.mu = a.mu + ((double)b.n / (double)a.n) * (b.mu - a.mu);
+                }
+            if (mn[0].n != h->fac_n[(size_t)c])
+                return fail(h, "PTE_RECORD_REFERENCE_REDUCTION: the log holds %lld step-size searches of chain %lld, the device counted %lld", (long long)mn[0].n, (long long)(c0 + c), (long long)h->fac_n[(size_t)c]);
+            if (mn[0].n > 0) h->fac_mean[(size_t)c] = mn[0].mu;
+        }
+    }
     // :online / :_transformed_online the same way, when the round's traces are there to replay them from (PTE_RECORD_TRACES: the target
     // chains' [state; log density] per scan are exactly what explore! fits, src/pt/pigeons.jl:116-131): every replica's Mean and Variance
     // (OnlineStats: mu += g (x - mu), s2 += g ((x - mu_new)(x - mu_old) - s2), g = 1/n; merge with g = n_b / n) per coordinate, tree-merged.
@@ -1051,13 +1091,13 @@ int pte_reduce(pte_engine *h) {
         }
         s.on_mean.resize(d + 1);
     }
-    if (e.swap_log && reference_reduce(h, s)) return 1;
     for (int64_t i = 0; i < K; ++i)       // cor(CovMatrix)[1,2]: the Bessel factors cancel
         if (s.eac_n[i] > 1) s.eac_cor[i] = s.eac_raw[5 * i + 3] / std::sqrt(s.eac_raw[5 * i + 2] * s.eac_raw[5 * i + 4]);
     for (int64_t i = 0; i < K; ++i) {
         h->fac_mean[i] = h->fac_n[i] > 0 ? fsum[i] / (double)h->fac_n[i] : 0.0;
         h->rev_mean[i] = h->rev_n[i] > 0 ? rsum[i] / (double)h->rev_n[i] : 0.0;
     }
+    if (e.swap_log && reference_reduce(h, s)) return 1;       // (PTE_RECORD_REFERENCE_REDUCTION: replaces the swap recorders, am_factors and, given traces, online)
     return reset_recorders(h);
 }
 

@@ -454,6 +454,7 @@ __device__ __forceinline__ void automala_body(EngineDev e, AmParams ap, const in
             }
         }
         steps_sum += 1 + n_steps; steps_n += 1;
+        if (e.am_log != nullptr && lane == 0 && fac_n < e.am_log_cap) e.am_log[(e.trace_idx * e.K + cl) * e.am_log_cap + fac_n] = (int16_t)exponent;
         fac_sum += ldexp(1.0, exponent); fac_n += 1;
         return exponent;
     };

@@ -48,6 +48,7 @@ struct EngineDev {
     double *swap_sum;  int64_t *swap_n;                    // [N-1] swap_acceptance_pr
     double *lsr_up;    double *lsr_dn;   int64_t *lsr_n;   // [N-1] log_sum_ratio (c,c+1) / (c+1,c)
     double *swap_log;                                      // null, or [max_scans][K][2] {log ratio of the lower chain's replica, of the upper's} per scan and pair, at the lower chain (PTE_RECORD_REFERENCE_REDUCTION)
+    int16_t *am_log; int am_log_cap;                       // null, or [max_scans][K][am_log_cap] exponents of the step-size searches of a scan, in call order (32639 = unused): PTE_RECORD_REFERENCE_REDUCTION
     int64_t *rt_state; int64_t *rt_restarts; int64_t *rt_trips;   // [slot] round_trip
     double *expl_acc_sum; int64_t *expl_acc_n;             // [chain] explorer_acceptance_pr
     double *expl_steps_sum; int64_t *expl_steps_n;         // [chain] explorer_n_steps

@@ -527,7 +527,10 @@ def adapt_explorer(pt, reduced):
             fm, fn = reduced.am_factors
             present = np.asarray(fn) > 0
             if present.any():
-                new_step = ex.step_size * float(np.mean(np.asarray(fm)[present]))
+                acc = 0.0                                # (a plain left-to-right sum, as the oracle's: np.mean sums in eight interleaved partial sums)
+                for v in np.asarray(fm, dtype=np.float64)[present]:
+                    acc += float(v)
+                new_step = ex.step_size * (acc / float(int(present.sum())))
         adapted.append((new_step, std))
         return type(ex)(ex.base_n_refresh, ex.exponent_n_refresh, new_step, ex.preconditioner, std)
     adapted = []

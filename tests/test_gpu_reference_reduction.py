@@ -151,19 +151,52 @@ def test_default_reduction_stays_within_its_tolerance_of_the_replayed_one(P):
     assert differs
 
 
-def test_automala_runs_with_the_flag(P):
-    """gradient-based explorers: the states are 1 ulp from the oracle's where ocml and libm differ, so the recorders cannot be bit-equal to
-    it; the replay must still agree with the device's sums and with the oracle inside the parity tolerance"""
-    N, d, rounds = 6, 10, 6
-    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=P.AutoMALA(), seed=1,
+@pytest.mark.parametrize("form", ["wg", "one_chain", "two_launches"])
+@pytest.mark.parametrize("kind,N,d,rounds,seed", [("automala", 6, 10, 7, 1), ("automala", 8, 128, 6, 1), ("automala", 5, 64, 6, 2), ("automala", 13, 20, 7, 3),
+                                                   ("mala", 6, 64, 6, 4), ("compose", 6, 12, 6, 5), ("sharded", 8, 10, 6, 6)])
+def test_automala_on_the_mvn_path_equals_the_oracle_bit_for_bit(P, kind, N, d, rounds, seed, form):
+    """AutoMALA / MALA on the scaled-precision path hold no transcendental in the state's arithmetic, so their kernels ARE bit-exact -- what
+    used to put an ulp between engine and oracle from round 2-4 on was the step size, adapted on the mean of am_factors (AutoMALA.jl:70-79),
+    and the preconditioner, refitted to the target chain's online variance.  With the flag both are reduced with the reference's arithmetic
+    (am_factors: the exponents of every step-size search logged and replayed; online: from the traces) and every state word, the step size
+    and the schedule equal the oracle's in every round"""
+    from pigeons_amd import _lib
+    flags = {"wg": 0, "one_chain": _lib.KERNEL_SCAN_LOOP_ONE_CHAIN, "two_launches": _lib.KERNEL_TWO_LAUNCHES}[form]
+    if kind in ("compose", "sharded") and form != "wg":
+        pytest.skip("Compose and chain-shards run the launch-per-scan loop whatever the flag says")
+    ex = {"automala": P.AutoMALA(), "sharded": P.AutoMALA(), "mala": P.MALA(step_size=0.15), "compose": P.Compose(P.AutoMALA(), P.SliceSampler())}[kind]
+    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=ex, seed=seed,
+                       record=[P.round_trip, P.index_process, P.log_sum_ratio, P.online, P.traces], show_report=False), reference_reduction=True, debug_kernel=flags,
+              **(dict(n_shards=2, transport="group") if kind == "sharded" else {}))
+    okw = {"automala": dict(explorer=O.EXPLORER_AUTOMALA), "sharded": dict(explorer=O.EXPLORER_AUTOMALA), "mala": dict(explorer=O.EXPLORER_MALA, am_step_size=0.15),
+           "compose": dict(explorer=O.EXPLORER_AUTOMALA, explorer2=O.EXPLORER_SLICE)}[kind]
+    ref = O.OraclePT(n_chains=N, dim=d, seed=seed, am_preconditioner=2, record_online=1, record_traces=1, **okw)
+    for _ in range(rounds):
+        red = _exact_round(P, pt, ref)
+        ex_now = pt.shared.explorer.first if kind == "compose" else pt.shared.explorer
+        assert ex_now.step_size == ref.step_size()
+        assert np.array_equal(red.traces, ref.traces())
+        assert np.array_equal(red.online[0], ref.online()[0]) and np.array_equal(red.online[1], ref.online()[1])
+        fm, fn, rm, rn = ref.automala_stats()
+        assert np.array_equal(red.am_factors[1], fn) and np.array_equal(red.am_factors[0], fm)
+        x, chain, rng = (pt.shards if pt.shards is not None else pt.replicas).states(); xr, cr, rr = ref.states()
+        assert np.array_equal(chain, cr) and np.array_equal(rng, rr) and np.array_equal(x, xr)
+
+
+def test_automala_on_the_funnel_stays_inside_its_tolerance(P):
+    """the funnel's density holds exp / log (ocml vs glibc: states an ulp apart from round 1), so there is nothing exact to reproduce; the
+    replay must still agree with the oracle inside the parity tolerance"""
+    N, d, rounds = 8, 8, 6
+    pt = P.PT(P.Inputs(target=P.Funnel(d), reference=P.ScaledPrecisionNormalLogPotential(1 / 9., d), n_chains=N, n_rounds=rounds, explorer=P.AutoMALA(), seed=1,
                        record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False), reference_reduction=True)
-    ref = O.OraclePT(n_chains=N, dim=d, seed=1, explorer=O.EXPLORER_AUTOMALA, am_preconditioner=2)
+    ref = O.OraclePT(n_chains=N, dim=d, seed=1, explorer=O.EXPLORER_AUTOMALA, target=O.TARGET_FUNNEL, p0=1 / 9., am_preconditioner=2)
     for _ in range(rounds):
         assert P.next_round(pt)
         red = P.run_one_round(pt); P.adapt(pt, red); ref.run_round()
         assert np.array_equal(red.index_process, ref.index_process())
-        np.testing.assert_allclose(red.swap_acceptance_pr[0], ref.swap_pr()[0], rtol=1e-9, atol=1e-300)
-        np.testing.assert_allclose(pt.shared.tempering.schedule.grids, ref.schedule(), rtol=1e-9)
+        np.testing.assert_allclose(red.swap_acceptance_pr[0], ref.swap_pr()[0], rtol=1e-6, atol=1e-300)
+        np.testing.assert_allclose(pt.shared.tempering.schedule.grids, ref.schedule(), rtol=1e-6)
+        np.testing.assert_allclose(pt.shared.explorer.step_size, ref.step_size(), rtol=1e-9)
 
 
 def test_the_flag_has_its_preconditions(P):
