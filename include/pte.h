@@ -91,7 +91,16 @@ enum {                                   /* pte_config.debug_kernel: which kerne
     /* a FLAG: where the one-kernel scan loop has a form with several consecutive chains per workgroup (their pairs shake hands through
      * LDS; pte_scan_loop_name ends in "_wg"), use the form with one chain per workgroup instead; bit-identical, for A/B runs and tests */
     PTE_KERNEL_SCAN_LOOP_ONE_CHAIN = 0x2000,
-    PTE_KERNEL_FLAG_BITS        = 0x3000
+    PTE_KERNEL_FLAG_BITS        = 0x3000,
+    /* FAULT INJECTION, test build libpte_test.so only (pte_create of the product library refuses them): what the one-kernel scan loop does when
+     * its forward-progress assumptions break (tests/test_gpu_scan_loop_progress.py).
+     *   DEAD_CHAIN      the wave of chain 7 leaves the loop silently before its third swap of every call: its partner's hand-shake times out after
+     *                   3 s, every other wave sees the error word and leaves, pte_run_scans fails, the engine is poisoned (pte_scan_loop_stats)
+     *   LATE_WORKGROUP  workgroup 3 of every scan-loop launch reaches the residency gate 80 ms late (as if the device had no room for it): the
+     *                   launch aborts with nothing written and the call runs as explore + swap launches -- same results, no error */
+    PTE_KERNEL_TEST_DEAD_CHAIN     = 0x4000,
+    PTE_KERNEL_TEST_LATE_WORKGROUP = 0x8000,
+    PTE_KERNEL_TEST_BITS        = 0xC000
 };
 
 /* Mirrors the fields of `Inputs` (src/pt/Inputs.jl:9-102) and of the explorer
@@ -283,6 +292,18 @@ const char *pte_kernel_name(const pte_engine *h);
  * pte_timing_get(kernel = 4) times these launches. */
 const char *pte_scan_loop_name(const pte_engine *h);
 int pte_scan_loop_info(const pte_engine *h, int64_t *resident_limit, int64_t *timed_launches, int64_t *timed_scans);
+/* Forward progress of that one kernel (round 6).  Its hand-shakes spin, so all its workgroups must be on the device together.  That is ENFORCED
+ * inside the launch: no workgroup touches anything before every workgroup has arrived at a counter; if one is still missing after 50 ms (another
+ * engine, stream or process holds compute units) all of them return with nothing written and pte_run_scans runs the same scans as explore + swap
+ * launches -- same results, no error, the next 1, 2, 4, ... 256 calls skip the attempt.  So pte_run_scans cannot hang, as the reference's loop
+ * cannot (src/pt/pigeons.jl:46-55).  What is left: a wave that dies or stays descheduled for 3 s AFTER all have arrived (the residency of a
+ * started workgroup is the hardware's; whole-queue preemption between processes suspends and resumes all of a queue's waves together).  Then the
+ * hand-shake times out, every other wave sees the error word and leaves at once, the call fails and the engine is POISONED: its replicas stopped at
+ * different scans.  Every pte_* call on it fails with a message saying so, except pte_destroy and pte_set_state with state, chain and rng of all
+ * replicas, which restores it (and discards the recorders of the round).
+ *   *fused_calls: pte_run_scans calls that ran as one launch; *gate_aborts: launches that found a workgroup missing and fell back;
+ *   *poisoned: 0 / 1.  NULLs are skipped. */
+int pte_scan_loop_stats(const pte_engine *h, int64_t *fused_calls, int64_t *gate_aborts, int32_t *poisoned);
 
 /* index process of the local slots: replica[scan][K], chain[scan][K] (global ids). */
 int pte_get_index_process_shard(const pte_engine *h, int64_t *replica, int64_t *chain, int64_t *n_scans);

@@ -108,7 +108,14 @@ struct pte_engine {
     int fused_wg = 1;                 // chains (waves) per workgroup of the scan-loop kernel this engine launches
     int64_t fused_limit = -1;         // workgroups of the scan-loop kernel the device holds at once (-1: not asked yet, 0: not available)
     unsigned long long *hs_flag = nullptr; double *hs_pub = nullptr;   // [K], [K][2][4]
-    unsigned long long hs_epoch = 0;  // epochs handed out so far (monotone: the flags are never reset)
+    unsigned long long hs_epoch = 0;  // epochs handed out so far (monotone; pte_set_state re-bases the flags of a poisoned engine to it)
+    // forward progress of that launch (round 6; pte_kernels.hpp scan_loop_gate): no workgroup starts before all have arrived, or the call falls back
+    unsigned long long *hs_gate = nullptr;                 // device [2]: arrivals so far, decision word of the last launch
+    unsigned long long gate_seq = 0, gate_arrived = 0;     // launches so far; workgroups they held (every workgroup of a finished launch has arrived)
+    int64_t fused_calls = 0, gate_aborts = 0;              // pte_run_scans calls that ran as one launch; launches that found a workgroup missing and fell back
+    int64_t fused_skip = 0, fused_backoff = 0;             // after an abort the next `fused_skip` calls go straight to explore + swap launches (1, 2, 4, ... 256)
+    bool poisoned = false;            // a device error inside the one-launch scan loop: chains stopped at different scans, only pte_set_state / pte_destroy accepted
+    int test_fault = 0;               // test build only: PTE_KERNEL_TEST_DEAD_CHAIN (1), PTE_KERNEL_TEST_LATE_WORKGROUP (2)
 };
 
 namespace {
@@ -258,8 +265,8 @@ int check_device_error(pte_engine *h) {
     case ERR_SLICE_MAX_ITER: return fail(h, "Maximum number of iterations reached in slice_shrink! (chain %d, index %d)", err[1], err[2]);
     case ERR_AM_DENSITY: return fail(h, "AutoMALA can only be called on a configuration of positive density. (chain %d)", err[1]);
     case ERR_AM_STEP: return fail(h, "Could not find a positive step size (chain %d)", err[1]);
-    case ERR_HANDSHAKE_TIMEOUT: return fail(h, "pte_run_scans: chain %d waited 3 s for its swap partner inside the fused scan loop (a workgroup was not resident, or the device is shared); "
-                                               "set PTE_KERNEL_TWO_LAUNCHES in pte_config.debug_kernel for the launch-per-scan loop", err[1]);
+    case ERR_HANDSHAKE_TIMEOUT: return fail(h, "pte_run_scans: chain %d gave up waiting for its swap partner inside the one-launch scan loop (every workgroup had arrived: "
+                                               "a wave died or was descheduled for seconds)", err[1]);
     default: return fail(h, "device error %d", err[0]);
     }
 }
@@ -311,6 +318,11 @@ int launch_explore(pte_engine *h, int64_t scan) {
     const int64_t N = h->K;
     if ((h->cfg.record_flags & PTE_RECORD_TRACES) && h->scans_in_round >= h->cfg.max_scans_per_round)
         return fail(h, "traces buffer full: %lld scans since the last pte_reduce (max_scans_per_round = %lld)",
+                    (long long)h->scans_in_round, (long long)h->cfg.max_scans_per_round);
+    // the explore kernels write row `scans_in_round` of the step-size-search log too (PTE_RECORD_REFERENCE_REDUCTION with AutoMALA): refuse BEFORE the
+    // launch, not at the swap that follows it (the scan after max_scans_per_round wrote K * cap int16 past the end of am_log)
+    if (h->dev.am_log && h->scans_in_round >= h->cfg.max_scans_per_round)
+        return fail(h, "step-size-search log full: %lld scans since the last pte_reduce (max_scans_per_round = %lld)",
                     (long long)h->scans_in_round, (long long)h->cfg.max_scans_per_round);
     h->dev.trace_idx = h->scans_in_round;
     if (h->cfg.explorer2 == PTE_EXPLORER_NONE) { h->dev.compose_phase = 0; return launch_explorer_kind(h, scan, h->cfg.explorer); }
@@ -491,7 +503,8 @@ bool fused_scans_eligible(pte_engine *h, int64_t n_scans) {
     const int kind = fused_kind(h);
     if (kind == 0) return false;
     // a recorder buffer that would overflow inside the call: the launch-per-scan loop reports it at the scan that overflows, as before
-    if ((h->cfg.record_flags & (PTE_RECORD_TRACES | PTE_RECORD_INDEX_PROCESS)) && h->scans_in_round + n_scans > h->cfg.max_scans_per_round) return false;
+    if (((h->cfg.record_flags & (PTE_RECORD_TRACES | PTE_RECORD_INDEX_PROCESS | PTE_RECORD_REFERENCE_REDUCTION)) || h->dev.am_log || h->dev.swap_log) &&
+        h->scans_in_round + n_scans > h->cfg.max_scans_per_round) return false;
     if (h->fused_limit < 0) {
         int per_cu = 0, cus = 0;
         if (kind == 1) {
@@ -514,20 +527,42 @@ bool fused_scans_eligible(pte_engine *h, int64_t n_scans) {
             if (per_cu_wg >= 1 && h->K <= (int64_t)wgn * cus) { h->fused_wg = wgn; h->fused_limit = std::max(h->fused_limit, (int64_t)wgn * cus); }
         }
         if (h->fused_limit > 0 && h->K <= h->fused_limit && !h->hs_flag) {
-            if (dev_alloc(h, &h->hs_flag, (size_t)h->K) || dev_alloc(h, &h->hs_pub, (size_t)h->K * 8)) { h->fused_limit = 0; h->err.clear(); }
+            if (dev_alloc(h, &h->hs_flag, (size_t)h->K) || dev_alloc(h, &h->hs_pub, (size_t)h->K * 8) || dev_alloc(h, &h->hs_gate, 2)) { h->fused_limit = 0; h->hs_flag = nullptr; h->err.clear(); }
             else hipStreamSynchronize(h->stream);
         }
     }
     return h->K <= h->fused_limit && h->hs_flag != nullptr;
 }
 
+// the loop of rounds 1-4: explore and swap launched per scan
+int run_scans_two_launches(pte_engine *h, int64_t first_scan, int64_t n_scans) {
+    for (int64_t s = first_scan; s < first_scan + n_scans; ++s) {
+        if (launch_explore(h, s)) return 1;
+        if (launch_swap(h, s)) return 1;
+    }
+    int rc = check_device_error(h);
+    time_collect(h);
+    return rc;
+}
+
+// One launch for all the scans of the call.  The launch starts with the residency gate (pte_kernels.hpp scan_loop_gate): if a workgroup is
+// missing after 50 ms -- another engine, stream or process holds compute units -- every workgroup returns with NOTHING written, and the same
+// scans run here as explore + swap launches: the call cannot hang and its result is the same either way (the reference's loop,
+// src/pt/pigeons.jl:46-55, has no failure mode of this kind; neither has pte_run_scans).  After an abort the next calls skip the attempt (1, 2, 4, ...
+// 256 calls: the device is evidently shared), pte_scan_loop_stats counts both.  What the gate does not cover: a wave that dies or is
+// descheduled for more than 3 s AFTER every workgroup has arrived -- then the hand-shake times out, every other wave sees the error word and
+// leaves, the call fails and the engine is poisoned (chains stopped at different scans) until pte_set_state.
 int run_scans_fused(pte_engine *h, int64_t first_scan, int64_t n_scans) {
     const int64_t N = h->K;
-    ScanLoop sl{first_scan, n_scans, h->scans_in_round, h->hs_epoch, h->hs_flag, h->hs_pub};
+    const int kind = fused_kind(h);
+    const unsigned long long wgs = (unsigned long long)((kind == 2 && h->fused_wg > 1) ? (N + h->fused_wg - 1) / h->fused_wg : N);
+    h->gate_seq += 1;
+    ScanLoop sl{first_scan, n_scans, h->scans_in_round, h->hs_epoch, h->hs_flag, h->hs_pub, h->hs_gate, h->gate_seq, h->gate_arrived + wgs, h->test_fault};
+    h->gate_arrived += wgs;                  // (whatever the gate decides: every workgroup of the launch arrives before the kernel ends)
     h->dev.compose_phase = 0; h->dev.trace_idx = h->scans_in_round;
     time_begin(h, 4, true);
     const bool timed = h->ev_open;
-    if (fused_kind(h) == 1) {
+    if (kind == 1) {
         SliceParams sp{h->cfg.slice_w, h->cfg.slice_p, h->cfg.slice_n_passes, h->cfg.slice_max_iter};
         if (fused_slice_variant(h) == 0) { DISPATCH_NLU_M(h->nlu, k_scans_slice8, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, sl); }
         else { DISPATCH_NLU_M(h->nlu, k_scans_slice8_generic, PTE_S8_BS, dim3((unsigned)N), dim3(64), h->stream, h->dev, sp, sl); }
@@ -546,14 +581,45 @@ int run_scans_fused(pte_engine *h, int64_t first_scan, int64_t n_scans) {
         if (langevin_launch(L, h->dev, ap)) { time_end(h); return fail(h, "this build holds no fused Langevin-family kernel"); }
     }
     time_end(h);
-    if (timed) h->t_scans4 += n_scans;
     HIP_OK(h, hipGetLastError());
+    unsigned long long gate[2] = {0, 0};
+    HIP_OK(h, hipMemcpyAsync(gate, h->hs_gate, sizeof gate, hipMemcpyDeviceToHost, h->stream));
+    int rc = check_device_error(h);          // synchronises the stream: `gate` has landed too
+    if (gate[1] == ((h->gate_seq << 1) | 1ull)) {
+        // not every workgroup was resident within the bound: nothing has run.  The aborted launch is no sample of the scan loop's timing.
+        if (timed && !h->events.empty() && h->events.back().kernel == 4) {
+            h->ev_pool.push_back(h->events.back().a); h->ev_pool.push_back(h->events.back().b); h->events.pop_back();
+        }
+        h->gate_aborts += 1;
+        h->fused_backoff = h->fused_backoff ? std::min<int64_t>(256, 2 * h->fused_backoff) : 1;
+        h->fused_skip = h->fused_backoff;
+        if (rc) return rc;                   // (cannot happen: no workgroup has touched the error word)
+        return run_scans_two_launches(h, first_scan, n_scans);
+    }
+    if (gate[1] != (h->gate_seq << 1) || gate[0] != h->gate_arrived) {
+        h->poisoned = true;
+        return fail(h, "pte_run_scans: the scan loop's residency gate is inconsistent (decision %llu, arrivals %llu; expected %llu, %llu)",
+                    gate[1], gate[0], h->gate_seq << 1, h->gate_arrived);
+    }
+    h->fused_calls += 1; h->fused_backoff = 0;
+    if (timed) h->t_scans4 += n_scans;
     h->hs_epoch += (unsigned long long)n_scans;
     h->scans_in_round += n_scans;
-    int rc = check_device_error(h);
     time_collect(h);
+    if (rc) {
+        // a wave that hits an error leaves the loop, and so does every wave that then waits for it: the chains stand at different scans
+        h->poisoned = true;
+        h->err += "; the engine's replicas stopped at different scans and its recorders are void: only pte_set_state (state, chain and rng of every replica; "
+                  "it also discards the round's recorders) or pte_destroy are accepted now";
+    }
     return rc;
 }
+
+int poisoned_error(pte_engine *h, const char *what) {
+    return fail(h, "%s: this engine is poisoned -- an earlier pte_run_scans failed inside the one-launch scan loop, its replicas stopped at different scans; "
+                   "restore it with pte_set_state(state, chain, rng) or destroy it", what);
+}
+#define PTE_ALIVE(h, what) do { if ((h)->poisoned) return poisoned_error(h, what); } while (0)
 
 }  // namespace
 
@@ -608,7 +674,7 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
         return fail(nullptr, "pte_create: the funnel path is implemented for AutoMALA / MALA / SliceSampler (and Compose of them); use the reference CPU path");
     if ((uses_grad || funnel) && (cfg->dim < 1 || cfg->dim > 1024))
         return fail(nullptr, "pte_create: AutoMALA / MALA (and every explorer of the funnel path) keep the replica in registers, dim must be in 1..1024 (got %lld)", (long long)cfg->dim);
-    if (funnel && (cfg->debug_kernel & ~PTE_KERNEL_FLAG_BITS) != 0)
+    if (funnel && (cfg->debug_kernel & ~(PTE_KERNEL_FLAG_BITS | PTE_KERNEL_TEST_BITS)) != 0)
         return fail(nullptr, "pte_create: debug_kernel %d is not available on the funnel path (one register-resident kernel serves it)", cfg->debug_kernel);
     if (cfg->explorer2 != PTE_EXPLORER_NONE) {           // Compose(first, second)
         auto composable = [&](int k) { return k == PTE_EXPLORER_SLICE || grad_based(k); };
@@ -629,8 +695,12 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
         if ((double)cfg->max_scans_per_round * (double)(cfg->n_chains + cfg->n_chains_variational) * 16.0 > 64e9)
             return fail(nullptr, "pte_create: the swap log (max_scans_per_round x chains x 2 doubles) would exceed 64 GB");
     }
+#ifndef PTE_TEST_KERNELS
+    if (cfg->debug_kernel & PTE_KERNEL_TEST_BITS)
+        return fail(nullptr, "pte_create: debug_kernel 0x%x carries a fault-injection flag (PTE_KERNEL_TEST_*); those exist in the test build libpte_test.so only", cfg->debug_kernel);
+#endif
     {   // debug_kernel: 0 = the default kernel of the explorer; anything else must exist in THIS build (no silent fall-through)
-        const int dk = cfg->debug_kernel & ~PTE_KERNEL_FLAG_BITS;      // (the flag bit chooses the scan loop's form, not the kernel generation)
+        const int dk = cfg->debug_kernel & ~(PTE_KERNEL_FLAG_BITS | PTE_KERNEL_TEST_BITS);      // (the flag bit chooses the scan loop's form, not the kernel generation)
         const bool slice = cfg->explorer == PTE_EXPLORER_SLICE || cfg->explorer2 == PTE_EXPLORER_SLICE;
         bool ok = dk == 0 || (slice && dk == PTE_KERNEL_SLICE_SEQUENTIAL) || (ising && dk == PTE_KERNEL_ISING_BYTES);
 #ifdef PTE_TEST_KERNELS
@@ -661,9 +731,10 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     const int64_t B = (d + 63) / 64;
     h->nlu = next_pow2_log(B > 0 ? B : 1);
     // pte_config.debug_kernel (validated above): which kernel generation explores; never read from the environment
-    const int dk_kernel = cfg->debug_kernel & ~PTE_KERNEL_FLAG_BITS;
+    const int dk_kernel = cfg->debug_kernel & ~(PTE_KERNEL_FLAG_BITS | PTE_KERNEL_TEST_BITS);
     h->fused_allowed = (cfg->debug_kernel & PTE_KERNEL_TWO_LAUNCHES) == 0;
     h->fused_wg_allowed = (cfg->debug_kernel & PTE_KERNEL_SCAN_LOOP_ONE_CHAIN) == 0;
+    h->test_fault = (cfg->debug_kernel & PTE_KERNEL_TEST_DEAD_CHAIN) ? 1 : ((cfg->debug_kernel & PTE_KERNEL_TEST_LATE_WORKGROUP) ? 2 : 0);
     if (cfg->explorer == PTE_EXPLORER_SLICE || cfg->explorer2 == PTE_EXPLORER_SLICE) h->slice_impl = dk_kernel == 0 ? 8 : dk_kernel;
     if (cfg->explorer == PTE_EXPLORER_ISING_METROPOLIS) h->ising_impl = dk_kernel == PTE_KERNEL_ISING_BITS ? 1 : (dk_kernel == PTE_KERNEL_ISING_BYTES ? 2 : 0);
     EngineDev &e = h->dev;
@@ -830,6 +901,7 @@ int pte_destroy(pte_engine *h) {
 
 int pte_set_schedule(pte_engine *h, const double *betas, int64_t n) {
     if (!h || !betas) return 1;
+    PTE_ALIVE(h, "pte_set_schedule");
     if (n != h->N) return fail(h, "pte_set_schedule: expected %lld grid points, got %lld", (long long)h->N, (long long)n);
     // Schedule constructor asserts (reference src/schedules/Schedule.jl:14-27)
     auto check_leg = [&](const double *b, int64_t m, int64_t stride) -> bool {   // grid of one leg, reference -> target
@@ -855,6 +927,7 @@ int pte_get_schedule(const pte_engine *h, double *betas) {
 
 int pte_set_explorer_adaptation(pte_engine *h, double step_size, const double *target_std, int64_t dim) {
     if (!h) return 1;
+    PTE_ALIVE(h, "pte_set_explorer_adaptation");
     {   // nothing to adapt for SliceSampler / ToyExplorer
         auto gb = [](int k) { return k == PTE_EXPLORER_AUTOMALA || k == PTE_EXPLORER_MALA; };
         if (!gb(h->cfg.explorer) && !gb(h->cfg.explorer2)) return 0;
@@ -873,6 +946,7 @@ int pte_set_explorer_adaptation(pte_engine *h, double step_size, const double *t
 
 int pte_explore(pte_engine *h, int64_t scan) {
     if (!h) return 1;
+    PTE_ALIVE(h, "pte_explore");
     HIP_OK(h, hipSetDevice(h->cfg.device));
     if (launch_explore(h, scan)) return 1;
     return check_device_error(h);
@@ -880,6 +954,7 @@ int pte_explore(pte_engine *h, int64_t scan) {
 
 int pte_swap(pte_engine *h, int64_t scan) {
     if (!h) return 1;
+    PTE_ALIVE(h, "pte_swap");
     HIP_OK(h, hipSetDevice(h->cfg.device));
     if (launch_swap(h, scan)) return 1;
     return check_device_error(h);
@@ -888,15 +963,13 @@ int pte_swap(pte_engine *h, int64_t scan) {
 int pte_run_scans(pte_engine *h, int64_t first_scan, int64_t n_scans) {
     if (!h) return 1;
     HIP_OK(h, hipSetDevice(h->cfg.device));
+    PTE_ALIVE(h, "pte_run_scans");
     if (h->world != 1) return run_scans_sharded(h, first_scan, n_scans);
-    if (fused_scans_eligible(h, n_scans)) return run_scans_fused(h, first_scan, n_scans);
-    for (int64_t s = first_scan; s < first_scan + n_scans; ++s) {
-        if (launch_explore(h, s)) return 1;
-        if (launch_swap(h, s)) return 1;
+    if (fused_scans_eligible(h, n_scans)) {
+        if (h->fused_skip > 0) h->fused_skip -= 1;         // a recent launch found the device shared: not this call (run_scans_fused)
+        else return run_scans_fused(h, first_scan, n_scans);
     }
-    int rc = check_device_error(h);
-    time_collect(h);
-    return rc;
+    return run_scans_two_launches(h, first_scan, n_scans);
 }
 
 // PTE_RECORD_REFERENCE_REDUCTION: swap_acceptance_pr and log_sum_ratio reduced as the reference reduces them.  There every REPLICA owns a
@@ -1028,6 +1101,7 @@ static int reference_reduce(pte_engine *h, Snapshot &s) {
 
 int pte_reduce(pte_engine *h) {
     if (!h) return 1;
+    PTE_ALIVE(h, "pte_reduce");
     HIP_OK(h, hipSetDevice(h->cfg.device));
     const int64_t K = h->K, d = h->d;
     EngineDev &e = h->dev;
@@ -1205,6 +1279,7 @@ int pte_get_replica_ids(const pte_engine *hc, int64_t *out) {
 // ---- two-phase swap of chain-sharded engines ---------------------------------------------------
 int pte_swap_begin(pte_engine *h, int64_t scan, double *stats_out, int32_t *active_out) {
     if (!h || !stats_out || !active_out) return 1;
+    PTE_ALIVE(h, "pte_swap_begin");
     HIP_OK(h, hipSetDevice(h->cfg.device));
     const int64_t K = h->K;
     if ((h->cfg.record_flags & PTE_RECORD_INDEX_PROCESS) && h->scans_in_round >= h->cfg.max_scans_per_round)
@@ -1223,6 +1298,7 @@ int pte_swap_begin(pte_engine *h, int64_t scan, double *stats_out, int32_t *acti
 }
 int pte_swap_finish(pte_engine *h, int64_t scan, const double *nbr_stats, int32_t *accepted_out) {
     if (!h || !nbr_stats || !accepted_out) return 1;
+    PTE_ALIVE(h, "pte_swap_finish");
     HIP_OK(h, hipSetDevice(h->cfg.device));
     const int64_t K = h->K;
     const int even = (scan % 2 == 0) ? 1 : 0;
@@ -1245,6 +1321,7 @@ int pte_swap_finish(pte_engine *h, int64_t scan, const double *nbr_stats, int32_
 int64_t pte_boundary_payload_bytes(const pte_engine *h) { return h ? (int64_t)sizeof(double) * (h->dev.sw + 6) : 0; }
 int pte_boundary_export(pte_engine *h, int side, void *dst, int dst_is_device) {
     if (!h || !dst || side < 0 || side > 1) return 1;
+    PTE_ALIVE(h, "pte_boundary_export");
     HIP_OK(h, hipSetDevice(h->cfg.device));
     double *buf = dst_is_device ? (double *)dst : h->d_payload;
     hipLaunchKernelGGL(k_boundary_export, dim3(1), dim3(256), 0, h->stream, h->dev, side, buf);
@@ -1256,6 +1333,7 @@ int pte_boundary_export(pte_engine *h, int side, void *dst, int dst_is_device) {
 }
 int pte_boundary_import(pte_engine *h, int side, const void *src, int src_is_device) {
     if (!h || !src || side < 0 || side > 1) return 1;
+    PTE_ALIVE(h, "pte_boundary_import");
     HIP_OK(h, hipSetDevice(h->cfg.device));
     const double *buf = (const double *)src;
     if (!src_is_device) {
@@ -1279,6 +1357,7 @@ int pte_shard_set_buffers(pte_engine *h, void *send_lo, void *recv_lo, void *sen
 }
 int pte_shard_scan_begin(pte_engine *h, int64_t scan, int32_t *active_out) {
     if (!h || !active_out) return 1;
+    PTE_ALIVE(h, "pte_shard_scan_begin");
     HIP_OK(h, hipSetDevice(h->cfg.device));
     if (!h->msg_send[0] || !h->msg_recv[0] || !h->msg_send[1] || !h->msg_recv[1])
         return fail(h, "pte_shard_scan_begin: call pte_shard_set_buffers first");
@@ -1300,6 +1379,7 @@ int pte_shard_scan_begin(pte_engine *h, int64_t scan, int32_t *active_out) {
 }
 int pte_shard_scan_finish(pte_engine *h, int64_t scan) {
     if (!h) return 1;
+    PTE_ALIVE(h, "pte_shard_scan_finish");
     HIP_OK(h, hipSetDevice(h->cfg.device));
     const int64_t K = h->K;
     const int even = (scan % 2 == 0) ? 1 : 0;
@@ -1323,6 +1403,7 @@ int pte_shard_scan_finish(pte_engine *h, int64_t scan) {
 }
 int pte_shard_sync(pte_engine *h, int64_t *boundary_swaps_out) {
     if (!h) return 1;
+    PTE_ALIVE(h, "pte_shard_sync");
     HIP_OK(h, hipSetDevice(h->cfg.device));
     int rc = check_device_error(h);                     // synchronises the engine's stream
     time_collect(h);
@@ -1605,6 +1686,14 @@ int pte_scan_loop_info(const pte_engine *hc, int64_t *resident_limit, int64_t *t
     return 0;
 }
 
+int pte_scan_loop_stats(const pte_engine *h, int64_t *fused_calls, int64_t *gate_aborts, int32_t *poisoned) {
+    if (!h) return 1;
+    if (fused_calls) *fused_calls = h->fused_calls;
+    if (gate_aborts) *gate_aborts = h->gate_aborts;
+    if (poisoned) *poisoned = h->poisoned ? 1 : 0;
+    return 0;
+}
+
 namespace {
 int refresh_funnel_stats(pte_engine *h) {
     const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
@@ -1621,6 +1710,7 @@ int refresh_funnel_stats(pte_engine *h) {
 // the chains with uses[c] != 0 run InterpolatingPath(GaussianReference(mean, std), target).  mean = std = NULL deactivates.
 int pte_set_variational_reference(pte_engine *h, const double *mean, const double *std_dev, int64_t dim, const int32_t *uses) {
     if (!h) return 1;
+    PTE_ALIVE(h, "pte_set_variational_reference");
     HIP_OK(h, hipSetDevice(h->cfg.device));
     EngineDev &e = h->dev;
     if (!mean || !std_dev || !uses) { e.v_use = nullptr; return 0; }
@@ -1650,6 +1740,7 @@ int pte_set_variational_reference(pte_engine *h, const double *mean, const doubl
 int pte_get_state(const pte_engine *hc, double *state, int64_t *chain, uint64_t *rng) {
     pte_engine *h = const_cast<pte_engine *>(hc);
     if (!h) return 1;
+    PTE_ALIVE(h, "pte_get_state");
     HIP_OK(h, hipSetDevice(h->cfg.device));
     const int64_t N = h->K, d = h->d;
     const bool ising = h->cfg.target == PTE_TARGET_ISING;
@@ -1677,6 +1768,20 @@ int pte_set_state(pte_engine *h, const double *state, const int64_t *chain, cons
     if (!h) return 1;
     HIP_OK(h, hipSetDevice(h->cfg.device));
     const int64_t N = h->K, d = h->d;
+    if (h->poisoned) {
+        // the one way back after a failure inside the one-launch scan loop: every field of every replica replaced, the round's recorders
+        // discarded, the hand-shake flags re-based to the epochs handed out so far ("every chain has published everything up to now")
+        if ((!state && d > 0) || !chain || !rng) return fail(h, "pte_set_state: a poisoned engine needs state, chain and rng of every replica");
+        HIP_OK(h, hipStreamSynchronize(h->stream));
+        HIP_OK(h, hipMemsetAsync(h->dev.error, 0, 4 * sizeof(int32_t), h->stream));
+        if (h->hs_flag) {
+            std::vector<unsigned long long> fl((size_t)N, h->hs_epoch);
+            HIP_OK(h, hipMemcpyAsync(h->hs_flag, fl.data(), sizeof(unsigned long long) * N, hipMemcpyHostToDevice, h->stream));
+            HIP_OK(h, hipStreamSynchronize(h->stream));
+        }
+        if (reset_recorders(h)) return 1;
+        h->poisoned = false;
+    }
     std::vector<uint32_t> packed;
     if (state && d > 0 && h->cfg.target == PTE_TARGET_ISING) {
         packed.assign((size_t)(N * h->dev.ld * 2), 0u);

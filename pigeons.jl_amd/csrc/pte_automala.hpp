@@ -672,6 +672,9 @@ template <int E, int TGT, bool FULL>
 __global__ __launch_bounds__(64) void k_scans_automala(EngineDev e, AmParams ap, ScanLoop sl) {
     const int lane = lane_id();
     const int64_t cl = am_chain_of_workgroup(e.K, blockIdx.x);
+    int go = 1;
+    if (lane == 0) go = scan_loop_gate(sl) ? 1 : 0;        // every workgroup of the launch is resident, or nobody starts (pte_kernels.hpp)
+    if (!__builtin_amdgcn_readfirstlane(go)) return;
     for (int64_t i = 0; i < sl.n_scans; ++i) {
 #ifndef PTE_TEST_NO_E_COPY
         e.trace_idx = sl.scan_idx0 + i;
@@ -708,10 +711,13 @@ template <int E, int TGT, bool FULL>
 __global__ __launch_bounds__(64 * PTE_SCAN_WG) void k_scans_automala_wg(EngineDev e, AmParams ap, ScanLoop sl) {
     constexpr int NW = PTE_SCAN_WG;
     __shared__ ScanWg<NW> wg;
+    __shared__ int wg_go;
     const int lane = lane_id();
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (threadIdx.x < NW) wg.flag[threadIdx.x] = sl.epoch0;          // "has published every epoch up to the last call's"
+    if (threadIdx.x == 0) wg_go = scan_loop_gate(sl) ? 1 : 0;        // every workgroup of the launch is resident, or nobody starts (pte_kernels.hpp)
     __syncthreads();
+    if (!wg_go) return;
 #if PTE_AM_WG_PERMUTE       // the per-scan kernel's stride permutation, over the GROUPS: neighbouring groups do similar work (the slow chains sit next to the reference)
     const int64_t G = (e.K + NW - 1) / NW;
     const int64_t cl = am_chain_of_workgroup(G, blockIdx.x) * NW + w;

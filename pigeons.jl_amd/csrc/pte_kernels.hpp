@@ -571,10 +571,58 @@ enum { ERR_HANDSHAKE_TIMEOUT = 9 };
 struct ScanLoop {
     int64_t first_scan, n_scans;       // scan numbers first_scan .. first_scan + n_scans - 1 (DEO parity = iseven(scan); AutoMALA's scan == 1 rule)
     int64_t scan_idx0;                 // scans of this round already run: row of index_process / traces the first scan writes
-    unsigned long long epoch0;         // hand-shake epochs of this call: epoch0 + 1 .. epoch0 + n_scans (monotone over the engine's life, never reset)
+    unsigned long long epoch0;         // hand-shake epochs of this call: epoch0 + 1 .. epoch0 + n_scans (monotone over the engine's life; re-based by pte_set_state only)
     unsigned long long *flag;          // [K] the last epoch chain c has published
     double *pub;                       // [K][2][4] {log ratio, uniform, slot, -} of chain c, double-buffered by the epoch's parity
+    // the residency gate (round 6, scan_loop_gate below): gate[0] = workgroups of scan-loop launches that have arrived so far (monotone),
+    // gate[1] = the decision word, (launch number << 1) | aborted
+    unsigned long long *gate;
+    unsigned long long gate_seq;       // this launch's number, 1, 2, ... (monotone over the engine's life)
+    unsigned long long gate_target;    // gate[0] once every workgroup of this launch has arrived
+    int test_fault;                    // 0; test build only (PTE_KERNEL_TEST_*): 1 = the wave of chain 7 dies before its third publish, 2 = workgroup 3 arrives 80 ms late
 };
+
+// ---------------------------------------------------------------------------------------------
+// The residency gate: forward progress of the scan loop, ENFORCED (round 6; the reference's loop, src/pt/pigeons.jl:46-55, cannot hang).
+// The hand-shakes below spin, so every workgroup of the launch must be on the device at once.  Rounds 5 inferred that from an occupancy query,
+// which knows nothing of another engine, stream or process holding compute units.  Now no workgroup touches anything before ALL of them have
+// ARRIVED: each adds one to gate[0]; the one that completes the count proposes "go", a workgroup that has waited PTE_GATE_TICKS (50 ms on the
+// 100 MHz clock) proposes "abort"; whichever compare-and-swap on the decision word lands first decides for the whole launch, late arrivals
+// included -- so all workgroups agree.  go: every workgroup holds its wave slots until the kernel ends (a resident wave is not descheduled in
+// favour of another queue's work), the spins cannot starve.  abort: every workgroup returns at once, NOTHING has been written (states, streams,
+// recorders, epochs as before the call) and the host runs the same scans as explore + swap launches (pte.hip, run_scans_fused).
+// One relaxed atomic add + a few polls per workgroup and launch: 2-4 us at 1024 workgroups (profiles/r06_gate_cost.txt).
+// ---------------------------------------------------------------------------------------------
+#ifndef PTE_GATE_TICKS
+#define PTE_GATE_TICKS 5000000ull
+#endif
+__device__ __forceinline__ bool scan_loop_gate_decide(unsigned long long *dec, unsigned long long seq, unsigned long long proposal) {
+    unsigned long long cur = __hip_atomic_load(dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while ((cur >> 1) < seq) {      // nobody has decided this launch yet
+        if (__hip_atomic_compare_exchange_strong(dec, &cur, proposal, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { cur = proposal; break; }
+    }
+    return cur == (seq << 1);
+}
+// called by ONE lane per workgroup; true = go
+__device__ __forceinline__ bool scan_loop_gate(const ScanLoop &sl) {
+    unsigned long long *cnt = sl.gate, *dec = sl.gate + 1;
+    const unsigned long long go = sl.gate_seq << 1;
+#ifdef PTE_TEST_KERNELS
+    if (sl.test_fault == 2 && blockIdx.x == 3) {           // a workgroup the dispatcher could not place for 80 ms
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < 8000000ull) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
+    const unsigned long long before = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (before + 1ull == sl.gate_target) return scan_loop_gate_decide(dec, sl.gate_seq, go);
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const unsigned long long cur = __hip_atomic_load(dec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((cur >> 1) >= sl.gate_seq) return cur == go;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > PTE_GATE_TICKS) return scan_loop_gate_decide(dec, sl.gate_seq, go | 1ull);
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
 
 // Which chain a workgroup of the scan loop holds.  Observed (not promised by HIP): consecutive workgroups are dealt round-robin over the 8
 // XCDs, workgroup b runs on XCD b mod 8, and each XCD has its own L2.  Dealing the chains out the other way round -- workgroup b holds chain
@@ -592,15 +640,20 @@ __device__ __forceinline__ int64_t scan_loop_group(int64_t G) {
     return g * q + (g < r ? g : r) + j;
 }
 
-__device__ __forceinline__ bool hs_wait(const unsigned long long *p, unsigned long long want) {
+// Wait for *p >= want.  false: give up -- 3 s have passed, or ANOTHER chain has already failed (the engine's error word is polled every
+// 16th spin, round 6: a broken launch ends when its first wave gives up, not after every blocked wave's own 3 s).
+__device__ __forceinline__ bool hs_wait(const unsigned long long *p, unsigned long long want, const int32_t *err) {
     if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    for (;;) {
+    for (unsigned spin = 1;; ++spin) {
 #ifndef PTE_HS_MEASURE_NO_SLEEP
         __builtin_amdgcn_s_sleep(8);
 #endif
         if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) return false;
+        if ((spin & 15u) == 0u) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) return false;
+        }
     }
 }
 
@@ -612,13 +665,16 @@ __device__ __forceinline__ bool hs_wait(const unsigned long long *p, unsigned lo
 // agent-scope hand-off below.  Every chain keeps BOTH of its flags (LDS and global) current every scan: the partner of the next scan looks
 // at the one it shares with this chain.
 template <int NW> struct ScanWg { unsigned long long flag[NW]; double pub[NW][2][4]; };
-__device__ __forceinline__ bool hs_wait_lds(unsigned long long *p, unsigned long long want) {
+__device__ __forceinline__ bool hs_wait_lds(unsigned long long *p, unsigned long long want, const int32_t *err) {
     if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) return true;
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    for (;;) {
+    for (unsigned spin = 1;; ++spin) {
         __builtin_amdgcn_s_sleep(1);
         if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) return true;
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) return false;
+        if ((spin & 63u) == 0u) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) return false;
+        }
     }
 }
 template <int NW = 1>
@@ -628,6 +684,10 @@ __device__ __forceinline__ int swap_handshake(const EngineDev &e, const ScanLoop
     const int64_t scan_idx = sl.scan_idx0 + i;
     const unsigned long long epoch = sl.epoch0 + 1ull + (unsigned long long)i;
     const int64_t pc = deo_partner(N, even, c);
+    if (__hip_atomic_load(e.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return -1;   // a chain has failed: the call is lost, leave (round 6)
+#ifdef PTE_TEST_KERNELS
+    if (sl.test_fault == 1 && c == 7 && i == 2) return -1;                // test build: this wave dies silently -- its partner must time out, everybody else must leave early
+#endif
     double lr = 0.0;
     if (e.target != 1) {
         lr = swap_log_ratio(e, slot, c, pc);
@@ -658,7 +718,7 @@ __device__ __forceinline__ int swap_handshake(const EngineDev &e, const ScanLoop
     if (near) {
         if constexpr (NW > 1) {
             const int w = (int)(c % NW), pw = (int)(pc % NW), par = (int)(epoch & 1ull);
-            if (!hs_wait_lds(&wg->flag[pw], epoch - 1ull)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
+            if (!hs_wait_lds(&wg->flag[pw], epoch - 1ull, e.error)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
             __hip_atomic_store(&wg->pub[w][par][0], lr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(&wg->pub[w][par][1], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(&wg->pub[w][par][2], (double)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -666,7 +726,7 @@ __device__ __forceinline__ int swap_handshake(const EngineDev &e, const ScanLoop
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // this wave's row / statistics stores have reached the L2 (through the L1 both waves share)
             __hip_atomic_store(&wg->flag[w], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __hip_atomic_store(&sl.flag[c], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (for the partner of the next scan, if it lives in another workgroup)
-            if (!hs_wait_lds(&wg->flag[pw], epoch)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
+            if (!hs_wait_lds(&wg->flag[pw], epoch, e.error)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             lr_p = __hip_atomic_load(&wg->pub[pw][par][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             u_p = __hip_atomic_load(&wg->pub[pw][par][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -674,7 +734,7 @@ __device__ __forceinline__ int swap_handshake(const EngineDev &e, const ScanLoop
         }
     } else {
     double *mine = sl.pub + ((c * 2 + (int64_t)(epoch & 1ull)) * 4);
-    if (!hs_wait(&sl.flag[pc], epoch - 1ull)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
+    if (!hs_wait(&sl.flag[pc], epoch - 1ull, e.error)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
     // {log ratio, uniform, slot}: device-coherent (sc1) stores / loads.  Then the hand-off proper, the form MI355X_MICROARCH.md
     // ("Workgroup dispatch, XCD placement & inter-workgroup visibility") prescribes for plain payload stores: producer = agent-scope release
     // (buffer_wbl2 sc1: the XCD's dirty L2 lines -- the state row this wave has just written -- reach memory) + an explicit s_waitcnt vmcnt(0)
@@ -686,13 +746,13 @@ __device__ __forceinline__ int swap_handshake(const EngineDev &e, const ScanLoop
     __hip_atomic_store(&mine[2], (double)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef PTE_HS_MEASURE_NO_FENCE     // measurement builds only (not coherent: wrong results): what the L2 write-back / L1 invalidate cost
     __hip_atomic_store(&sl.flag[c], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!hs_wait(&sl.flag[pc], epoch)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
+    if (!hs_wait(&sl.flag[pc], epoch, e.error)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
 #else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&sl.flag[c], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if constexpr (NW > 1) __hip_atomic_store(&wg->flag[c % NW], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (for the partner of the next scan: a wave of this workgroup)
-    if (!hs_wait(&sl.flag[pc], epoch)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
+    if (!hs_wait(&sl.flag[pc], epoch, e.error)) { set_error(e, ERR_HANDSHAKE_TIMEOUT, (int)c, -1); return -1; }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #endif
     const double *theirs = sl.pub + ((pc * 2 + (int64_t)(epoch & 1ull)) * 4);

@@ -790,6 +790,9 @@ template <int NLU, int S8_BS, int WINDOW, int DBL_MODE>
 __device__ __forceinline__ void slice8_scan_loop(EngineDev e, const SliceParams &sp, const ScanLoop &sl) {
     const int lane = lane_id();
     const int64_t cl = scan_loop_chain(e.K);               // XCD-aware: consecutive chains share an L2 (pte_kernels.hpp)
+    int go = 1;
+    if (lane == 0) go = scan_loop_gate(sl) ? 1 : 0;        // every workgroup of the launch is resident, or nobody starts (pte_kernels.hpp)
+    if (!__builtin_amdgcn_readfirstlane(go)) return;
     for (int64_t i = 0; i < sl.n_scans; ++i) {
         e.trace_idx = sl.scan_idx0 + i;
         slice8_body<NLU, S8_BS, WINDOW, DBL_MODE>(e, sp, cl);

@@ -26,6 +26,7 @@ ABI_VERSION = 2
 KERNEL_DEFAULT, KERNEL_SLICE_SEQUENTIAL, KERNEL_ISING_BITS, KERNEL_ISING_BYTES = 0, 1, 101, 102
 KERNEL_SCAN_LOOP_ONE_CHAIN = 0x2000     # flag: the one-kernel scan loop with ONE chain per workgroup even where the form with several (LDS hand-shakes) exists
 KERNEL_FLAG_BITS = 0x3000
+KERNEL_TEST_DEAD_CHAIN, KERNEL_TEST_LATE_WORKGROUP, KERNEL_TEST_BITS = 0x4000, 0x8000, 0xC000     # fault injection into the one-kernel scan loop: libpte_test.so only
 KERNEL_TWO_LAUNCHES = 0x1000            # flag: explore + swap launched per scan even where pte_run_scans could be one kernel (pte_scan_loop_name)
 COMM_ID_BYTES = 128
 RNG_TAIL_LOG1P = 1                      # include/pte_rng_policy.h
@@ -76,7 +77,7 @@ EXPORTS = [
     "pte_get_online_log_density", "pte_get_energy_ac1", "pte_get_traces", "pte_set_variational_reference",
     "pte_comm_allow_library_override", "pte_comm_library", "pte_comm_unique_id", "pte_comm_init", "pte_comm_destroy", "pte_comm_info", "pte_comm_barrier",
     "pte_comm_allreduce", "pte_comm_allgather", "pte_group_run_scans", "pte_kernel_name",
-    "pte_set_rng_policy", "pte_get_rng_policy", "pte_scan_loop_name", "pte_scan_loop_info",
+    "pte_set_rng_policy", "pte_get_rng_policy", "pte_scan_loop_name", "pte_scan_loop_info", "pte_scan_loop_stats",
 ]
 
 _libs = {}
@@ -177,6 +178,7 @@ def load(path=None):
     L.pte_scan_loop_name.argtypes = [vp]
     L.pte_scan_loop_name.restype = C.c_char_p
     L.pte_scan_loop_info.argtypes = [vp, ip, ip, ip]
+    L.pte_scan_loop_stats.argtypes = [vp, ip, ip, i32p]
     for name in EXPORTS:
         if name not in ("pte_last_error", "pte_boundary_payload_bytes", "pte_get_stream", "pte_shard_message_bytes", "pte_kernel_name", "pte_scan_loop_name"):
             getattr(L, name).restype = C.c_int

@@ -234,6 +234,15 @@ class Engine:
         self._chk(self.L.pte_scan_loop_info(self.h, _ip(a), _ip(b), _ip(c)))
         return int(a[0]), int(b[0]), int(c[0])
 
+
+    def scan_loop_stats(self):
+        """(fused_calls, gate_aborts, poisoned): run_scans calls that ran as ONE launch; launches whose residency gate found a workgroup
+        missing (the call then ran as explore + swap launches, same results); whether a failure inside the one-launch loop has poisoned
+        the engine (only set_state / close are accepted then) -- pte_scan_loop_stats"""
+        a = np.zeros(1, dtype=np.int64); b = np.zeros(1, dtype=np.int64); c = np.zeros(1, dtype=np.int32)
+        self._chk(self.L.pte_scan_loop_stats(self.h, _ip(a), _ip(b), c.ctypes.data_as(C.POINTER(C.c_int32))))
+        return int(a[0]), int(b[0]), bool(c[0])
+
     def explorer_stats(self):
         am = np.zeros(self.K); ss = np.zeros(self.K)
         an = np.zeros(self.K, dtype=np.int64); sn = np.zeros(self.K, dtype=np.int64)

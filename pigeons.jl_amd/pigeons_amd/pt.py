@@ -393,7 +393,7 @@ class PT:
         make = engine_factory or Engine
         if debug_kernel:
             kw.update(debug_kernel=debug_kernel)
-            if (debug_kernel & ~_lib.KERNEL_FLAG_BITS) not in (0, _lib.KERNEL_SLICE_SEQUENTIAL, _lib.KERNEL_ISING_BYTES):
+            if (debug_kernel & ~(_lib.KERNEL_FLAG_BITS | _lib.KERNEL_TEST_BITS)) not in (0, _lib.KERNEL_SLICE_SEQUENTIAL, _lib.KERNEL_ISING_BYTES) or (debug_kernel & _lib.KERNEL_TEST_BITS):
                 kw.update(test_build=True)              # the dominated generations live in libpte_test.so only
         self.shards = None
         if n_shards > 1:
