@@ -34,6 +34,7 @@ for p in (ROOT, os.path.join(ROOT, "pigeons.jl_amd"), os.path.join(ROOT, "tests"
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0    # ... and the measured float4-copy rate the guide quotes (SURVEY.md 8(d) prices against both)
+NRM_OCCUPANCY = 5              # waves per SIMD of k_explore_toy / k_init (96 VGPRs, 31 KB of LDS per 4-wave workgroup: profiles/r05_kernel_resources.txt)
 
 
 def parse_args():
@@ -194,6 +195,14 @@ def hbm_kernels(P):
         gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         out[name] = {"bytes_per_launch": nbytes, "avg_launch_us": ms * 1e3, "GBps": gbs,
                      "frac_of_6.29TBps": gbs / HBM_ACHIEVABLE_GBS, "frac_of_8TBps": gbs / HBM_PEAK_GBS}
+    # the two floors of k_explore_toy: HBM -- the bytes at the achievable rate -- and ISSUE -- the model fitted
+    # to tools/ubench/normals_dev.hip, T(k) = 27 + 5 k us for k rows sharing a SIMD: a row costs its SIMD 5 us of issue slots (8 rows: 40 us, at the
+    # HBM floor) and 27 us is one wave's dependency chain, paid once per GENERATION of co-resident waves (occupancy_waves_per_simd of them at a time)
+    rows_per_simd = N / 1024.0
+    out["k_explore_toy"]["floors"] = {"hbm_us_at_6.29TBps": (8 * d + 32) * N / (HBM_ACHIEVABLE_GBS * 1e9) * 1e6, "hbm_us_at_8TBps": (8 * d + 32) * N / (HBM_PEAK_GBS * 1e9) * 1e6,
+                                      "rows_per_simd": rows_per_simd, "issue_us_per_row": 5.0, "issue_us": 5.0 * rows_per_simd,
+                                      "dependency_chain_us_per_generation": 27.0, "occupancy_waves_per_simd": NRM_OCCUPANCY,
+                                      "model": "T(k) = 27 + 5 k us for k rows of d = 4096 sharing a SIMD (DESIGN.md 4.1, tools/ubench/normals_dev.hip)"}
     out["k_init"]["launch_us_of_6_constructions"] = [m * 1e3 for m in init_all]      # avg_launch_us is the MEAN of the five fastest (the slowest first-touches fresh memory) ...
     out["k_init"]["min_launch_us"] = min(init_all) * 1e3                              # ... the minimum is reported separately, not as the average
     out["k_init"]["GBps_at_min_launch"] = (8 * d + 32) * N / (min(init_all) * 1e-3) / 1e9
@@ -269,38 +278,88 @@ def invariance_check(P, d, total_chains, explorer_name, rank, world, local_rank,
     return agree(ok)
 
 
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X datasheet, FP64 vector: 256 CUs x 128 flop / clk x 2.4 GHz; a wave64 FP64 op occupies its SIMD's VALU for 4 cycles
+
+
+def extra_config_list(P):
+    """The other BASELINE configs at their per-GPU shapes + the 1-GPU anchor of the strong-scaling clause:
+    (key, description, Inputs factory, preparation rounds, timed scans, algorithmic HBM bytes per replica and scan).
+    Bytes: explore 16 d + 32 (state in / out + rng) and swap 96; Ising: the 8 KiB bit-packed lattice in / out + 128."""
+    rec = [P.round_trip, P.log_sum_ratio]
+    mvn = lambda d: 16 * d + 32 + 96
+    return [
+        ("C1", "C1 toy_mvn_target(2), n_chains=10, SliceSampler (the reference's quickstart: launch bound)", lambda: P.Inputs(target=P.toy_mvn_target(2), n_chains=10, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 5, 256, mvn(2)),
+        ("C2", "C2 toy_mvn_target(1024), n_chains=256, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(1024), n_chains=256, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 3, 16, mvn(1024)),
+        ("C3", "C3 funnel d=128, n_chains=1024, AutoMALA", lambda: P.Inputs(target=P.Funnel(128), reference=P.ScaledPrecisionNormalLogPotential(1 / 9., 128), n_chains=1024, explorer=P.AutoMALA(), record=rec, n_rounds=8, show_report=False), 6, 128, mvn(128)),
+        ("C4_shard", "C4 shard: toy_mvn_target(4096), 1024 of 8192 chains, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(4096), n_chains=1024, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 2, 8, mvn(4096)),
+        ("C4_one_gpu", "C4 on ONE GPU (strong-scaling anchor): toy_mvn_target(4096), n_chains=8192, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(4096), n_chains=8192, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 1, 4, mvn(4096)),
+        ("C5_shard", "C5 shard: Ising 256x256, 512 of 4096 chains, IsingMetropolis(3 sweeps)", lambda: P.Inputs(target=P.IsingLogPotential(1.0, 256), n_chains=512, record=rec, n_rounds=8, show_report=False), 2, 8, 2 * 8192 + 128),
+    ]
+
+
+def run_extra_config(P, cfg, static=None, repeats=1):
+    """One entry of extra_configs: prepared as a run in progress -- rounds 1 .. r of the algorithm itself (2, 4, ... 2^r scans, reduce +
+    adaptation after each: schedule; AutoMALA: step size and preconditioner) -- then `scans` scans timed by the wall clock around pte_run_scans
+    (ms_per_scan, no HIP events in the stream) and the same scans once more with HIP events on every kernel launch (hipExtLaunchKernelGGL:
+    the kernels' own begin / end): the kernel time per scan behind `roofline`.  `static`: this config's entry of profiles/r06_configs.json
+    (rocprofv3 PMC passes of tools/prof_configs6.py -- the same preparation, the same scans: counters cannot be read inside an unprofiled run)."""
+    import torch
+    from pigeons_amd.pt import reduce_recorders, adapt
+    key, name, mk, rounds, scans, bytes_per_replica = cfg
+    inp = mk()
+    pt = P.PT(inp)
+    e = pt.replicas
+    for r in range(1, rounds + 1):
+        e.run_scans(1, 2 ** r); adapt(pt, reduce_recorders(pt))
+    torch.cuda.synchronize()
+    t = time.perf_counter(); e.run_scans(1, scans); torch.cuda.synchronize(); dt = time.perf_counter() - t
+    fused = e.scan_loop_name()
+    k_ms = []
+    for _ in range(max(repeats, 1)):
+        e.timing_reset(True)
+        e.run_scans(1, scans)
+        if fused:
+            k_ms.append((e.timing(4)[0] / scans, 0.0))
+        else:
+            k_ms.append((e.timing(0)[0] / scans, e.timing(1)[0] / scans))
+        e.timing_reset(False)
+    ex_ms = sum(a for a, _ in k_ms) / len(k_ms); sw_ms = sum(b for _, b in k_ms) / len(k_ms)
+    kernel_ms = ex_ms + sw_ms
+    alg = bytes_per_replica * inp.n_chains
+    gbs = alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    roof = {"bound": "hbm", "kernel": fused or e.kernel_name(), "source": "HIP events on the kernel launches of this run (%d scans%s)" % (scans, ", one launch" if fused else ", explore + swap per scan"),
+            "kernel_ms_per_scan": kernel_ms, "explore_kernel_ms_per_scan": None if fused else ex_ms, "swap_kernel_ms_per_scan": None if fused else sw_ms,
+            "algorithmic_bytes_per_replica_scan": bytes_per_replica, "algorithmic_bytes_per_scan": alg,
+            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "hbm_frac": gbs / HBM_PEAK_GBS, "frac_of_6.29TBps": gbs / HBM_ACHIEVABLE_GBS}
+    if static:
+        # executed FP64 flop/s = flops per scan the PMC pass counted at this shape / the kernel time per scan measured HERE
+        fl = static.get("fp64_flops_per_scan")
+        roof.update({"limited_by": static.get("limited_by"), "static_source": static.get("source"),
+                     "valu_issue_frac": static.get("valu_issue_frac"), "cycles_per_instruction": static.get("cycles_per_instruction"),
+                     "sq_wait_any_frac": static.get("sq_wait_any_frac"),
+                     "fp64_flops_executed_per_scan": fl,
+                     "fp64_executed_TFLOPs": (fl / (kernel_ms * 1e-3) / 1e12) if (fl and kernel_ms > 0) else None,
+                     "fp64_vector_peak_TFLOPs": FP64_VECTOR_PEAK_TFLOPS,
+                     "fp64_frac_of_vector_peak": (fl / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS) if (fl and kernel_ms > 0) else None,
+                     "traffic": static.get("traffic_bytes_per_scan"), "traffic_over_algorithmic": (static.get("traffic_bytes_per_scan") / alg) if static.get("traffic_bytes_per_scan") else None})
+    out = {"config": name, "key": key, "kernel": e.kernel_name(), "scan_loop": fused or "two launches per scan", "ms_per_scan": dt / scans * 1e3, "replica_steps_per_s": inp.n_chains * scans / dt,
+           "preparation": "rounds 1..%d of the algorithm (%d scans, adapted after each round); then %d timed scans" % (rounds, 2 ** (rounds + 1) - 2, scans),
+           "chains_per_gpu": inp.n_chains, "waves_per_simd": inp.n_chains / 1024.0, "roofline": roof}
+    del pt, e
+    return out
+
+
 def extra_configs(P):
     """ms / scan (explore + swap, wall clock around pte_run_scans, states resident) of the other BASELINE configs at their per-GPU
     shapes, and the 1-GPU anchor of the strong-scaling clause -- untimed for the headline, so that every config has a driver-visible
-    number.  A handful of scans each, prepared as a run in progress: rounds 1 .. r of the algorithm itself (2, 4, ... 2^r scans, reduce +
-    adaptation after each: schedule; AutoMALA: step size and preconditioner), then the timed scans.  What a fresh engine costs is another
-    regime, and C3's cost moves with the adapted step size and preconditioner (tools/diag_regimes.py: from zeros with the untuned step size
-    0.23-0.24 ms per scan, rounds 3-8 0.19-0.23, adapted every 16 scans 0.17-0.20): the line times round 7 (128 scans) after rounds 1-6."""
-    import torch
-    from pigeons_amd.pt import reduce_recorders, adapt
-    rec = [P.round_trip, P.log_sum_ratio]
-    cfgs = [
-        ("C1 toy_mvn_target(2), n_chains=10, SliceSampler (the reference's quickstart: launch bound)", lambda: P.Inputs(target=P.toy_mvn_target(2), n_chains=10, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 5, 256),
-        ("C2 toy_mvn_target(1024), n_chains=256, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(1024), n_chains=256, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 3, 16),
-        ("C3 funnel d=128, n_chains=1024, AutoMALA", lambda: P.Inputs(target=P.Funnel(128), reference=P.ScaledPrecisionNormalLogPotential(1 / 9., 128), n_chains=1024, explorer=P.AutoMALA(), record=rec, n_rounds=8, show_report=False), 6, 128),
-        ("C4 shard: toy_mvn_target(4096), 1024 of 8192 chains, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(4096), n_chains=1024, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 2, 8),
-        ("C4 on ONE GPU (strong-scaling anchor): toy_mvn_target(4096), n_chains=8192, SliceSampler", lambda: P.Inputs(target=P.toy_mvn_target(4096), n_chains=8192, explorer=P.SliceSampler(), record=rec, n_rounds=8, show_report=False), 1, 4),
-        ("C5 shard: Ising 256x256, 512 of 4096 chains, IsingMetropolis(3 sweeps)", lambda: P.Inputs(target=P.IsingLogPotential(1.0, 256), n_chains=512, record=rec, n_rounds=8, show_report=False), 2, 8),
-    ]
-    out = []
-    for name, mk, rounds, scans in cfgs:
-        inp = mk()
-        pt = P.PT(inp)
-        e = pt.replicas
-        for r in range(1, rounds + 1):
-            e.run_scans(1, 2 ** r); adapt(pt, reduce_recorders(pt))
-        torch.cuda.synchronize()
-        t = time.perf_counter(); e.run_scans(1, scans); torch.cuda.synchronize(); dt = time.perf_counter() - t
-        out.append({"config": name, "kernel": e.kernel_name(), "scan_loop": e.scan_loop_name() or "two launches per scan", "ms_per_scan": dt / scans * 1e3, "replica_steps_per_s": inp.n_chains * scans / dt,
-                    "preparation": "rounds 1..%d of the algorithm (%d scans, adapted after each round); then %d timed scans" % (rounds, 2 ** (rounds + 1) - 2, scans),
-                    "chains_per_gpu": inp.n_chains, "waves_per_simd": inp.n_chains / 1024.0})
-        del pt, e
-    return out
+    number and a `roofline` object of its own.  A handful of scans each, prepared as a run in progress (run_extra_config).  What a fresh
+    engine costs is another regime, and C3's cost moves with the adapted step size and preconditioner (tools/diag_regimes.py: from zeros with the
+    untuned step size 0.23-0.24 ms per scan, rounds 3-8 0.19-0.23, adapted every 16 scans 0.17-0.20): the line times round 7 (128 scans) after rounds 1-6."""
+    try:
+        static = json.load(open(os.path.join(ROOT, "profiles", "r06_configs.json")))
+    except Exception:
+        static = {}
+    return [run_extra_config(P, cfg, static.get(cfg[0])) for cfg in extra_config_list(P)]
 
 
 def main():
@@ -580,6 +639,15 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_extra:
         del pt, runner, eng                              # (frees the metric engine's HBM before the 256 MiB one)
+        if prep:
+            # the order of rounds 1-4 next to the prepared one, in the same line -- a fresh engine, W warm-up scans from the initial
+            # states, reduce + schedule adaptation, then the K timed scans (they then hold the ~20-scan transient after a schedule change)
+            pt0 = P.PT(inputs); e0 = pt0.replicas
+            e0.run_scans(1, W); adapt(pt0, reduce_recorders(pt0))
+            torch.cuda.synchronize(); t0 = time.perf_counter(); e0.run_scans(1, K); torch.cuda.synchronize(); dt0 = time.perf_counter() - t0
+            out["value_unprepared"] = {"value": total_chains * K / dt0, "ms_per_step": dt0 / K * 1e3,
+                                       "preparation": "none (--prepare 0, the order of rounds 1-4): %d warm-up scans from the initial states, reduce + schedule adaptation, then the %d timed scans" % (W, K)}
+            del pt0, e0
         out["hbm_kernels"] = hbm_kernels(P)
         out["extra_configs"] = extra_configs(P)
     if rank == 0:

@@ -88,6 +88,29 @@ def test_single_gpu_line_has_the_contract_fields():
     x = j["extra_configs"]
     assert len(x) == 6 and all(c["ms_per_scan"] > 0 and c["kernel"] for c in x) and x[0]["config"].startswith("C1 ")
     assert {c["kernel"] for c in x} >= {"k_explore_slice8", "k_explore_slice8_lds10k", "k_explore_automala", "k_explore_ising_spec"}
+    # round 6: every config carries a roofline object of its own -- kernel time per scan from HIP events of THIS run,
+    # algorithmic bytes per SURVEY 8(d), and (static, the profile file named) the VALU-issue fraction and the FP64 flops the kernel EXECUTES
+    bytes_by_key = {"C1": 16 * 2 + 128, "C2": 16 * 1024 + 128, "C3": 16 * 128 + 128, "C4_shard": 16 * 4096 + 128, "C4_one_gpu": 16 * 4096 + 128, "C5_shard": 2 * 8192 + 128}
+    assert [c["key"] for c in x] == list(bytes_by_key)
+    for c in x:
+        q = c["roofline"]
+        assert q["bound"] == "hbm" and q["unit"] == "GB/s" and q["peak"] == 8000.0 and q["kernel"] and q["kernel_ms_per_scan"] > 0
+        assert q["algorithmic_bytes_per_replica_scan"] == bytes_by_key[c["key"]] and q["algorithmic_bytes_per_scan"] == bytes_by_key[c["key"]] * c["chains_per_gpu"]
+        assert abs(q["achieved"] - q["algorithmic_bytes_per_scan"] / (q["kernel_ms_per_scan"] * 1e-3) / 1e9) < 1e-6 * q["achieved"]
+        assert abs(q["frac"] - q["achieved"] / 8000.0) < 1e-12 and q["hbm_frac"] == q["frac"]
+        assert q["kernel_ms_per_scan"] <= 1.3 * c["ms_per_scan"]                 # kernel time inside the wall clock (separate passes of a few scans: some scatter)
+        if c["scan_loop"] == "two launches per scan":
+            assert q["explore_kernel_ms_per_scan"] > 0 and q["swap_kernel_ms_per_scan"] > 0
+        if "static_source" in q:                                                  # profiles/r06_configs.json present
+            assert str(q["static_source"]).startswith("profiles/") and 0 < q["valu_issue_frac"] <= 1.0
+            assert q["fp64_vector_peak_TFLOPs"] == 78.6
+            if q["fp64_flops_executed_per_scan"]:
+                assert abs(q["fp64_executed_TFLOPs"] - q["fp64_flops_executed_per_scan"] / (q["kernel_ms_per_scan"] * 1e-3) / 1e12) < 1e-9
+                assert 0 < q["fp64_frac_of_vector_peak"] < 1.0
+    t = h["k_explore_toy"]["floors"]                     # the two floors of the HBM-write-bound kernel, from DESIGN 4.1's model T(k) = 27 + 5 k us
+    assert abs(t["hbm_us_at_6.29TBps"] - h["k_explore_toy"]["bytes_per_launch"] / 6.29e12 * 1e6) < 1e-6 and t["rows_per_simd"] == 8.0 and t["issue_us"] == 40.0
+    u = j["value_unprepared"]                            # the order of rounds 1-4 (--prepare 0) in the same line
+    assert u["value"] > 0 and abs(u["value"] - 1024 * 3 / (u["ms_per_step"] * 3e-3)) < 1e-6 * u["value"] and "--prepare 0" in u["preparation"]
     assert j["config"]["chains_per_gpu"] == 1024 and j["config"]["waves_per_simd"] == 1.0
     assert j["config"]["env_overrides"] == {k: os.environ[k] for k in ("PTE_RCCL_LIB", "PTE_BENCH_BACKEND") if os.environ.get(k)}
     assert j["config"]["transport_library"] is None and j["config"]["parallelism_invariant"] is None       # (single GPU)

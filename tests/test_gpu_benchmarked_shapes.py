@@ -68,10 +68,11 @@ def test_strong_scaling_anchor_kernel_against_the_oracle(P):
         _check_round(P, pt, ref)
 
 
-def _run_slice_rounds(P, N, d, rounds, seed, impl):
+def _run_slice_rounds(P, N, d, rounds, seed, impl, kernel="k_explore_slice8_lds10k"):
+    from pigeons_amd import _lib
     pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, seed=seed, explorer=P.SliceSampler(),
                        record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False), debug_kernel=impl)
-    assert pt.replicas.kernel_name() == ("k_explore_slice" if impl == 1 else "k_explore_slice8_lds10k")
+    assert pt.replicas.kernel_name() == ("k_explore_slice" if (impl & ~_lib.KERNEL_FLAG_BITS) == 1 else kernel)
     out = []
     for _ in range(rounds):
         assert P.next_round(pt)
@@ -107,6 +108,64 @@ def test_strong_scaling_anchor_kernel_equals_sequential_kernel(P, N, d, rounds, 
                        record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False))
     assert pt.replicas.kernel_name() == "k_explore_slice8_lds10k"
     _mvn_properties(P, pt, N, d, 2)
+
+
+def test_config2_full_size_against_the_oracle(P):
+    """BASELINE configs[1] AS QUOTED in the bench line -- toy_mvn_target(1024), n_chains = 256, SliceSampler, the
+    one-kernel scan loop -- rounds 1-2 against the oracle's full O(d) recompute (SliceSampler.jl:89-237): states, RNG counters, chains, index
+    process, recorders, adapted schedule (about 6 s of the host's cores)."""
+    pt, ref = _mk_slice(P, 256, 1024, 2, seed=2)
+    assert pt.replicas.kernel_name() == "k_explore_slice8" and pt.replicas.scan_loop_name() == "k_scans_slice8"
+    for _ in range(2):
+        _check_round(P, pt, ref)
+
+
+@pytest.mark.parametrize("two_launches", [False, True])
+def test_config4_shard_shape_equals_sequential_kernel(P, two_launches):
+    """the C4 shard AS QUOTED -- toy_mvn_target(4096), 1024 chains on one GPU, k_explore_slice8<6, 9> (the 512-draw
+    kernel at the deepest tree, not the anchor's _lds10k twin) -- two rounds bit for bit against the plain sequential kernel (debug_kernel = 1,
+    oracle-pinned at d = 4096 in tests/test_gpu_parity.py), under both settings of the scan loop (rows of 32 KB stay on two launches per scan
+    either way: pte_scan_loop_name is "" -- asserted, so that the day the fused loop takes d = 4096 this test holds IT to the sequential kernel)."""
+    from pigeons_amd import _lib
+    flag = _lib.KERNEL_TWO_LAUNCHES if two_launches else 0
+    pa, a = _run_slice_rounds(P, 1024, 4096, 2, 13, 1 | flag)
+    sa = pa.replicas.states(); del pa
+    pb, b = _run_slice_rounds(P, 1024, 4096, 2, 13, flag, kernel="k_explore_slice8")
+    assert pb.replicas.scan_loop_name() == ""
+    sb = pb.replicas.states(); del pb
+    for r, (ra, rb) in enumerate(zip(a, b)):
+        for k, (x, y) in enumerate(zip(ra, rb)):
+            assert np.array_equal(x, y), (r, k)
+    for x, y in zip(sa, sb):
+        assert np.array_equal(x, y)
+
+
+def test_config5_shard_shape_equals_byte_lattice_kernel(P):
+    """the C5 shard AS QUOTED -- Ising 256 x 256, 512 chains, IsingMetropolis(3 sweeps), k_explore_ising_spec (56
+    lane hypotheses per 16-site chunk) -- two rounds bit for bit against the scalar byte-lattice sweep (PTE_KERNEL_ISING_BYTES, the raster
+    loop of examples/ising.jl:96-116 site by site; oracle-pinned at 256 x 256 in tests/test_gpu_parity.py): index process, recorders, adapted
+    schedule, every spin, every RNG counter."""
+    from pigeons_amd import _lib
+    outs = []
+    for impl, name in ((_lib.KERNEL_ISING_BYTES, "k_explore_ising"), (0, "k_explore_ising_spec")):
+        pt = P.PT(P.Inputs(target=P.IsingLogPotential(1.0, 256), n_chains=512, n_rounds=2, seed=3,
+                           record=[P.round_trip, P.index_process, P.log_sum_ratio], show_report=False), debug_kernel=impl)
+        assert pt.replicas.kernel_name() == name
+        rows = []
+        for _ in range(2):
+            assert P.next_round(pt)
+            red = P.run_one_round(pt); P.adapt(pt, red)
+            rows.append((red.index_process.copy(), np.array(red.round_trip), red.swap_acceptance_pr[0].copy(), red.log_sum_ratio[0].copy(),
+                         red.log_sum_ratio[2].copy(), red.explorer_acceptance_pr[0].copy(), red.explorer_acceptance_pr[1].copy(),
+                         np.array(pt.shared.tempering.schedule.grids).copy()))
+        outs.append((rows, pt.replicas.states())); del pt
+    (a, sa), (b, sb) = outs
+    for r, (ra, rb) in enumerate(zip(a, b)):
+        for k, (x, y) in enumerate(zip(ra, rb)):
+            assert np.array_equal(x, y), (r, k)
+    for x, y in zip(sa, sb):
+        assert np.array_equal(x, y)
+    assert 0.0 < sa[0].mean() < 1.0                        # (spins did move)
 
 
 def test_config3_full_size_against_the_oracle(P):
