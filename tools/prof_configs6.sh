@@ -15,4 +15,6 @@ rocprofv3 --pmc WRITE_SIZE -d $O -o write -- $P > $O/write.log 2>&1
 python3 $R/tools/r06_configs_summary.py $O > $O/summary.txt 2> $O/summary.err
 cp $O/configs.json $R/gpurun_out/r06_configs_$TAG.json 2>/dev/null
 cp $O/summary.txt $R/gpurun_out/r06_configs_pmc_summary_$TAG.txt
+ls -la $O | head -30; du -sh $O
+find $O -name "*.db" -delete          # (gpurun copies back at most 64 MiB: the summaries travel, the databases do not)
 tail -5 $O/summary.err; cut -c1-200 $O/summary.txt | head -150

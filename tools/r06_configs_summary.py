@@ -111,19 +111,15 @@ def main():
                 n_inst *= 2
             clk = gui / n_inst                      # shader-clock cycles of the timed dispatches
             frac = gr["SQ_INSTS_VALU"] * 4.0 / (1024.0 * clk)
-            thr = gr.get("SQ_THREAD_CYCLES_VALU", 0.0)
             print("   VALU issue: SQ_INSTS_VALU %.3g x 4 cycles / (1024 SIMDs x %.3g cycles [GRBM_GUI_ACTIVE / %d instances = %.0f MHz effective]) = %.4f of the chip's VALU issue slots"
                   % (gr["SQ_INSTS_VALU"], clk, n_inst, mhz / n_inst, frac))
             ent.update({"valu_issue_frac": frac, "effective_clock_MHz": mhz / n_inst})
-            if thr:
-                print("   lanes: SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU x 64 x 4) = %.3f of the lane-cycles of the issued VALU instructions had their lane enabled" % (thr / (gr["SQ_INSTS_VALU"] * 256.0)))
-                ent["valu_lane_utilisation"] = thr / (gr["SQ_INSTS_VALU"] * 256.0)
         if fp:
             f64 = fp.get("SQ_INSTS_VALU_ADD_F64", 0) + fp.get("SQ_INSTS_VALU_MUL_F64", 0) + fp.get("SQ_INSTS_VALU_TRANS_F64", 0) + 2 * fp.get("SQ_INSTS_VALU_FMA_F64", 0)
             flops = f64 * 64.0 / scans_total
             tf = flops / ((k_us) * 1e-6) / 1e12 if k_us > 0 else 0.0
             print("   FP64 wave-instructions per scan: ADD %.3g  MUL %.3g  FMA %.3g  TRANS %.3g  (INT32 %.3g, INT64 %.3g, LDS %.3g) -> %.4g flops EXECUTED per scan (x 64 lanes, FMA = 2) = %.3f TFLOP/s = %.4f of the 78.6 TF FP64 vector peak"
-                  % tuple(fp.get(k, 0) / scans_total for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_LDS")) + (flops, tf, tf / 78.6))
+                  % (tuple(fp.get(k, 0) / scans_total for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_LDS")) + (flops, tf, tf / 78.6)))
             ent.update({"fp64_flops_per_scan": flops, "fp64_TFLOPs_in_trace": tf, "int32_valu_per_scan": fp.get("SQ_INSTS_VALU_INT32", 0) / scans_total})
         alg = c["bytes_per_replica_scan"] * N
         if fe.get("FETCH_SIZE") is not None and wr.get("WRITE_SIZE") is not None:
