@@ -488,12 +488,19 @@ int fused_slice_variant(const pte_engine *h) {
 // XCD's dirty L2 lines, and 128 waves x 32 KB of freshly written rows are all of it); 2048 chains at d = 1024 x0.91 (a wave that polls shares
 // its SIMD with a wave that works, and the fences cost per resident workgroup).  Elsewhere the loop of rounds 1-4 stays.
 #define OCC_NLU_M(nlu, KERNEL, MM, out) OCC_NLU_MB(nlu, KERNEL, MM, 64, out)
+// The shapes the one-kernel loop was MEASURED to win at, as build-time constants with the profile that produced them (re-measure before moving them):
+#ifndef PTE_FUSED_SLICE_MAX_D
+#define PTE_FUSED_SLICE_MAX_D 2048       // profiles/r05_fused_shapes.txt: 1024 chains, d = 512 x1.055, 1024 x1.03, 2048 x1.00, 4096 x0.99 against two launches per scan
+#endif
+#ifndef PTE_FUSED_LANGEVIN_MAX_D
+#define PTE_FUSED_LANGEVIN_MAX_D 512     // the Langevin-family loop exists for the register layouts one wave holds without spilling (E <= 8 blocks; profiles/r05_am_wg_ab.txt)
+#endif
 // 0: not a fused kind; 1: SliceSampler on the MVN path (k_scans_slice8*); 2: AutoMALA / MALA on the MVN or funnel path (k_scans_automala)
 int fused_kind(const pte_engine *h) {
     if (h->cfg.explorer2 != PTE_EXPLORER_NONE) return 0;
-    if (h->cfg.explorer == PTE_EXPLORER_SLICE && h->cfg.target == PTE_TARGET_MVN_SCALED_PRECISION && h->slice_impl == 8) return h->d <= 2048 ? 1 : 0;
+    if (h->cfg.explorer == PTE_EXPLORER_SLICE && h->cfg.target == PTE_TARGET_MVN_SCALED_PRECISION && h->slice_impl == 8) return h->d <= PTE_FUSED_SLICE_MAX_D ? 1 : 0;
     if ((h->cfg.explorer == PTE_EXPLORER_AUTOMALA || h->cfg.explorer == PTE_EXPLORER_MALA) &&
-        (h->cfg.target == PTE_TARGET_MVN_SCALED_PRECISION || h->cfg.target == PTE_TARGET_FUNNEL)) return h->d <= 512 ? 2 : 0;
+        (h->cfg.target == PTE_TARGET_MVN_SCALED_PRECISION || h->cfg.target == PTE_TARGET_FUNNEL)) return h->d <= PTE_FUSED_LANGEVIN_MAX_D ? 2 : 0;
     return 0;
 }
 int langevin_E(const pte_engine *h) { return h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16; }

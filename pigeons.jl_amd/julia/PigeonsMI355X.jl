@@ -73,14 +73,18 @@ Base.@kwdef mutable struct PteConfig
 end
 
 # ---- targets on the device -------------------------------------------------------------------------------------------------
-"""`on_mi355x(target; device = 0, rank = 0, world_size = 1)`: run the explore-then-swap loop of `target` on an MI355X."""
+"""`on_mi355x(target; device = 0, rank = 0, world_size = 1, reference_reduction = false)`: run the explore-then-swap loop of `target` on an MI355X.
+`reference_reduction = true` (PTE_RECORD_REFERENCE_REDUCTION, include/pte.h): the swap recorders are reduced with the reference's own arithmetic --
+per-replica Mean / LogSum fits merged over the binary tree on the replica index -- instead of chain-keyed sums; forces :index_process, logs 16 B per
+chain and scan.  An explicit option, like `PT(reference_reduction = ...)` on the Python side: nothing here reads the environment (ADVICE r05)."""
 struct OnDevice{T}
     target::T
     device::Int
     rank::Int
     world_size::Int
+    reference_reduction::Bool
 end
-on_mi355x(target; device = 0, rank = 0, world_size = 1) = OnDevice(target, device, rank, world_size)
+on_mi355x(target; device = 0, rank = 0, world_size = 1, reference_reduction = false) = OnDevice(target, device, rank, world_size, reference_reduction)
 
 # everything Shared(inputs) / preflight ask of a target goes to the wrapped one (src/targets/target.jl informal interface)
 Pigeons.create_path(t::OnDevice, inputs::Inputs) = Pigeons.create_path(t.target, inputs)
@@ -145,8 +149,8 @@ function record_flags(inputs::Inputs, shared::Shared)
     (:traces in names && inputs.extended_traces) && (f |= RECORD_TRACES_EXTENDED)
     :energy_ac1 in names && (f |= RECORD_ENERGY_AC1)
     :disk in names && error("the disk recorder is not served by the device path (SURVEY.md 2: out of scope)")
-    # ENV["PIGEONS_MI355X_REFERENCE_REDUCTION"] = "1": the reference's own reduction arithmetic for the swap recorders (and :online when :traces is recorded)
-    get(ENV, "PIGEONS_MI355X_REFERENCE_REDUCTION", "0") == "1" && (f |= RECORD_REFERENCE_REDUCTION | RECORD_INDEX_PROCESS)
+    # on_mi355x(target; reference_reduction = true): the reference's own reduction arithmetic for the swap recorders (and :online when :traces is recorded)
+    (inputs.target isa OnDevice && inputs.target.reference_reduction) && (f |= RECORD_REFERENCE_REDUCTION | RECORD_INDEX_PROCESS)
     return f
 end
 
