@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r05_steps20; mkdir -p $O
+R=$GRAFT_REPO_ROOT; TAG=${1:-r05}; O=$R/gpurun_out/prof_${TAG}_steps20; mkdir -p $O
 rocprofv3 --kernel-trace --stats -d $O -o stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --round-trip-rounds 0 > $O/stats.log 2>&1
 python3 - "$O" <<'PY'
 import sqlite3, sys, json, os

@@ -11,7 +11,7 @@ def main():
     def q(db, sql):
         con = sqlite3.connect(os.path.join(O, db)); rows = con.execute(sql).fetchall(); con.close(); return rows
     print("# rocprofv3 passes of `python3 bench.py --no-cpu-baseline --no-extra --round-trip-rounds 0 --steps %d --warmup %d` (tools/prof_round5.sh):" % (S, S))
-    print("# warm-up, timed and event-free passes are three launches of the fused scan loop, %d scans each; N = %d chains, d = %d" % (S, N, d))
+    print("# warm-up, timed and event-free passes are three launches of the fused scan loop, %d scans each (the two shorter dispatches before them: bench.py's untimed preparation, 2 x 64 scans); N = %d chains, d = %d" % (S, N, d))
     for db in ("stats_results.db", "sq_results.db"):
         rows = q(db, "select name, (end-start)/1e6 from kernels where name like '%k_scans%' order by start")
         print("%-18s k_scans dispatches, ms: %s  -> per scan, us: %s" % (db, ["%.2f" % r[1] for r in rows], ["%.1f" % (r[1] * 1e3 / S) for r in rows]))
@@ -19,7 +19,12 @@ def main():
     print("\n== --kernel-trace --stats (top kernels)\n%-76s %6s %12s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
     for r in rows[:6]:
         print("%-76s %6d %12.0f %12.0f %7.2f" % (r[0][:76], r[1], r[2], r[3], r[4]))
-    c = {r[0]: r[1] for r in q("sq_results.db", "select counter_name, avg(value) from counters_collection where kernel_name like '%k_scans%' group by counter_name")}
+    # round 6: bench.py also launches the scan loop for its untimed preparation (2 x 64 scans) -- the counters are those of the LAST THREE dispatches
+    # (warm-up, timed, event-free: S scans each), chosen by dispatch id, averaged per dispatch
+    def last3(db):
+        ids = [r[0] for r in q(db, "select dispatch_id, min(start) from counters_collection where kernel_name like '%k_scans%' group by dispatch_id order by min(start)")][-3:]
+        return ",".join(str(i) for i in ids)
+    c = {r[0]: r[1] / 3.0 for r in q("sq_results.db", "select counter_name, sum(value) from counters_collection where kernel_name like '%%k_scans%%' and dispatch_id in (%s) group by counter_name" % last3("sq_results.db"))}
     W = c["SQ_WAVES"]
     per = lambda k: c[k] / W / S
     ins = per("SQ_INSTS_VALU") + per("SQ_INSTS_SALU") + per("SQ_INSTS_BRANCH")
@@ -29,8 +34,8 @@ def main():
     print("wave cycles %.3f M per scan (incl. the hand-shake's polls and s_sleep) = %.2f cycles per instruction; SQ_WAIT_ANY %.3f, SQ_WAIT_INST_ANY %.3f, SQ_ACTIVE_INST_ANY %.3f of the wave cycles"
           % (cyc / 1e6, cyc / ins, c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"]))
     print("issue roofline of a lone wave: instructions x 4.44 / wave cycles = %.3f" % (ins * 4.44 / cyc))
-    f = q("fetch_results.db", "select avg(value) from counters_collection where kernel_name like '%k_scans%' and counter_name = 'FETCH_SIZE'")[0][0]
-    w = q("write_results.db", "select avg(value) from counters_collection where kernel_name like '%k_scans%' and counter_name = 'WRITE_SIZE'")[0][0]
+    f = q("fetch_results.db", "select sum(value) / 3.0 from counters_collection where kernel_name like '%%k_scans%%' and counter_name = 'FETCH_SIZE' and dispatch_id in (%s)" % last3("fetch_results.db"))[0][0]
+    w = q("write_results.db", "select sum(value) / 3.0 from counters_collection where kernel_name like '%%k_scans%%' and counter_name = 'WRITE_SIZE' and dispatch_id in (%s)" % last3("write_results.db"))[0][0]
     fb, wb = f * 1024 * 2 / S, w * 1024 / S
     alg = (16 * d + 32 + 96) * N
     print("\n== HBM traffic per SCAN: FETCH_SIZE %.1f KB per launch -> %.2f MB fetched, WRITE_SIZE %.1f KB per launch -> %.2f MB written; algorithmic (16 d + 32 + 96) N = %.2f MB"
