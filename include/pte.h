@@ -100,7 +100,10 @@ enum {                                   /* pte_config.debug_kernel: which kerne
      *                   launch aborts with nothing written and the call runs as explore + swap launches -- same results, no error */
     PTE_KERNEL_TEST_DEAD_CHAIN     = 0x4000,
     PTE_KERNEL_TEST_LATE_WORKGROUP = 0x8000,
-    PTE_KERNEL_TEST_BITS        = 0xC000
+    /* A/B reference, test build only: AutoMALA / MALA at 512 < dim <= 1024 on the ONE-wave kernel with sixteen blocks per lane (rounds 1-5; it
+     * spills 250-300 VGPRs) instead of the four-waves-per-replica kernel k_explore_langevin_mw (round 6) -- bit-identical, tests/test_gpu_langevin_mw.py */
+    PTE_KERNEL_TEST_LANGEVIN_ONE_WAVE = 0x10000,
+    PTE_KERNEL_TEST_BITS        = 0x1C000
 };
 
 /* Mirrors the fields of `Inputs` (src/pt/Inputs.jl:9-102) and of the explorer

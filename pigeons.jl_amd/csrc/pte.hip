@@ -307,6 +307,7 @@ void time_collect(pte_engine *h) {
 // one launch of the Langevin-family kernel (pte_automala_params.hpp); like PTE_LAUNCH1, the open timing bracket's events ride on it
 static int launch_langevin(pte_engine *h, int E, int target, bool slice, bool full, int64_t N, const AmParams &ap) {
     LangevinLaunch L{E, target, slice, full, (unsigned)N, h->stream, false, nullptr, nullptr};
+    L.one_wave16 = (h->cfg.debug_kernel & PTE_KERNEL_TEST_LANGEVIN_ONE_WAVE) != 0;       // (test build only: pte_create refuses the flag otherwise)
     if (h->ev_open && h->ev_ext && !h->ev_ext_done) { L.ext = true; L.ev_a = h->events.back().a; L.ev_b = h->events.back().b; h->ev_ext_done = true; }
     if (langevin_launch(L, h->dev, ap)) return fail(h, "this build holds no Langevin-family kernels (PTE_DEV_NO_LANGEVIN)");
     return 0;
@@ -787,6 +788,8 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.on_mean, (size_t)(2 * (d + 1)));   rc |= dev_alloc(h, &e.on_m2, (size_t)(2 * (d + 1)) + PTE_WAVE_PROFILE_WORDS * (size_t)K);   // (+ 4 words per wave in -DPTE_PROFILE_WAVES builds)
     rc |= dev_alloc(h, &e.eac, (size_t)(5 * K)); rc |= dev_alloc(h, &e.eac_n, (size_t)K);
     rc |= dev_alloc(h, &e.lp_stash, (size_t)K);
+    e.am_stash = nullptr;
+    if (uses_grad && d > 512) rc |= dev_alloc(h, &e.am_stash, (size_t)(K * e.ld));       // k_explore_langevin_mw: one more row per replica (L2-resident: 8 MB at 1024 x 1024)
     const int64_t trace_rows = (cfg->record_flags & PTE_RECORD_TRACES_EXTENDED) ? K : (cfg->n_chains_variational > 0 ? 2 : 1);   // chains traced per scan
     rc |= dev_alloc(h, &e.traces, (cfg->record_flags & PTE_RECORD_TRACES) ? (size_t)(cfg->max_scans_per_round * trace_rows * (d + 1)) : 1, false);
     rc |= dev_alloc(h, &e.on_n, 2);
@@ -1646,11 +1649,9 @@ const char *pte_kernel_name(const pte_engine *h) {
     switch (h->cfg.explorer) {
     case PTE_EXPLORER_TOY: return "k_explore_toy";
     case PTE_EXPLORER_SLICE:
-        // The register-resident Langevin-family kernel keeps a replica's eight vectors in VGPRs: 16 coordinates per lane (d > 512) is past
-        // what the register file holds -- those instantiations spill (316-364 VGPRs to scratch, profiles/r04_kernel_resources.txt) and run
-        // at one wave per SIMD.  They are correct (held to the oracle at every layout) and UNOPTIMISED: the name says so, and no quoted
-        // number uses them (BASELINE configs[2] is d = 128).
-        if (h->cfg.target == PTE_TARGET_FUNNEL) return h->d > 512 ? "k_explore_automala [d > 512: unoptimised, spills to scratch]" : "k_explore_automala";      // its SliceSampler instantiation
+        // SliceSampler on the interpolated path: the one-wave Langevin-family kernel in its slice mode (no momentum, gradient or trial copies:
+        // its sixteen-block instantiation for d > 512 holds 255 VGPRs + 7 AGPRs and does not touch scratch)
+        if (h->cfg.target == PTE_TARGET_FUNNEL) return "k_explore_automala";
         switch (h->slice_impl) {
         case 1: return "k_explore_slice"; case 2: return "k_explore_slice2"; case 5: return "k_explore_slice5";
         case 7: return "k_explore_slice7";
@@ -1659,7 +1660,10 @@ const char *pte_kernel_name(const pte_engine *h) {
             return (h->cfg.slice_p > PTE_S8_BD && h->cfg.slice_p <= 20 && h->cfg.slice_max_iter >= PTE_S8_BS) ? "k_explore_slice8" : "k_explore_slice8_generic";
         }
     case PTE_EXPLORER_AUTOMALA: case PTE_EXPLORER_MALA:
-        return h->d > 512 ? "k_explore_automala [d > 512: unoptimised, spills to scratch]" : "k_explore_automala";
+        // d > 512: four waves per replica (pte_automala_mw.hpp, round 6); the one-wave kernel with sixteen blocks per lane -- 250-300 spilled VGPRs,
+        // "unoptimised" in rounds 1-5 -- survives in the test build as its A/B reference
+        if (h->d > 512) return (h->cfg.debug_kernel & PTE_KERNEL_TEST_LANGEVIN_ONE_WAVE) ? "k_explore_automala [test build: one wave, sixteen blocks per lane]" : "k_explore_langevin_mw";
+        return "k_explore_automala";
     case PTE_EXPLORER_ISING_METROPOLIS: {
         const int64_t L = (int64_t)std::llround(std::sqrt((double)h->d));
         return (L % 32 == 0 && h->ising_impl == 0) ? "k_explore_ising_spec" : (L % 32 == 0 && h->ising_impl == 1) ? "k_explore_ising_bits" : "k_explore_ising";

@@ -1,0 +1,864 @@
+// pte_automala_mw.hpp -- k_explore_langevin_mw: AutoMALA / MALA for 512 < d <= 1024 with FOUR wavefronts per replica (round 6;
+// VERDICT r05 item 4).  Reference: src/explorers/AutoMALA.jl:84-275, src/explorers/MALA.jl:74-97,
+// src/explorers/hamiltonian_dynamics.jl:40-84, src/explorers/Preconditioner.jl:57-77 -- the same procedure, draw for draw and
+// addition for addition, as k_explore_automala (pte_automala.hpp), whose E = 16 instantiations (one wave holding sixteen 64-coordinate
+// blocks of twelve vectors: 250-300 spilled VGPRs, one wave per SIMD) this kernel replaces in the product build.
+//
+// Leapfrog, gradient and log joint are elementwise + tree reductions, so a replica can own a 256-thread workgroup: wave w holds coordinates
+// 256 w .. 256 w + 255, lane l FOUR CONSECUTIVE ones (its register j <-> coordinate 256 w + 4 l + j).  Why the results do not change by a bit:
+//   * a reduction is the SAME fixed tree (pte_device.hpp: balanced, leaves in natural order).  With four consecutive leaves per lane its first two
+//     levels are in-lane additions -- (t0 + t1) + (t2 + t3) -- the next six the xor butterfly over the 64 lanes (wave_sum_dpp: one register per
+//     sum, where the one-wave layout -- one leaf per lane and block -- pays six levels for each of its blocks), which gives the 256-leaf node W_w;
+//     the top two levels -- (W0 + W1) + (W2 + W3) -- are added by EVERY wave from the four partial sums exchanged through LDS: all waves hold
+//     the same root, to the bit, so every branch of the algorithm (step-size search, finiteness checks, accept / reject) is taken identically
+//     by the four waves without further talk;
+//   * the replica's stream is consumed in the reference's order.  The momentum (d sequential randn) is the stream compaction of
+//     pte_normals.hpp cut over the four waves: wave w evaluates the 320 stream positions of ITS segment (1280 = 1024 + slack) as if the
+//     ziggurat's fast path applied, resolves the 1.5 % that leave it in one divergent pass, marks the positions those attempts consume;
+//     the waves exchange how many positions each segment consumed, and every position that was not consumed is an output -- its index is
+//     its position minus the consumed positions before it -- scattered to LDS in output order.  An attempt at a segment's last position
+//     consumes the next segment's first (followed, when that position is no event itself); a longer spill, a tail that runs on, 32 or
+//     more events in a segment: that refresh takes the plain sequential procedure instead (sixteen blocks, the stream handed from wave to
+//     wave), which is what the fast path must equal anyway.  Every other draw (the preconditioner's, the two bounds, the accept uniform)
+//     is taken by all four waves from identical copies of the stream;
+//   * the funnel's first coordinate (its scale enters every term) is broadcast by the lane that owns it;
+//   * a / M and x / sigma are the IEEE quotients (see div_M below): Markstein's correctly rounded q' = fma(fma(-q, b, a), r, q), the division
+//     itself wherever the theorem's conditions are not met.
+// Storage: a wave keeps x, p, g, g0, M, 1 / M and the forward search's restore copy of p in registers (7 vectors x 8 VGPRs); the start
+// state, the kept trial's state and momentum (its conditioned gradient is RE-EVALUATED from the state: elementwise, plus one saved word for
+// the funnel's first coordinate) and the conditioned gradient at the start live in LDS (32 KB per replica; each lane reads back only what
+// it wrote: no barrier; the momentum's workspace uses 19 KB of the same bytes while no trial is kept).  <= 128 VGPRs and 38.4 KB of LDS:
+// four workgroups per compute unit = 1024 replicas resident, four waves per SIMD.  The search is ONE loop with one leapfrog in it.
+#pragma once
+#include "pte_automala.hpp"
+#include "pte_normals.hpp"
+
+namespace pte {
+
+constexpr int MW_NWV = 4;                 // waves per replica
+constexpr int MW_EW = 4;                  // 64-coordinate blocks per wave: 16 blocks = d <= 1024
+constexpr int MW_DMAX = 64 * MW_NWV * MW_EW;
+
+constexpr int MW_SEG = 320;               // stream positions per wave of the momentum's compaction (4 x 320 = 1024 outputs + 256 of slack: ~25 are consumed)
+constexpr int MW_SLOTS = MW_SEG / 64;
+constexpr int MW_MAX_EV = 32;             // events a wave resolves lane-parallel, two lanes each
+constexpr int MW_EV_CAP = 128;
+struct MwMomentum {                       // (lives in the bytes of MwLds::v[0 .. 2]: no trial is kept while a momentum is drawn)
+    double seg[MW_NWV][MW_SEG];           // a segment's values by stream position; consumed positions marked with a NaN
+    double out[MW_DMAX];                  // the momentum in output order
+    unsigned short ev[MW_NWV][MW_EV_CAP]; // positions that left the fast path, in stream order
+};
+enum { MW_XK = 0, MW_PK = 1, MW_GS = 2, MW_XS = 3 };      // MwLds::v: kept trial's state, its momentum, conditioned gradient at the start point, start state
+struct MwLds {
+    double wi[256]; unsigned long long ki[256];                      // the normal ziggurat's fast-path tables
+#ifndef PTE_MW_FI_GLOBAL
+    double fi[256];                                                  // ... and the wedge test's
+#endif
+    union { double v[4][MW_DMAX]; MwMomentum mom; };
+    double part[2][MW_NWV][4];            // the waves' partial sums of up to four reductions taken in lockstep, double-buffered
+    double ybuf[2];                       // the funnel's first coordinate
+    unsigned long long seed[MW_NWV];      // sequential procedure: stream position after wave w's momentum blocks
+    int mom_cons[MW_NWV], mom_fail[MW_NWV], mom_below[MW_NWV];      // compaction: positions a segment consumed; what it cannot follow; consumed by the attempts of the outputs below d
+#ifdef PTE_MW_LDS_PAD                     // development builds only: where does the fourth workgroup of a compute unit stop fitting
+    char pad[PTE_MW_LDS_PAD];
+#endif
+};
+static_assert(sizeof(MwMomentum) <= sizeof(double) * 3 * MW_DMAX, "the momentum's workspace must not reach the start state");
+static_assert(sizeof(MwLds) <= 40 * 1024, "four workgroups per compute unit");
+
+using MwLdsP = __attribute__((address_space(3))) MwLds *;
+
+// ---- cold paths as CALLED functions: the code a refresh walks through stays small (the kernel's instruction footprint, not its arithmetic, is
+// what a lone wave per SIMD waits for) and the register allocation of the hot path is not bent around them
+__device__ __attribute__((noinline)) double mw_div_exact(double a, double b) { return a / b; }
+__device__ __attribute__((noinline)) double mw_exp_exact(double t) { return exp(t); }
+// tail of the normal ziggurat (Random/src/normal.jl randn_unlikely, idx == 0) for the two lanes of an event's pair, exactly, at stream position zt:
+// trial k takes the draws 2k - 1 (-> xx) and 2k (-> yy) behind the event; the even lane evaluates the first, the odd lane the second.  Returns xx; *pairs_out = trials
+__device__ __attribute__((noinline)) double mw_tail_event(uint64_t zt, const uint64_t gamma, const int role, const bool tail_log1p, const int max_pairs, int *pairs_out) {
+    int pairs = 0;
+    double xx, yy;
+    do {
+        const double ut = u52_to_unit(mix64(zt));
+        const double v = tail_log1p ? -log1p(-ut) : -log(ut);
+        zt += gamma + gamma;
+        const double pv = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, true),
+                                           __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, true));
+        xx = ZIG_NOR_INV_R * (role ? pv : v);
+        yy = role ? v : pv;
+        pairs += 1;
+    } while (!(yy + yy > xx * xx) && pairs < max_pairs);
+    *pairs_out = pairs;
+    return xx;
+}
+// the plain procedure for the momentum: sixteen blocks in stream order (wave_randn_block), each drawn by the wave that owns it, the stream handed on
+// through LDS; leaves the momentum in L->mom.out, returns the stream's new position
+template <bool FULL>
+__device__ __attribute__((noinline)) uint64_t mw_draw_momentum_sequential(const MwLdsP L, const uint64_t seed0, const uint64_t gamma, const int64_t d) {
+    const int lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    SeqRng r{seed0, gamma};
+    for (int ww = 0; ww < MW_NWV; ++ww) {
+        if (w == ww) {
+#pragma unroll 1
+            for (int j = 0; j < MW_EW; ++j) {
+                const int jg = w * MW_EW + j;
+                const int nl = FULL ? 64 : (int)max((int64_t)0, min((int64_t)64, d - 64 * (int64_t)jg));
+                if (nl > 0) { const double v = wave_randn_block(r, lane, nl); if (lane < nl) L->mom.out[64 * jg + lane] = v; }
+            }
+            if (lane == 0) L->seed[ww] = r.seed;
+        }
+        __syncthreads();
+        r.seed = L->seed[ww];
+    }
+    return r.seed;
+}
+
+// The momentum of a refresh: d sequential randn(rng) of the replica's stream (seed, gamma), left in L->mom.out in output order by the four
+// waves of the workgroup together; returns the stream's new position (the same in every wave).
+//   fast path = the stream compaction of pte_normals.hpp (steps 1-3 as they stand there, per wave on its own segment of 320 positions), then
+//     across the waves: consumed positions per segment exchanged, every position that was not consumed scattered to its output index;
+//   plain path = sixteen blocks in stream order (wave_randn_block), each drawn by the wave that owns it, the stream handed on through LDS.
+template <bool FULL>
+__device__ __forceinline__ uint64_t mw_draw_momentum(const MwLdsP L, const uint64_t seed0, const uint64_t gamma, const int64_t d) {
+    constexpr int NWV = MW_NWV;
+    const int lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int dn = FULL ? MW_DMAX : (int)d;
+    __syncthreads();                                                // every wave has read its part of the kept trial: the bytes are the workspace's now
+    const uint64_t g64 = gamma << 6;
+    const uint64_t base = seed0 + (uint64_t)(MW_SEG * w) * gamma;  // this segment: positions base + 1 .. base + MW_SEG
+    const double NRM_DEAD = __longlong_as_double(0x7ff8dead00000000LL);      // a consumed stream position (no fast-path value is a NaN)
+    const bool tail_log1p = (g_rng_policy & PTE_RNG_TAIL_LOG1P) != 0;
+    __attribute__((address_space(3))) double *const out = L->mom.seg[w];
+    __attribute__((address_space(3))) unsigned short *const evl = L->mom.ev[w];
+    // 1. the segment's positions as if the fast path applied; the others go to the event list.  Per position (pte_normals.hpp): the draw's 52 bits with
+    //    bit 0 cleared are 2 rabs, (2 rabs)(wi / 2) is rabs wi bit for bit, and "rabs < ki" is one unsigned compare of the pattern of 2^52 + 2 rabs
+    uint64_t zc = base + (uint64_t)(lane + 1) * gamma;
+    int n_ev = 0;
+    uint64_t raw_n = mix64(zc);
+    double tw_n = L->wi[((uint32_t)raw_n >> 1) & 0xFFu]; unsigned long long tk_n = L->ki[((uint32_t)raw_n >> 1) & 0xFFu];
+#pragma unroll
+    for (int j = 0; j < MW_SLOTS; ++j) {
+        const uint64_t raw = raw_n;
+        const double tw = tw_n; const unsigned long long tk = tk_n;
+        if (j + 1 < MW_SLOTS) { zc += g64; raw_n = mix64(zc); tw_n = L->wi[((uint32_t)raw_n >> 1) & 0xFFu]; tk_n = L->ki[((uint32_t)raw_n >> 1) & 0xFFu]; }
+        const uint32_t lo = (uint32_t)raw, hi = (uint32_t)(raw >> 32);
+        const uint64_t mb = ((uint64_t)((hi & 0x000FFFFFu) | 0x43300000u) << 32) | (lo & ~1u);
+        const double wsigned = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(0.5 * tw) ^ ((unsigned long long)(lo & 1u) << 63)));
+        // (+ 0.0: rabs = 0 with the sign bit set gives -0.0 here where randn gives +0.0)
+        out[64 * j + lane] = (__longlong_as_double((long long)mb) - 4503599627370496.0) * wsigned + 0.0;
+        const bool slow = !(mb < ((tk << 1) | 0x4330000000000000ull));
+        const uint64_t m = ballot64(slow);
+        if (m) {
+            const int at = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, (unsigned)n_ev));
+            if (slow) evl[min(at, MW_EV_CAP - 1)] = (unsigned short)(64 * j + lane);
+            n_ev += __popcll(m);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    int spill = 0;                                          // uniform: positions of the NEXT segment this one's attempts consume (99: more than the bookkeeping follows)
+    if (n_ev >= MW_MAX_EV) { n_ev = MW_MAX_EV; spill = 99; }
+    // 2. one divergent pass over the events, lanes 2 e and 2 e + 1 resolve event e together (pte_normals.hpp, step 2)
+    const int role = lane & 1;
+    const bool in_pass = (lane >> 1) < n_ev;
+    const bool is_ev = in_pass && role == 0;
+    int e_pos = 0x3fffffff, e_kind = 0, e_delta = 0;
+    double e_tail = 0.0;
+    if (in_pass) {
+        e_pos = evl[lane >> 1];
+        const double xv = out[e_pos];
+        const uint64_t zr = base + (uint64_t)(e_pos + 1 + role) * gamma;
+        const uint64_t mine = mix64(zr);
+        const uint64_t theirs = ((uint64_t)(uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(mine >> 32), 0xB1, 0xF, 0xF, true) << 32)
+                                | (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)mine, 0xB1, 0xF, 0xF, true);
+        const uint64_t raw = role ? theirs : mine, nxt = role ? mine : theirs;
+        const int idx = (int)((raw >> 1) & 0xFF);
+        if (idx == 0) {
+            int pairs = 0;
+            const double xx = mw_tail_event(zr + gamma, gamma, role, tail_log1p, MW_SEG, &pairs);
+            e_kind = 3; e_delta = 2 * pairs;
+            e_tail = ((raw >> 9) & 1) ? (-ZIG_NOR_R - xx) : (ZIG_NOR_R + xx);
+        } else {
+            const double u1 = u52_to_unit(nxt);
+#ifdef PTE_MW_FI_GLOBAL
+            const double f1 = ZIG_FI[idx - 1], f0 = ZIG_FI[idx];
+#else
+            const double f1 = L->fi[idx - 1], f0 = L->fi[idx];
+#endif
+            const double t = -0.5 * xv * xv;
+            const double y = (f1 - f0) * u1 + f0;
+            const double ea = (double)__builtin_amdgcn_exp2f((float)t * 1.44269504088896341f);     // decided by the single-precision exp2 outside a band of 8e-6, exactly inside it
+            e_kind = (y < ea * (1.0 - 8e-6)) ? 1 : ((y > ea * (1.0 + 8e-6)) ? 2 : 0);
+            if (__builtin_expect(e_kind == 0, 0)) e_kind = (y < mw_exp_exact(t)) ? 1 : 2;
+            e_delta = e_kind;
+        }
+    }
+    // 3. which events start an attempt (pte_normals.hpp, step 3), the consumed positions
+    const int e_cons = (e_kind == 3) ? e_delta : 1;
+    const int prev_end = __shfl_up(e_pos + e_cons, 2, 64);
+    const bool covered = is_ev && lane > 1 && e_pos <= prev_end;
+    bool live = is_ev;
+    if (ballot64(covered) != 0ull) {
+        for (int itj = 0; itj < 3; ++itj) { const bool pl = __shfl_up((int)live, 2, 64) != 0; live = is_ev && !(covered && pl); }
+        const bool pl = __shfl_up((int)live, 2, 64) != 0;
+        const int prev2_end = __shfl_up(e_pos + e_cons, 4, 64);
+        const bool bad = (live != (is_ev && !(covered && pl))) || (is_ev && lane > 3 && e_pos <= prev2_end);
+        if (ballot64(bad) != 0ull) {
+            uint64_t lm = 0ull; int cend = -1;
+            for (int j = 0; j < 2 * n_ev; j += 2) {
+                const int pq = __builtin_amdgcn_readlane(e_pos, j);
+                if (pq <= cend) continue;
+                lm |= 1ull << j;
+                cend = pq + __builtin_amdgcn_readlane(e_cons, j);
+            }
+            live = __builtin_amdgcn_inverse_ballot_w64(lm);
+        }
+    }
+    {   // an attempt that consumes positions of the NEXT segment: one position (a wedge at this segment's last position) is followed, more is not
+        const uint64_t sm = ballot64(live && e_pos + e_cons >= MW_SEG);
+        if (sm != 0ull) {
+            const int sl = (int)__builtin_ctzll(sm);
+            const int over = __builtin_amdgcn_readlane(e_pos, sl) + __builtin_amdgcn_readlane(e_cons, sl) - (MW_SEG - 1);
+            spill = (spill == 0 && over == 1 && __popcll(sm) == 1) ? 1 : 99;
+        }
+    }
+    const int e_d = live ? e_delta : 0;
+    const int e_incl = wave_iscan_i32(e_d);
+    const int e_kout = e_pos - (e_incl - e_d);          // the output (counted from the segment's first) the attempt belongs to
+    if (live) {
+        const int first = e_pos + ((e_kind == 2) ? 0 : 1), last = min(e_pos + ((e_kind == 3) ? e_delta : 1), MW_SEG - 1);
+        for (int q = first; q <= last; ++q) out[q] = NRM_DEAD;
+        if (e_kind == 3) out[e_pos] = e_tail;
+    }
+    const int consumed = __builtin_amdgcn_readlane(e_incl, 63);
+    const int first_is_event = (n_ev > 0 && evl[0] == 0) ? 1 : 0;              // (a spill INTO this segment must not land on an event)
+    if (lane == 0) { L->mom_cons[w] = consumed; L->mom_fail[w] = spill | (first_is_event << 8); }
+    __syncthreads();
+    // 4. across the waves: outputs before this segment = positions before it minus the positions consumed before it
+    int before = 0, any_fail = 0, total = 0, spill_in = 0, prev_spill = 0;
+#pragma unroll
+    for (int u = 0; u < NWV; ++u) {
+        const int cu = L->mom_cons[u], fu = L->mom_fail[u], su = fu & 0xFF, eu = fu >> 8;
+        const int o0 = MW_SEG * u - (total - prev_spill);             // index of segment u's first output (a position spilled into it is counted before it, but lies in it)
+        if (o0 < dn) {                                                  // (a segment past the last output wanted may be anything)
+            if (su > 1 || (prev_spill == 1 && eu)) any_fail = 1;
+            if (su == 1 && u == NWV - 1) any_fail = 1;
+        }
+        if (u == w) { before = total; spill_in = prev_spill; }
+        total += cu;
+        prev_spill = (su == 1) ? 1 : 0;
+    }
+    if (NWV * MW_SEG - total < dn + 2) any_fail = 1;
+    if (__builtin_expect(any_fail, 0)) {                            // uniform over the workgroup: everybody read the same words
+        __syncthreads();                                            // (the segments are done with)
+        return mw_draw_momentum_sequential<FULL>(L, seed0, gamma, d);
+    }
+    if (spill_in) out[0] = NRM_DEAD;                                // consumed by the last attempt of the segment before (lane-uniform store of one word)
+    __builtin_amdgcn_wave_barrier();
+    const int out0 = MW_SEG * w - before + spill_in;               // index of this segment's first output
+    {
+        double vall[MW_SLOTS];
+#pragma unroll
+        for (int j = 0; j < MW_SLOTS; ++j) vall[j] = out[64 * j + lane];
+        int cum = out0;
+#pragma unroll
+        for (int j = 0; j < MW_SLOTS; ++j) {
+            const double vj = vall[j];
+            const uint64_t keep = ballot64(vj == vj);
+            const int at = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(keep >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)keep, (unsigned)cum));
+            if (vj == vj && at < MW_DMAX) L->mom.out[at] = vj;
+            cum += __popcll(keep);
+        }
+    }
+    {   // draws consumed by the attempts of the outputs below dn (the live events are sorted by output): the stream's new position
+        const uint64_t below = ballot64(live && (MW_SEG * w - before) + e_kout < dn);
+        const int cb = below ? __builtin_amdgcn_readlane(e_incl, 63 - (int)__builtin_clzll(below)) : 0;
+        if (lane == 0) L->mom_below[w] = cb;
+    }
+    __syncthreads();
+    return seed0 + (uint64_t)(dn + ((L->mom_below[0] + L->mom_below[1]) + (L->mom_below[2] + L->mom_below[3]))) * gamma;
+}
+
+template <int TGT, bool FULL>
+__device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmParams &ap, const int64_t wg) {
+    constexpr int EW = MW_EW, NWV = MW_NWV;
+    static_assert(NWV == 4, "the cross-wave levels of the tree are written for four waves");
+    __shared__ MwLds L;
+    const int lane = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int i = (int)threadIdx.x; i < 256; i += 64 * NWV) {
+        L.wi[i] = ZIG_WI[i]; L.ki[i] = ZIG_KI[i];
+#ifndef PTE_MW_FI_GLOBAL
+        L.fi[i] = ZIG_FI[i];
+#endif
+    }
+    __syncthreads();
+    const int64_t cl = am_chain_of_workgroup(e.K, wg);
+    if (cl >= e.K) return;
+    const int64_t c = e.c0 + cl;
+    const int slot = e.slot_of_chain[cl];
+    const int64_t d = e.d;
+    double *xrow = e.x + (int64_t)slot * e.ld;
+    const double nhp = e.nhp[c], nprec = e.nprec[c];
+    const double beta = e.beta[c], omb = 1.0 - beta;
+    const double ref_nhp = -0.5 * ap.ref_prec, ref_nprec = -ap.ref_prec, log3 = ap.log3;
+    const bool v_on = (TGT == TGT_FUNNEL) && e.v_use != nullptr;      // a GaussianReference is active on this engine
+    const bool vr = v_on && e.v_use[c] != 0;
+    int par = 0, ypar = 0;                                            // uniform: which half of the exchange buffers the next exchange uses
+    const MwLdsP Lp = (MwLdsP)&L;
+#ifdef PTE_PROFILE_AM                      // debug builds only (tools/prof_mw.py): shader-clock time per section of the refresh loop, wave 0's view
+    uint64_t mw_prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mw_sync = 0;
+    uint64_t mw_tlast = __builtin_amdgcn_s_memtime();
+    const uint64_t mw_rt0 = __builtin_amdgcn_s_memrealtime();
+#define MW_STAMP(k) do { asm volatile("" ::: "memory"); const uint64_t t_ = __builtin_amdgcn_s_memtime(); mw_prof[k] += t_ - mw_tlast; mw_tlast = t_; asm volatile("" ::: "memory"); } while (0)
+#define MW_X0() asm volatile("" ::: "memory"); const uint64_t tq1_ = __builtin_amdgcn_s_memtime()
+#define MW_X1() asm volatile("" ::: "memory"); mw_sync += __builtin_amdgcn_s_memtime() - tq1_
+#else
+#define MW_STAMP(k) do { } while (0)
+#define MW_X0() do { } while (0)
+#define MW_X1() do { } while (0)
+#endif
+
+    // A value that is the same in all 64 lanes, MOVED to a scalar register pair: the sums, log densities, bounds and step sizes of the algorithm are
+    // wave-uniform doubles that live across the whole search -- computed by vector instructions they would each hold two VGPRs of the 128
+    auto U = [](double v) -> double {
+        return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    };
+    const int cbase = 64 * EW * w + EW * lane;                         // this lane's first coordinate: four consecutive ones per lane
+    auto valid = [&](int j) -> bool { return FULL || (int64_t)(cbase + j) < d; };
+    auto gidx = [&](int j) -> int { return cbase + j; };
+    const bool owns_first = (w == 0 && lane == 0);                    // the lane that holds coordinate 0
+    // ---- IEEE division by a value that stays the same for many divisions (the preconditioner's diagonal for the whole scan, the funnel's sigma for
+    // one evaluation): a / b as q = a r, q' = fma(fma(-q, b, a), r, q) with r = RN(1 / b) -- correctly rounded (Markstein 1990: r the correctly rounded
+    // reciprocal, no over / underflow, b's significand not all ones), i.e. the SAME bits as the division the reference makes, in 3 instructions
+    // instead of ~13 with ~10 temporaries each.  Whatever the theorem does not cover takes the division itself, decided per vector (uniform branch):
+    // a quotient outside [2^-900, 2^900] -- zero, subnormal, infinite, NaN -- in a lane that holds a coordinate, or an excluded divisor.
+    // (tests/test_gpu_langevin_mw.py holds the kernel bit for bit to the one-wave kernel, which divides.)
+    auto markstein_divisor_ok = [](double b) -> bool {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(b);
+        const int ex = (int)((u >> 52) & 0x7FF);
+        return (u & MASK52) != MASK52 && ex > 1023 - 500 && ex < 1023 + 500;
+    };
+    auto quotient_in_range = [](double q) -> bool { const double a = fabs(q); return a >= 0x1p-900 && a <= 0x1p900; };
+    // ---- sums: the wave's four blocks (tree_sum_regs*: one subtree of the fixed tree), then the two cross-wave levels from the partial sums of all four waves
+    auto exchange = [&](const auto &mine, auto &out) {                 // K partial sums -> K roots, one barrier
+        constexpr int K = (int)(sizeof(mine) / sizeof(double));
+        MW_X0();
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) L.part[par][w][k] = mine[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k) out[k] = U((L.part[par][0][k] + L.part[par][1][k]) + (L.part[par][2][k] + L.part[par][3][k]));
+        par ^= 1;
+        MW_X1();
+    };
+    // the wave's 256-leaf node of K sums in lockstep: two in-lane levels, six across the lanes
+    auto wave_nodes = [&](auto &leaf4 /* [K][EW] */, auto &nodes /* [K] */) {
+        constexpr int K = (int)(sizeof(nodes) / sizeof(double));
+        static_assert(EW == 4, "two in-lane levels");
+        double v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = (leaf4[k][0] + leaf4[k][1]) + (leaf4[k][2] + leaf4[k][3]);
+        if constexpr (K == 1) nodes[0] = wave_sum_dpp(v[0]);
+        else {
+            wave_sum_dpp_multi<K>(v);
+#pragma unroll
+            for (int k = 0; k < K; ++k) nodes[k] = v[k];
+        }
+    };
+    auto reduce1 = [&](const double (&t)[EW]) -> double {
+        double leaf[1][EW], mine[1], out[1];
+#pragma unroll
+        for (int j = 0; j < EW; ++j) leaf[0][j] = t[j];
+        wave_nodes(leaf, mine);
+        exchange(mine, out);
+        return out[0];
+    };
+    auto sqr_norm = [&](const double (&v)[EW]) -> double {
+        double t[EW];
+#pragma unroll
+        for (int j = 0; j < EW; ++j) t[j] = v[j] * v[j];
+        return reduce1(t);
+    };
+    // the wave's partial sums of |a|^2 and |b|^2, in lockstep
+    auto partial_sqr2 = [&](const double (&a)[EW], const double (&b)[EW], double &sa, double &sb) {
+        double t[2][EW], o[2];
+#pragma unroll
+        for (int j = 0; j < EW; ++j) { t[0][j] = a[j] * a[j]; t[1][j] = b[j] * b[j]; }
+        wave_nodes(t, o);
+        sa = o[0]; sb = o[1];
+    };
+    // x[coordinate 0] to every wave (the funnel: y = z[1], sigma = exp(y / 2) enters every term)
+    auto first_coordinate = [&](const double (&x)[EW]) -> double {
+        MW_X0();
+        if (owns_first) L.ybuf[ypar] = x[0];
+        __syncthreads();
+        const double y = U(L.ybuf[ypar]);
+        ypar ^= 1;
+        MW_X1();
+        return y;
+    };
+    // GaussianReference end of the path (variational leg), constants read where they are used (as the sixteen-block kernel does)
+    auto VM = [&](int j) -> double { return valid(j) ? e.v_mean[gidx(j)] : 0.0; };
+    auto VC0 = [&](int j) -> double { return valid(j) ? e.v_c0[gidx(j)] : 0.0; };
+    auto VI2 = [&](int j) -> double { return valid(j) ? e.v_i2[gidx(j)] : 0.0; };
+    auto VGF = [&](int j) -> double { return valid(j) ? e.v_gf[gidx(j)] : 0.0; };
+    auto variational_lp = [&](const double (&x)[EW]) -> double {          // gaussian_logdensity (GaussianReference.jl:43-49), fixed tree
+        double t[EW];
+#pragma unroll
+        for (int j = 0; j < EW; ++j) { const double dx = x[j] - VM(j); t[j] = valid(j) ? (VC0(j) - VI2(j) * (dx * dx)) : 0.0; }
+        return reduce1(t);
+    };
+    auto ref_lp = [&](const double (&x)[EW], double S) -> double { if (__builtin_expect(vr, 0)) return variational_lp(x); return ref_nhp * S; };
+    // a / sigma for the wave's coordinates (sigma uniform; rinv = 1 / sigma)
+    auto div_sigma = [&](const double (&a)[EW], double sigma, double rinv, bool divisor_ok, double (&o)[EW]) {
+        double tq[EW];
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < EW; ++j) {
+            const double q = a[j] * rinv;
+            tq[j] = __builtin_fma(__builtin_fma(-q, sigma, a[j]), rinv, q);
+            bad = bad || (valid(j) && !quotient_in_range(q));
+        }
+        if (__builtin_expect(!divisor_ok || ballot64(bad) != 0ull, 0)) {
+#pragma unroll
+            for (int j = 0; j < EW; ++j) o[j] = mw_div_exact(a[j], sigma);
+        } else {
+#pragma unroll
+            for (int j = 0; j < EW; ++j) o[j] = tq[j];
+        }
+    };
+    // the funnel's gradient without the first coordinate's sum (AmTarget::funnel: g2 = -(z / sigma) / sigma) blended with the reference's:
+    // g[j] = (reference gradient) (1 - beta) + g2[j] beta; the owner of coordinate 0 overwrites its entry once the sum is known
+    auto funnel_gradient_elementwise = [&](const double (&x)[EW], const double (&zi)[EW], double sigma, double rinv, bool sok, double (&g)[EW]) {
+        double zs[EW];
+        div_sigma(zi, sigma, rinv, sok, zs);
+        if (__builtin_expect(vr, 0)) {               // BufferedAD{GaussianReference}: -1/s^2 (x - m)
+#pragma unroll
+            for (int j = 0; j < EW; ++j) g[j] = (VGF(j) * (x[j] - VM(j))) * omb + (valid(j) ? -zs[j] : 0.0) * beta;
+        } else {
+#pragma unroll
+            for (int j = 0; j < EW; ++j) g[j] = (ref_nprec * x[j]) * omb + (valid(j) ? -zs[j] : 0.0) * beta;
+        }
+    };
+    // funnel log density alone (test/supporting/dimensional-analysis.jl:36-48): AmTarget::funnel, term for term
+    auto funnel_lp = [&](const double (&x)[EW]) -> double {
+        const double y = first_coordinate(x);
+        const double sigma = U(exp(y / 2.0));
+        const double logsigma = U(log(sigma));
+        const double rinv = U(1.0 / sigma);
+        const bool sok = markstein_divisor_ok(sigma);
+        const double LOG2PI = 1.8378770664093453;
+        double t[EW], zi[EW];
+        div_sigma(x, sigma, rinv, sok, zi);
+#pragma unroll
+        for (int j = 0; j < EW; ++j) t[j] = valid(j) ? (-(zi[j] * zi[j] + LOG2PI) / 2.0 - logsigma) : 0.0;
+        const double zv = y / 3.0;
+        if (owns_first) t[0] = -(zv * zv + LOG2PI) / 2.0 - log3;
+        return reduce1(t);
+    };
+    // LogDensityProblems.logdensity_and_gradient of the interpolated funnel path with Q = sum q^2 taken alongside (AmTarget::logdensity_and_gradient_q<true>):
+    // four independent fixed trees, their in-wave parts taken two at a time (registers), ONE exchange for all four
+    auto funnel_logdensity_and_gradient_q = [&](const double (&x)[EW], double (&g)[EW], const double (&q)[EW], double &Q) -> double {
+        const double y = first_coordinate(x);
+        const double sigma = U(exp(y / 2.0));
+        const double logsigma = U(log(sigma));
+        const double rinv = U(1.0 / sigma);
+        const bool sok = markstein_divisor_ok(sigma);
+        const double LOG2PI = 1.8378770664093453;
+        double mine[4], out[4];
+        partial_sqr2(x, q, mine[0], mine[3]);
+        {
+            double zi[EW];
+            div_sigma(x, sigma, rinv, sok, zi);
+            {
+                double t[2][EW], o[2];
+#pragma unroll
+                for (int j = 0; j < EW; ++j) {
+                    t[0][j] = valid(j) ? (-(zi[j] * zi[j] + LOG2PI) / 2.0 - logsigma) : 0.0;
+                    t[1][j] = valid(j) ? (zi[j] * zi[j] - 1.0) / 2.0 : 0.0;
+                }
+                const double zv = y / 3.0;
+                if (owns_first) { t[0][0] = -(zv * zv + LOG2PI) / 2.0 - log3; t[1][0] = -(y / 9.0); }
+                wave_nodes(t, o);
+                mine[1] = o[0]; mine[2] = o[1];
+            }
+            funnel_gradient_elementwise(x, zi, sigma, rinv, sok, g);
+        }
+        exchange(mine, out);
+        const double S = out[0], l2 = out[1];
+        Q = out[3];
+        if (owns_first) {                            // g2[0] = the sum; the same blend as the other coordinates
+            if (__builtin_expect(vr, 0)) g[0] = (VGF(0) * (x[0] - VM(0))) * omb + out[2] * beta;
+            else g[0] = (ref_nprec * x[0]) * omb + out[2] * beta;
+        }
+        const double l1 = ref_lp(x, S);
+        double logdens = 0.0;
+        logdens += l1 * omb;
+        logdens += l2 * beta;
+        return logdens;
+    };
+
+    double x[EW];
+    if (is_ref_chain(e, c)) {
+        if (e.compose_phase == 2) return;
+        // sample_iid! at the reference (pigeons.jl:104-105): d sequential normals, drawn and stored by wave 0 as the one-wave kernel does
+        double lp0r = 0.0, S0 = 0.0;
+        if (w == 0) {
+            lp0r = lp_before_explore(e, c, slot);
+            if (vr) {      // sample_iid!(::GaussianReference) (GaussianReference.jl:33-40): x_i = randn * sd_i + mean_i, in draw order
+                SeqRng r0{e.rng[2 * slot], e.rng[2 * slot + 1]};
+                for (int jg = 0; jg < NWV * EW; ++jg) {
+                    const int nl = (int)max((int64_t)0, min((int64_t)64, d - 64 * (int64_t)jg));
+                    if (nl > 0) {
+                        const double z = wave_randn_block(r0, lane, nl);
+                        if (lane < nl) xrow[64 * jg + lane] = z * e.v_std[64 * jg + lane] + e.v_mean[64 * jg + lane];
+                    }
+                }
+                if (lane == 0) e.rng[2 * slot] = r0.seed;
+            } else {
+                S0 = iid_refresh<4>(e, slot, e.sd[c], lane);
+            }
+        }
+        __syncthreads();                                              // wave 0's row is visible to the workgroup (one compute unit: one L1)
+        if (TGT == TGT_FUNNEL || vr) {
+#pragma unroll
+            for (int j = 0; j < EW; ++j) x[j] = valid(j) ? xrow[gidx(j)] : 0.0;
+        }
+        if (vr) { S0 = sqr_norm(x); if (owns_first) e.suff[slot] = S0; }
+        double l20 = 0.0, l30 = 0.0;
+        if (TGT == TGT_FUNNEL) {
+            l20 = funnel_lp(x);
+            if (owns_first) e.suff2[slot] = l20;
+            if (v_on) { l30 = variational_lp(x); if (owns_first) e.suff3[slot] = l30; }
+        }
+        if (w == 0) record_after_explore_impl(e, cl, c, slot, lane, lp0r, S0, l20, l30);
+        return;
+    }
+    const double lp_before = (w == 0) ? lp_before_explore(e, c, slot) : 0.0;
+#pragma unroll
+    for (int j = 0; j < EW; ++j) x[j] = valid(j) ? xrow[gidx(j)] : 0.0;
+
+    SeqRng r{e.rng[2 * slot], e.rng[2 * slot + 1]};                   // every wave holds the stream; they advance it identically
+    // build_preconditioner! (Preconditioner.jl:57-77)
+    double M[EW];
+#pragma unroll
+    for (int j = 0; j < EW; ++j) M[j] = 1.0;
+    if (ap.target_std != nullptr && ap.precond != 0) {
+        double sdv[EW];
+#pragma unroll
+        for (int j = 0; j < EW; ++j) sdv[j] = valid(j) ? ap.target_std[gidx(j)] : 1.0;
+        if (ap.precond == 1) {
+#pragma unroll
+            for (int j = 0; j < EW; ++j) M[j] = sdv[j] == 0.0 ? 1.0 : 1.0 / sdv[j];
+        } else {
+            const double u = r.rand();
+            if (u <= ap.p0) {
+#pragma unroll
+                for (int j = 0; j < EW; ++j) M[j] = sdv[j] == 0.0 ? 1.0 : 1.0 / sdv[j];
+            } else if (u <= ap.p0 + ap.p1) {
+                // ones
+            } else {
+                const double mix = r.rand(), rmix = 1.0 - mix;
+#pragma unroll
+                for (int j = 0; j < EW; ++j) M[j] = sdv[j] == 0.0 ? 1.0 : mix + rmix / sdv[j];
+            }
+        }
+    }
+    double Minv[EW];
+    bool m_not_one = false, m_excluded = false;
+#pragma unroll
+    for (int j = 0; j < EW; ++j) {
+        Minv[j] = 1.0 / M[j];
+        m_not_one = m_not_one || (valid(j) && M[j] != 1.0);
+        m_excluded = m_excluded || (valid(j) && !markstein_divisor_ok(M[j]));
+    }
+    const bool m_one = ballot64(m_not_one) == 0ull;                    // the identity (round 1; a third of the scans of MixDiagonalPreconditioner): a / 1.0 is a
+    const bool m_ok = ballot64(m_excluded) == 0ull;
+    // a[j] / M[j] for the wave's coordinates; `o` may be `a`
+    auto div_M = [&](const double (&a)[EW], double (&o)[EW]) {
+        if (m_one) {
+#pragma unroll
+            for (int j = 0; j < EW; ++j) o[j] = a[j];
+            return;
+        }
+        double tq[EW];
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < EW; ++j) {
+            const double q = a[j] * Minv[j];
+            tq[j] = __builtin_fma(__builtin_fma(-q, M[j], a[j]), Minv[j], q);
+            bad = bad || (valid(j) && !quotient_in_range(q));
+        }
+        if (__builtin_expect(!m_ok || ballot64(bad) != 0ull, 0)) {
+#pragma unroll
+            for (int j = 0; j < EW; ++j) o[j] = mw_div_exact(a[j], M[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < EW; ++j) o[j] = tq[j];
+        }
+    };
+
+    double p[EW], g[EW], pb[EW], g0[EW];
+    long long steps_sum = 0; int steps_n = 0;
+    double fac_sum = 0.0; int fac_n = 0;
+    int rev_sum = 0, rev_n = 0;
+    double acc_sum = 0.0; int acc_n = 0;
+    int err = 0;
+    // (as in the one-wave kernel: each point's log density / conditioned gradient is evaluated once and its bits reused where the
+    // reference recomputes them -- pure functions of the state)
+    double lp0 = 0.0, pp0 = 0.0;
+    // log density and CONDITIONED gradient at x, with Q = sum q^2
+    auto density_and_conditioned_gradient = [&](double (&gout)[EW], const double (&q)[EW], double &Q) -> double {
+        double lp;
+        if constexpr (TGT == TGT_MVN) {
+            double mine[2], out[2];
+            partial_sqr2(x, q, mine[0], mine[1]);
+#pragma unroll
+            for (int j = 0; j < EW; ++j) gout[j] = nprec * x[j];
+            exchange(mine, out);
+            Q = out[1];
+            lp = nhp * out[0];
+        } else lp = funnel_logdensity_and_gradient_q(x, gout, q, Q);
+        div_M(gout, gout);
+        return lp;
+    };
+    // the conditioned gradient at x alone, given the first coordinate's entry (kept from the evaluation that made the sum): elementwise
+    auto conditioned_gradient_again = [&](double (&gout)[EW], double first_entry) {
+        if constexpr (TGT == TGT_MVN) {
+#pragma unroll
+            for (int j = 0; j < EW; ++j) gout[j] = nprec * x[j];
+        } else {
+            const double y = first_coordinate(x);
+            const double sigma = U(exp(y / 2.0));
+            const double rinv = U(1.0 / sigma);
+            const bool sok = markstein_divisor_ok(sigma);
+            double zi[EW];
+            div_sigma(x, sigma, rinv, sok, zi);
+            funnel_gradient_elementwise(x, zi, sigma, rinv, sok, gout);
+        }
+        div_M(gout, gout);
+        if (TGT != TGT_MVN && owns_first) gout[0] = first_entry;
+    };
+    auto kinetic = [&]() -> double { return U(0.5 * sqr_norm(p)); };
+    auto leap_frog = [&](double eps, double &logp_out, double &ke_out) -> bool {      // hamiltonian_dynamics! with n_steps = 1
+        const double half = eps / 2;
+#pragma unroll
+        for (int j = 0; j < EW; ++j) p[j] = p[j] + half * g0[j];
+        {
+            double pm[EW];
+            div_M(p, pm);
+#pragma unroll
+            for (int j = 0; j < EW; ++j) x[j] = x[j] + eps * pm[j];
+        }
+        if constexpr (TGT == TGT_MVN) {
+            // the gradient is elementwise here (-prec x), so the momentum after the second half kick is known before any sum is: |x|^2, |p|^2
+            // after the first kick and |p|^2 after the second are three independent fixed trees -- ONE exchange per leapfrog instead of two,
+            // the same bits.  The second kick is committed only where the reference makes it (a non-finite joint returns first).
+            double mine[3], out[3], pn[EW];
+#pragma unroll
+            for (int j = 0; j < EW; ++j) g[j] = nprec * x[j];
+            div_M(g, g);
+            {
+                double t[3][EW];
+#pragma unroll
+                for (int j = 0; j < EW; ++j) {
+                    pn[j] = p[j] + half * g[j];
+                    t[0][j] = x[j] * x[j]; t[1][j] = p[j] * p[j]; t[2][j] = pn[j] * pn[j];
+                }
+                wave_nodes(t, mine);
+            }
+            exchange(mine, out);
+            const double logp = U(nhp * out[0]);
+            logp_out = logp;
+            const double ke_mid = U(0.5 * out[1]);
+            ke_out = ke_mid;
+            const double cur = logp - ke_mid;
+            if (__builtin_expect(!isfinite(cur), 0)) return false;
+#pragma unroll
+            for (int j = 0; j < EW; ++j) p[j] = pn[j];
+            const double sq = out[2];
+            ke_out = U(0.5 * sq);
+            if (__builtin_expect(!isfinite(sq), 0)) return false;
+            return true;
+        } else {
+            double pp_mid;
+            const double logp = U(density_and_conditioned_gradient(g, p, pp_mid));
+            logp_out = logp;
+            const double ke_mid = U(0.5 * pp_mid);
+            ke_out = ke_mid;
+            const double cur = logp - ke_mid;
+            if (__builtin_expect(!isfinite(cur), 0)) return false;
+#pragma unroll
+            for (int j = 0; j < EW; ++j) p[j] = p[j] + half * g[j];
+            const double sq = sqr_norm(p);
+            ke_out = U(0.5 * sq);
+            if (__builtin_expect(!isfinite(sq), 0)) return false;
+            return true;
+        }
+    };
+    double lpk = 0.0, kek = 0.0, gk_first = 0.0; bool okk = true;   // the kept trial's scalars (gk_first: its conditioned gradient's first entry, per lane); its vectors: L.v[MW_XK], L.v[MW_PK]
+    // auto_step_size (AutoMALA.jl:184-214) as ONE loop with one trial leapfrog in it (mode 0: the first trial at the current step size; 1: halving
+    // until the joint's change rises above `lower`; 2: doubling until it falls below `upper` or stops being finite) -- the sequence of trials,
+    // of kept trials and of restores is the reference's; one copy of the leapfrog in the kernel instead of six.  `forward`: the search from the
+    // refresh's start point (it keeps the trial the proposal would repeat; x is restored from the start state); otherwise from the proposed
+    // point (x restored from the kept trial's state).  p is restored from pb.
+    auto auto_step_size = [&](double lower, double upper, double h_before, bool forward) -> int {
+        const int xsrc = forward ? MW_XS : MW_XK;
+#pragma unroll
+        for (int j = 0; j < EW; ++j) pb[j] = p[j];
+        double eps = ap.step_size;
+        int mode = 0, n = 0, n_steps = 0, exponent = 0;
+        for (;;) {
+            double t_lp = 0.0, t_ke = 0.0;
+            const bool t_ok = leap_frog(eps, t_lp, t_ke);
+            const double diff = U((t_lp - t_ke) - h_before);
+            const bool stop_growing = mode == 2 && (!isfinite(diff) || diff < upper);
+            if (forward && !stop_growing) {     // the trial the proposal would repeat: the last one when shrinking or not moving, the last but one when growing
+#pragma unroll
+                for (int j = 0; j < EW; ++j) { L.v[MW_XK][gidx(j)] = x[j]; L.v[MW_PK][gidx(j)] = p[j]; }
+                gk_first = g[0];
+                lpk = t_lp; kek = t_ke; okk = t_ok;
+            }
+#pragma unroll
+            for (int j = 0; j < EW; ++j) { x[j] = L.v[xsrc][gidx(j)]; p[j] = pb[j]; }
+            if (mode == 0) {
+                if (!isfinite(diff) || diff < lower) mode = 1;
+                else if (diff > upper) mode = 2;
+                else break;
+            } else if (mode == 1) {
+                if (eps == 0.0) { err = ERR_AM_STEP; break; }
+                if (diff > lower) { n_steps = n; exponent = -n; break; }
+            } else if (stop_growing) { n_steps = n; exponent = n - 1; break; }
+            n += 1;
+            eps = U((mode == 1) ? eps / 2.0 : eps * 2.0);
+        }
+        steps_sum += 1 + n_steps; steps_n += 1;
+        if (e.am_log != nullptr && owns_first && fac_n < e.am_log_cap) e.am_log[(e.trace_idx * e.K + cl) * e.am_log_cap + fac_n] = (int16_t)exponent;
+        fac_sum = U(fac_sum + ldexp(1.0, exponent)); fac_n += 1;
+        return exponent;
+    };
+
+    for (int it = 0; it < ap.n_refresh && !err; ++it) {
+        MW_STAMP(7);
+        // the refresh's start state (read back by the forward search's restores and on a rejection)
+#pragma unroll
+        for (int j = 0; j < EW; ++j) L.v[MW_XS][gidx(j)] = x[j];
+        // the momentum: d sequential randn(rng), left in LDS in output order by the four waves together (mw_draw_momentum)
+        r.seed = mw_draw_momentum<FULL>(Lp, r.seed, r.gamma, d);
+#pragma unroll
+        for (int j = 0; j < EW; ++j) p[j] = valid(j) ? L.mom.out[gidx(j)] : 0.0;
+        __syncthreads();                                                // (the workspace's bytes are the kept trial's and the start gradient's again from here on)
+        MW_STAMP(0);
+        if (it == 0) lp0 = U(density_and_conditioned_gradient(g0, p, pp0));
+        else pp0 = sqr_norm(p);
+        const double lp_s = lp0;
+#pragma unroll
+        for (int j = 0; j < EW; ++j) L.v[MW_GS][gidx(j)] = g0[j];
+        MW_STAMP(1);
+        const double init_joint = U(lp0 - 0.5 * pp0);
+        if (!isfinite(init_joint)) { err = ERR_AM_DENSITY; break; }
+        if (ap.mala) {                                   // mala! (MALA.jl:79-96)
+            double lpn, ken;
+            leap_frog(ap.step_size, lpn, ken);
+#pragma unroll
+            for (int j = 0; j < EW; ++j) p[j] = p[j] * -1.0;
+            const double ex = exp((lpn - ken) - init_joint);
+            const double probability = ex < 1.0 ? ex : (isnan(ex) ? ex : 1.0);
+            acc_sum = U(acc_sum + probability); acc_n += 1;
+            if (!(r.rand() < probability)) {
+#pragma unroll
+                for (int j = 0; j < EW; ++j) x[j] = L.v[MW_XS][gidx(j)];                 // (lp0, g0 stay those of the start point)
+            } else {
+                lp0 = lpn;
+#pragma unroll
+                for (int j = 0; j < EW; ++j) g0[j] = g[j];
+            }
+            steps_sum += 1; steps_n += 1;
+            continue;
+        }
+        const double ua = r.rand(), ub = r.rand();
+        const double lower = U(log(ua < ub ? ua : ub)), upper = U(log(ua < ub ? ub : ua));
+        MW_STAMP(2);
+        // forward search from the start point, then (scan != 1) the reversed search from the proposed point: one copy of the search
+        int proposed = 0, reversed = 0;
+        double h_rev = 0.0;
+        for (int dir = 0; dir < 2 && !err; ++dir) {
+            if (dir == 1) {
+                MW_STAMP(3);
+                // leap_frog!(..., step_size * 2^proposed) from the start point == the trial the search kept: its state and momentum from LDS, its
+                // conditioned gradient evaluated again (elementwise; the same bits)
+#pragma unroll
+                for (int j = 0; j < EW; ++j) { x[j] = L.v[MW_XK][gidx(j)]; p[j] = L.v[MW_PK][gidx(j)]; }
+                lp0 = lpk;                                   // log density at the proposed point: the leapfrog computed it
+                conditioned_gradient_again(g0, gk_first);
+                MW_STAMP(4);
+                if (!ap.use_mh) break;                       // no MH step: the chain stays where the proposal leapfrog ended
+#pragma unroll
+                for (int j = 0; j < EW; ++j) p[j] = p[j] * -1.0;
+                h_rev = U(lp0 - (okk ? kek : kinetic()));
+            }
+            const int ex = auto_step_size(lower, upper, dir == 0 ? init_joint : h_rev, dir == 0);
+            if (dir == 0) proposed = ex; else reversed = ex;
+        }
+        if (err) break;
+        if (ap.use_mh) {
+            MW_STAMP(5);
+            const bool passed = reversed == proposed;
+            rev_sum += passed ? 1 : 0; rev_n += 1;
+            double probability = 0.0;
+            if (passed) {
+                const double ex = exp(h_rev - init_joint);      // final_joint_log == log_joint at the proposed point
+                probability = ex < 1.0 ? ex : (isnan(ex) ? ex : 1.0);
+            }
+            acc_sum = U(acc_sum + probability); acc_n += 1;
+            if (!(r.rand() < probability)) {
+                lp0 = lp_s;
+#pragma unroll
+                for (int j = 0; j < EW; ++j) { x[j] = L.v[MW_XS][gidx(j)]; g0[j] = L.v[MW_GS][gidx(j)]; }
+            }
+            MW_STAMP(6);
+        }
+    }
+#ifdef PTE_PROFILE_AM
+    if (owns_first) {
+        double *o = e.on_m2 + 2 * (d + 1) + 12 * cl;
+        for (int k = 0; k < 7; ++k) o[k] = (double)mw_prof[k];
+        o[0] += (double)mw_prof[7];            // (loop head + the start state's store: with the momentum)
+        o[7] = (double)(mw_rt0 & 0xFFFFFFFFFFFull); o[10] = (double)mw_sync;       // (o[7]: the workgroup's start on the 100 MHz clock)
+        o[8] = (double)(__builtin_amdgcn_s_memrealtime() - mw_rt0); o[9] = (double)steps_sum; o[11] = (double)ap.n_refresh;
+    }
+#endif
+    if (err) { if (owns_first) set_error(e, err, (int)c, -1); return; }
+#pragma unroll
+    for (int j = 0; j < EW; ++j) if (valid(j)) xrow[gidx(j)] = x[j];
+    const double S = sqr_norm(x);
+    double l2 = 0.0, l3 = 0.0;
+    if (TGT == TGT_FUNNEL) l2 = funnel_lp(x);
+    if (v_on) l3 = variational_lp(x);
+    if (owns_first) {
+        e.suff[slot] = S;
+        if (TGT == TGT_FUNNEL) e.suff2[slot] = l2;
+        if (v_on) e.suff3[slot] = l3;
+        e.rng[2 * slot] = r.seed;
+        e.expl_steps_sum[cl] += (double)steps_sum; e.expl_steps_n[cl] += steps_n;
+        e.expl_acc_sum[cl] += acc_sum;             e.expl_acc_n[cl] += acc_n;
+        e.am_fac_sum[cl] += fac_sum;               e.am_fac_n[cl] += fac_n;
+        e.am_rev_sum[cl] += (double)rev_sum;       e.am_rev_n[cl] += rev_n;
+    }
+    __syncthreads();                                                  // every wave's part of the row is stored before wave 0's recorders read it
+    if (w == 0) record_after_explore(e, cl, c, slot, lane, lp_before, S, l2, l3);
+}
+
+template <int TGT, bool FULL>
+#ifndef PTE_MW_OCC
+#define PTE_MW_OCC 4
+#endif
+__global__ __launch_bounds__(64 * MW_NWV) __attribute__((amdgpu_waves_per_eu(PTE_MW_OCC, PTE_MW_OCC)))
+void k_explore_langevin_mw(EngineDev e, AmParams ap) {
+    langevin_mw_body<TGT, FULL>(e, ap, blockIdx.x);
+}
+
+}  // namespace pte

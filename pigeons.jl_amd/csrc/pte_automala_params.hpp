@@ -29,7 +29,8 @@ struct AmParams {
 // the start / stop events (hipExtLaunchKernelGGL: the kernel's own begin and end, see PTE_LAUNCH1 in pte.hip)
 struct LangevinLaunch { int E; int target; bool slice; bool full; unsigned N; hipStream_t stream; bool ext; hipEvent_t ev_a, ev_b;
                         const ScanLoop *scans = nullptr;        // scans != nullptr: k_scans_automala, all the scans of a pte_run_scans call in one launch
-                        int scan_wg = 1; };                      // ... > 1: k_scans_automala_wg, that many consecutive chains (waves) per workgroup (must equal langevin_scan_wg())
+                        int scan_wg = 1;                         // ... > 1: k_scans_automala_wg, that many consecutive chains (waves) per workgroup (must equal langevin_scan_wg())
+                        bool one_wave16 = false; };              // test build only (PTE_KERNEL_TEST_LANGEVIN_ONE_WAVE): 512 < d <= 1024 on the one-wave kernel with sixteen blocks per lane
 int langevin_launch(const LangevinLaunch &L, const EngineDev &dev, const AmParams &ap);     // 0, or 1 if this build holds no such kernel
 int langevin_scan_loop_blocks_per_cu(int E, int target, bool full, int scan_wg = 1);         // occupancy of k_scans_automala[_wg]<E, target, full> (0: not in this build)
 int langevin_scan_wg();                                                                      // PTE_SCAN_WG of the Langevin translation unit

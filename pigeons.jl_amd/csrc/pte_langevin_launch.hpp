@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_ext.h>
 #include "pte_automala.hpp"
+#include "pte_automala_mw.hpp"
 
 namespace pte {
 
@@ -10,6 +11,12 @@ template <typename K>
 static inline void langevin_launch_one(K kernel, const LangevinLaunch &L, const EngineDev &dev, const AmParams &ap) {
     if (L.ext) hipExtLaunchKernelGGL(kernel, dim3(L.N), dim3(64), 0, L.stream, L.ev_a, L.ev_b, 0, dev, ap);
     else hipLaunchKernelGGL(kernel, dim3(L.N), dim3(64), 0, L.stream, dev, ap);
+}
+
+template <typename K>
+static inline void langevin_launch_mw(K kernel, const LangevinLaunch &L, const EngineDev &dev, const AmParams &ap) {      // one 256-thread workgroup per replica
+    if (L.ext) hipExtLaunchKernelGGL(kernel, dim3(L.N), dim3(64 * MW_NWV), 0, L.stream, L.ev_a, L.ev_b, 0, dev, ap);
+    else hipLaunchKernelGGL(kernel, dim3(L.N), dim3(64 * MW_NWV), 0, L.stream, dev, ap);
 }
 
 template <typename K>
@@ -33,7 +40,7 @@ static inline void langevin_launch_scans(K kernel, const LangevinLaunch &L, cons
 
 int langevin_scan_wg() { return PTE_SCAN_WG; }
 int langevin_scan_loop_blocks_per_cu(int E, int target, bool full, int scan_wg) {
-#ifdef PTE_DEV_NO_LANGEVIN
+#if defined(PTE_DEV_NO_LANGEVIN) || defined(PTE_DEV_ONLY_MW)
     (void)E; (void)target; (void)full; (void)scan_wg; return 0;
 #else
     int n = 0;
@@ -55,6 +62,14 @@ int langevin_launch(const LangevinLaunch &L, const EngineDev &dev, const AmParam
 #ifdef PTE_DEV_NO_LANGEVIN      // development builds only (tools/build_variant.sh): three quarters of the compile time are these instantiations
     (void)L; (void)dev; (void)ap; return 1;
 #else
+#ifdef PTE_DEV_ONLY_MW           // development builds only (tools/build_variant_mw.sh): the four-waves-per-replica kernel and nothing else of the family
+    if (L.scans || L.slice || L.E != 16) return 1;
+    if (L.target == TGT_FUNNEL && L.full) langevin_launch_mw(k_explore_langevin_mw<TGT_FUNNEL, true>, L, dev, ap);
+    else if (L.target == TGT_FUNNEL) langevin_launch_mw(k_explore_langevin_mw<TGT_FUNNEL, false>, L, dev, ap);
+    else if (L.full) langevin_launch_mw(k_explore_langevin_mw<TGT_MVN, true>, L, dev, ap);
+    else langevin_launch_mw(k_explore_langevin_mw<TGT_MVN, false>, L, dev, ap);
+    return 0;
+#else
     if (L.scans) {
         const int target = L.target; const bool full = L.full;
 #define AM_GO(KERNEL) langevin_launch_scans(KERNEL, L, dev, ap)
@@ -73,13 +88,38 @@ int langevin_launch(const LangevinLaunch &L, const EngineDev &dev, const AmParam
     else if (L.target == TGT_FUNNEL) langevin_launch_one(k_explore_automala<EE, TGT_FUNNEL>, L, dev, ap);                        \
     else if (L.full) langevin_launch_one(k_explore_automala<EE, TGT_MVN, false, true>, L, dev, ap);                              \
     else langevin_launch_one(k_explore_automala<EE, TGT_MVN>, L, dev, ap);
-    switch (L.E) { case 1: AM_ONE(1) break; case 2: AM_ONE(2) break; case 4: AM_ONE(4) break; case 8: AM_ONE(8) break; default: AM_ONE(16) break; }
+    switch (L.E) {
+    case 1: AM_ONE(1) break; case 2: AM_ONE(2) break; case 4: AM_ONE(4) break; case 8: AM_ONE(8) break;
+    default:
+        // 512 < d <= 1024.  SliceSampler on the interpolated path: the one-wave kernel's slice instantiation (it holds no momentum, gradient or
+        // trial copies and does not spill).  AutoMALA / MALA: four waves per replica (pte_automala_mw.hpp, round 6) -- the one-wave
+        // instantiations with sixteen blocks per lane (250-300 spilled VGPRs) exist in the test build only, as the A/B reference of the new kernel
+        if (L.slice) { langevin_launch_one(k_explore_automala<16, TGT_FUNNEL, true>, L, dev, ap); break; }
+#ifdef PTE_TEST_KERNELS
+        if (L.one_wave16) {
+            if (L.target == TGT_FUNNEL && L.full) langevin_launch_one(k_explore_automala<16, TGT_FUNNEL, false, true>, L, dev, ap);
+            else if (L.target == TGT_FUNNEL) langevin_launch_one(k_explore_automala<16, TGT_FUNNEL>, L, dev, ap);
+            else if (L.full) langevin_launch_one(k_explore_automala<16, TGT_MVN, false, true>, L, dev, ap);
+            else langevin_launch_one(k_explore_automala<16, TGT_MVN>, L, dev, ap);
+            break;
+        }
+#endif
+        if (L.target == TGT_FUNNEL && L.full) langevin_launch_mw(k_explore_langevin_mw<TGT_FUNNEL, true>, L, dev, ap);
+        else if (L.target == TGT_FUNNEL) langevin_launch_mw(k_explore_langevin_mw<TGT_FUNNEL, false>, L, dev, ap);
+        else if (L.full) langevin_launch_mw(k_explore_langevin_mw<TGT_MVN, true>, L, dev, ap);
+        else langevin_launch_mw(k_explore_langevin_mw<TGT_MVN, false>, L, dev, ap);
+        break;
+    }
 #undef AM_ONE
     return 0;
+#endif
 #endif
 }
 
 void langevin_refresh_funnel_stats(int E, unsigned N, hipStream_t stream, const EngineDev &dev, double log3) {
+#ifdef PTE_DEV_ONLY_MW
+    hipLaunchKernelGGL(k_refresh_funnel_stats<16>, dim3(N), dim3(64), 0, stream, dev, log3); (void)E; return;
+#endif
     switch (E) {
     case 1: hipLaunchKernelGGL(k_refresh_funnel_stats<1>, dim3(N), dim3(64), 0, stream, dev, log3); break;
     case 2: hipLaunchKernelGGL(k_refresh_funnel_stats<2>, dim3(N), dim3(64), 0, stream, dev, log3); break;

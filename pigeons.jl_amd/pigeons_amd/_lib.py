@@ -26,7 +26,8 @@ ABI_VERSION = 2
 KERNEL_DEFAULT, KERNEL_SLICE_SEQUENTIAL, KERNEL_ISING_BITS, KERNEL_ISING_BYTES = 0, 1, 101, 102
 KERNEL_SCAN_LOOP_ONE_CHAIN = 0x2000     # flag: the one-kernel scan loop with ONE chain per workgroup even where the form with several (LDS hand-shakes) exists
 KERNEL_FLAG_BITS = 0x3000
-KERNEL_TEST_DEAD_CHAIN, KERNEL_TEST_LATE_WORKGROUP, KERNEL_TEST_BITS = 0x4000, 0x8000, 0xC000     # fault injection into the one-kernel scan loop: libpte_test.so only
+KERNEL_TEST_DEAD_CHAIN, KERNEL_TEST_LATE_WORKGROUP, KERNEL_TEST_BITS = 0x4000, 0x8000, 0x1C000    # fault injection into the one-kernel scan loop: libpte_test.so only
+KERNEL_TEST_LANGEVIN_ONE_WAVE = 0x10000   # libpte_test.so only: 512 < d <= 1024 on the one-wave Langevin kernel (A/B reference of k_explore_langevin_mw)
 KERNEL_TWO_LAUNCHES = 0x1000            # flag: explore + swap launched per scan even where pte_run_scans could be one kernel (pte_scan_loop_name)
 COMM_ID_BYTES = 128
 RNG_TAIL_LOG1P = 1                      # include/pte_rng_policy.h
