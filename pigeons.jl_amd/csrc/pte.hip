@@ -788,8 +788,6 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.on_mean, (size_t)(2 * (d + 1)));   rc |= dev_alloc(h, &e.on_m2, (size_t)(2 * (d + 1)) + PTE_WAVE_PROFILE_WORDS * (size_t)K);   // (+ 4 words per wave in -DPTE_PROFILE_WAVES builds)
     rc |= dev_alloc(h, &e.eac, (size_t)(5 * K)); rc |= dev_alloc(h, &e.eac_n, (size_t)K);
     rc |= dev_alloc(h, &e.lp_stash, (size_t)K);
-    e.am_stash = nullptr;
-    if (uses_grad && d > 512) rc |= dev_alloc(h, &e.am_stash, (size_t)(K * e.ld));       // k_explore_langevin_mw: one more row per replica (L2-resident: 8 MB at 1024 x 1024)
     const int64_t trace_rows = (cfg->record_flags & PTE_RECORD_TRACES_EXTENDED) ? K : (cfg->n_chains_variational > 0 ? 2 : 1);   // chains traced per scan
     rc |= dev_alloc(h, &e.traces, (cfg->record_flags & PTE_RECORD_TRACES) ? (size_t)(cfg->max_scans_per_round * trace_rows * (d + 1)) : 1, false);
     rc |= dev_alloc(h, &e.on_n, 2);

@@ -56,7 +56,8 @@ struct MwLds {
 #endif
     union { double v[4][MW_DMAX]; MwMomentum mom; };
     double part[2][MW_NWV][4];            // the waves' partial sums of up to four reductions taken in lockstep, double-buffered
-    double ybuf[2];                       // the funnel's first coordinate
+    double ybuf[2][4];                    // the funnel's first coordinate y and what every term needs of it: sigma = exp(y / 2), log sigma, 1 / sigma (evaluated by wave 0 alone)
+    double bounds[2];                     // log of the two uniforms that bound the step-size search (evaluated by wave 0 alone)
     unsigned long long seed[MW_NWV];      // sequential procedure: stream position after wave w's momentum blocks
     int mom_cons[MW_NWV], mom_fail[MW_NWV], mom_below[MW_NWV];      // compaction: positions a segment consumed; what it cannot follow; consumed by the attempts of the outputs below d
 #ifdef PTE_MW_LDS_PAD                     // development builds only: where does the fourth workgroup of a compute unit stop fitting
@@ -302,7 +303,11 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
     const double nhp = e.nhp[c], nprec = e.nprec[c];
     const double beta = e.beta[c], omb = 1.0 - beta;
     const double ref_nhp = -0.5 * ap.ref_prec, ref_nprec = -ap.ref_prec, log3 = ap.log3;
+#ifdef PTE_MW_NO_VR                         // development builds only: what the GaussianReference branches cost in registers
+    const bool v_on = false;
+#else
     const bool v_on = (TGT == TGT_FUNNEL) && e.v_use != nullptr;      // a GaussianReference is active on this engine
+#endif
     const bool vr = v_on && e.v_use[c] != 0;
     int par = 0, ypar = 0;                                            // uniform: which half of the exchange buffers the next exchange uses
     const MwLdsP Lp = (MwLdsP)&L;
@@ -390,15 +395,25 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
         wave_nodes(t, o);
         sa = o[0]; sb = o[1];
     };
-    // x[coordinate 0] to every wave (the funnel: y = z[1], sigma = exp(y / 2) enters every term)
-    auto first_coordinate = [&](const double (&x)[EW]) -> double {
+    // The funnel's scale: y = x[coordinate 0], sigma = exp(y / 2), log sigma, 1 / sigma enter every term.  They are wave-uniform, and the vector
+    // unit has no scalar double arithmetic: evaluated by all four waves they are ~300 instructions of exp and log per evaluation, three quarters of
+    // them redundant -- and the kernel is bound by instruction issue (four waves per SIMD).  Wave 0 (which owns coordinate 0) evaluates them alone
+    // and publishes the four words; the barrier is the one the broadcast of y needed anyway.  Same functions, same argument: the same bits.
+    struct FunnelScale { double y, sigma, logsigma, rinv; };
+    auto funnel_scale = [&](const double (&x)[EW]) -> FunnelScale {
         MW_X0();
-        if (owns_first) L.ybuf[ypar] = x[0];
+        if (w == 0) {
+            const double y = U(x[0]);                                 // (lane 0 is the first lane: coordinate 0)
+            const double sigma = exp(y / 2.0);
+            const double logsigma = log(sigma);
+            const double rinv = 1.0 / sigma;
+            if (lane == 0) { L.ybuf[ypar][0] = y; L.ybuf[ypar][1] = sigma; L.ybuf[ypar][2] = logsigma; L.ybuf[ypar][3] = rinv; }
+        }
         __syncthreads();
-        const double y = U(L.ybuf[ypar]);
+        FunnelScale f{U(L.ybuf[ypar][0]), U(L.ybuf[ypar][1]), U(L.ybuf[ypar][2]), U(L.ybuf[ypar][3])};
         ypar ^= 1;
         MW_X1();
-        return y;
+        return f;
     };
     // GaussianReference end of the path (variational leg), constants read where they are used (as the sixteen-block kernel does)
     auto VM = [&](int j) -> double { return valid(j) ? e.v_mean[gidx(j)] : 0.0; };
@@ -445,10 +460,8 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
     };
     // funnel log density alone (test/supporting/dimensional-analysis.jl:36-48): AmTarget::funnel, term for term
     auto funnel_lp = [&](const double (&x)[EW]) -> double {
-        const double y = first_coordinate(x);
-        const double sigma = U(exp(y / 2.0));
-        const double logsigma = U(log(sigma));
-        const double rinv = U(1.0 / sigma);
+        const FunnelScale fs = funnel_scale(x);
+        const double y = fs.y, sigma = fs.sigma, logsigma = fs.logsigma, rinv = fs.rinv;
         const bool sok = markstein_divisor_ok(sigma);
         const double LOG2PI = 1.8378770664093453;
         double t[EW], zi[EW];
@@ -462,10 +475,8 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
     // LogDensityProblems.logdensity_and_gradient of the interpolated funnel path with Q = sum q^2 taken alongside (AmTarget::logdensity_and_gradient_q<true>):
     // four independent fixed trees, their in-wave parts taken two at a time (registers), ONE exchange for all four
     auto funnel_logdensity_and_gradient_q = [&](const double (&x)[EW], double (&g)[EW], const double (&q)[EW], double &Q) -> double {
-        const double y = first_coordinate(x);
-        const double sigma = U(exp(y / 2.0));
-        const double logsigma = U(log(sigma));
-        const double rinv = U(1.0 / sigma);
+        const FunnelScale fs = funnel_scale(x);
+        const double y = fs.y, sigma = fs.sigma, logsigma = fs.logsigma, rinv = fs.rinv;
         const bool sok = markstein_divisor_ok(sigma);
         const double LOG2PI = 1.8378770664093453;
         double mine[4], out[4];
@@ -631,9 +642,8 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
 #pragma unroll
             for (int j = 0; j < EW; ++j) gout[j] = nprec * x[j];
         } else {
-            const double y = first_coordinate(x);
-            const double sigma = U(exp(y / 2.0));
-            const double rinv = U(1.0 / sigma);
+            const FunnelScale fs = funnel_scale(x);
+            const double sigma = fs.sigma, rinv = fs.rinv;
             const bool sok = markstein_divisor_ok(sigma);
             double zi[EW];
             div_sigma(x, sigma, rinv, sok, zi);
@@ -705,7 +715,7 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
     // of kept trials and of restores is the reference's; one copy of the leapfrog in the kernel instead of six.  `forward`: the search from the
     // refresh's start point (it keeps the trial the proposal would repeat; x is restored from the start state); otherwise from the proposed
     // point (x restored from the kept trial's state).  p is restored from pb.
-    auto auto_step_size = [&](double lower, double upper, double h_before, bool forward) -> int {
+    auto auto_step_size = [&](double &lower, double &upper, double h_before, bool forward) -> int {
         const int xsrc = forward ? MW_XS : MW_XK;
 #pragma unroll
         for (int j = 0; j < EW; ++j) pb[j] = p[j];
@@ -714,6 +724,7 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
         for (;;) {
             double t_lp = 0.0, t_ke = 0.0;
             const bool t_ok = leap_frog(eps, t_lp, t_ke);
+            if (forward && mode == 0) { lower = U(L.bounds[0]); upper = U(L.bounds[1]); }      // (behind the leapfrog's exchange barrier: wave 0 has published them)
             const double diff = U((t_lp - t_ke) - h_before);
             const bool stop_growing = mode == 2 && (!isfinite(diff) || diff < upper);
             if (forward && !stop_growing) {     // the trial the proposal would repeat: the last one when shrinking or not moving, the last but one when growing
@@ -779,8 +790,14 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
             steps_sum += 1; steps_n += 1;
             continue;
         }
+        // the bounds of the search: log of two uniforms (every wave draws them: the streams stay identical); the two logarithms -- ~250 instructions of
+        // wave-uniform arithmetic -- by wave 0 alone, published before the first trial leapfrog's exchange and read by everybody behind its barrier
         const double ua = r.rand(), ub = r.rand();
-        const double lower = U(log(ua < ub ? ua : ub)), upper = U(log(ua < ub ? ub : ua));
+        if (w == 0) {
+            const double lo_ = log(ua < ub ? ua : ub), hi_ = log(ua < ub ? ub : ua);
+            if (lane == 0) { L.bounds[0] = lo_; L.bounds[1] = hi_; }
+        }
+        double lower = 0.0, upper = 0.0;                 // (set by the forward search behind its first exchange)
         MW_STAMP(2);
         // forward search from the start point, then (scan != 1) the reversed search from the proposed point: one copy of the search
         int proposed = 0, reversed = 0;
@@ -852,11 +869,20 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
     if (w == 0) record_after_explore(e, cl, c, slot, lane, lp_before, S, l2, l3);
 }
 
-template <int TGT, bool FULL>
+// Waves per SIMD the register allocation is held to.  Scaled-precision MVN path: 4 = 128 VGPRs, four workgroups per compute unit, 1024 replicas
+// resident; its trial loop is free of scratch traffic (72-88 values are spilled around it, at refresh level).  Funnel path: the evaluation (exp, log,
+// two quotient passes, four sums) does not fit 128 registers with the seven vectors -- held to 4 (or 3) it reloads ~36 values per trial leapfrog from
+// scratch and takes 4.1 (3.1) ms per scan at N = 1024 where 2 waves per SIMD (256 VGPRs, two generations of 512 replicas) take 2.2: measured,
+// profiles/r06_langevin_mw.txt.
 #ifndef PTE_MW_OCC
 #define PTE_MW_OCC 4
 #endif
-__global__ __launch_bounds__(64 * MW_NWV) __attribute__((amdgpu_waves_per_eu(PTE_MW_OCC, PTE_MW_OCC)))
+#ifndef PTE_MW_OCC_FUNNEL
+#define PTE_MW_OCC_FUNNEL 2
+#endif
+template <int TGT, bool FULL>
+__global__ __launch_bounds__(64 * MW_NWV)
+__attribute__((amdgpu_waves_per_eu(TGT == TGT_FUNNEL ? PTE_MW_OCC_FUNNEL : PTE_MW_OCC, TGT == TGT_FUNNEL ? PTE_MW_OCC_FUNNEL : PTE_MW_OCC)))
 void k_explore_langevin_mw(EngineDev e, AmParams ap) {
     langevin_mw_body<TGT, FULL>(e, ap, blockIdx.x);
 }

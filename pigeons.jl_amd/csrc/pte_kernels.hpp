@@ -63,7 +63,6 @@ struct EngineDev {
     // i2 = 1/(2 s^2), gf = -1/s^2 (computed on the host: same libm as the oracle); suff3[slot] = its log density
     const int32_t *v_use; const double *v_mean, *v_std, *v_c0, *v_i2, *v_gf; double *suff3;
     int compose_phase; double *lp_stash;                   // Compose(first, second): 0 single explorer, 1 first, 2 second kernel of the scan; [K] lp before the first
-    double *am_stash;                                      // null, or [K][ld]: k_explore_langevin_mw (AutoMALA / MALA, d > 512) keeps the conditioned gradient at a refresh's start point here
     int32_t *index_process;                                // [scan][slot]
     int32_t *error;                                        // [4] code, chain, coordinate, spare
     uint32_t record_flags;
