@@ -333,6 +333,12 @@ int pte_get_rng_policy(int32_t device, uint32_t *policy);
  * stream (seed, gamma) on the device, in the reference's sequential order.
  * kind: 0 = rand (Float64 in [0,1)), 1 = randn, 2 = randexp, 3 = rand(rng, Bool) as 0.0 / 1.0.  Returns the advanced stream. */
 int pte_test_rng_fill(int32_t device, uint64_t *seed_gamma /*2, in-out*/, int32_t kind, int64_t n, double *out);
+/* The quotient procedure of the Langevin-family kernels, element by element (round 6): the preconditioner's diagonal and the funnel's sigma divide
+ * thousands of values each, so a / b is evaluated as Markstein's correctly rounded q' = fma(fma(-q, b, a), r, q), q = a r, r = RN(1 / b), and as the
+ * division itself wherever the theorem does not apply (quotient estimate outside [2^-900, 2^900], zero, non-finite; divisor with an extreme exponent
+ * or an all-ones significand).  out[i] must equal the IEEE quotient a[i] / b[i] the reference computes (src/explorers/hamiltonian_dynamics.jl:60-76,
+ * `./ M`) bit for bit; took_division[i] = 1 where the guards chose the division. */
+int pte_test_quotient(int32_t device, const double *a, const double *b, int64_t n, double *out, int32_t *took_division);
 /* sqr_norm of each row of x [rows][d] with the engine's fixed reduction tree. */
 int pte_test_sqr_norm(int32_t device, const double *x, int64_t rows, int64_t d, double *out);
 

@@ -1908,6 +1908,21 @@ int pte_test_rng_fill(int32_t device, uint64_t *sg, int32_t kind, int64_t n, dou
     return e == hipSuccess ? 0 : fail(nullptr, "pte_test_rng_fill: %s", hipGetErrorString(e));
 }
 
+int pte_test_quotient(int32_t device, const double *a, const double *b, int64_t n, double *out, int32_t *took_division) {
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, "pte_test_quotient: no HIP device");
+    if (!a || !b || !out || !took_division || n < 1) return fail(nullptr, "pte_test_quotient: bad argument");
+    double *da = nullptr, *db = nullptr, *dout = nullptr; int32_t *dt = nullptr;
+    if (hipMalloc((void **)&da, sizeof(double) * n) != hipSuccess || hipMalloc((void **)&db, sizeof(double) * n) != hipSuccess ||
+        hipMalloc((void **)&dout, sizeof(double) * n) != hipSuccess || hipMalloc((void **)&dt, sizeof(int32_t) * n) != hipSuccess)
+        return fail(nullptr, "pte_test_quotient: hipMalloc failed");
+    hipMemcpy(da, a, sizeof(double) * n, hipMemcpyHostToDevice); hipMemcpy(db, b, sizeof(double) * n, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_test_quotient, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, da, db, n, dout, dt);
+    hipError_t e = hipDeviceSynchronize();
+    hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost); hipMemcpy(took_division, dt, sizeof(int32_t) * n, hipMemcpyDeviceToHost);
+    hipFree(da); hipFree(db); hipFree(dout); hipFree(dt);
+    return e == hipSuccess ? 0 : fail(nullptr, "pte_test_quotient: %s", hipGetErrorString(e));
+}
+
 int pte_test_sqr_norm(int32_t device, const double *x, int64_t rows, int64_t d, double *out) {
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, "pte_test_sqr_norm: no HIP device");
     if (d < 1 || d > 4096) return fail(nullptr, "pte_test_sqr_norm: d must be in 1..4096");

@@ -333,18 +333,7 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
     auto valid = [&](int j) -> bool { return FULL || (int64_t)(cbase + j) < d; };
     auto gidx = [&](int j) -> int { return cbase + j; };
     const bool owns_first = (w == 0 && lane == 0);                    // the lane that holds coordinate 0
-    // ---- IEEE division by a value that stays the same for many divisions (the preconditioner's diagonal for the whole scan, the funnel's sigma for
-    // one evaluation): a / b as q = a r, q' = fma(fma(-q, b, a), r, q) with r = RN(1 / b) -- correctly rounded (Markstein 1990: r the correctly rounded
-    // reciprocal, no over / underflow, b's significand not all ones), i.e. the SAME bits as the division the reference makes, in 3 instructions
-    // instead of ~13 with ~10 temporaries each.  Whatever the theorem does not cover takes the division itself, decided per vector (uniform branch):
-    // a quotient outside [2^-900, 2^900] -- zero, subnormal, infinite, NaN -- in a lane that holds a coordinate, or an excluded divisor.
-    // (tests/test_gpu_langevin_mw.py holds the kernel bit for bit to the one-wave kernel, which divides.)
-    auto markstein_divisor_ok = [](double b) -> bool {
-        const unsigned long long u = (unsigned long long)__double_as_longlong(b);
-        const int ex = (int)((u >> 52) & 0x7FF);
-        return (u & MASK52) != MASK52 && ex > 1023 - 500 && ex < 1023 + 500;
-    };
-    auto quotient_in_range = [](double q) -> bool { const double a = fabs(q); return a >= 0x1p-900 && a <= 0x1p900; };
+    // (quotients: markstein_quotient, pte_device.hpp)
     // ---- sums: the wave's four blocks (tree_sum_regs*: one subtree of the fixed tree), then the two cross-wave levels from the partial sums of all four waves
     auto exchange = [&](const auto &mine, auto &out) {                 // K partial sums -> K roots, one barrier
         constexpr int K = (int)(sizeof(mine) / sizeof(double));

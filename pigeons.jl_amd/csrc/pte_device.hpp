@@ -246,6 +246,26 @@ __device__ __forceinline__ void wave_sum_pairs(double (&v)[M], double (&out)[M /
     }
 }
 #endif
+// ---- IEEE quotients by a divisor that stays the same for many divisions ---------------------------
+// (the preconditioner's diagonal for a whole scan, the funnel's sigma for one evaluation: round 6)
+// a / b as q = a r, q' = fma(fma(-q, b, a), r, q) with r = RN(1 / b): CORRECTLY ROUNDED (Markstein 1990: r the correctly rounded reciprocal, no over /
+// underflow on the way, b's significand not all ones) -- the same bits as the division the reference makes, in 3 instructions instead of ~13 with ~10
+// temporaries.  What the theorem does not cover takes the division itself, decided per vector by the caller (a uniform branch): a quotient estimate
+// outside [2^-900, 2^900] -- zero, subnormal, infinite, NaN -- in a lane that holds a coordinate, or an excluded divisor (extreme exponent, all-ones
+// significand).  pte_test_quotient holds the procedure to a / b on the host; the kernels that use it are held to kernels that divide
+// (tests/test_gpu_langevin_mw.py) and to the oracle.
+__device__ __forceinline__ bool markstein_divisor_ok(double b) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(b);
+    const int ex = (int)((u >> 52) & 0x7FF);
+    return (u & MASK52) != MASK52 && ex > 1023 - 500 && ex < 1023 + 500;
+}
+__device__ __forceinline__ bool quotient_in_range(double q) { const double a = fabs(q); return a >= 0x1p-900 && a <= 0x1p900; }
+__device__ __forceinline__ double markstein_quotient(double a, double b, double rinv, double &q_estimate) {
+    const double q = a * rinv;
+    q_estimate = q;
+    return __builtin_fma(__builtin_fma(-q, b, a), rinv, q);
+}
+
 // ---- sequential (uniform) stream: used on slow paths and for single draws ---------------------
 struct SeqRng {
     uint64_t seed, gamma;   // uniform

@@ -985,6 +985,19 @@ __global__ __launch_bounds__(64) void k_test_rng(uint64_t *sg, int kind, int64_t
 #endif
 
 #ifndef PTE_TU_LANGEVIN
+// pte_test_quotient: the quotient procedure of the Langevin-family kernels (pte_device.hpp: markstein_quotient and its guards) element by element:
+// out[i] = what the kernels compute for a[i] / b[i], took_division[i] = 1 where the guards sent it to the division itself
+__global__ __launch_bounds__(256) void k_test_quotient(const double *a, const double *b, int64_t n, double *out, int32_t *took_division) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double rinv = 1.0 / b[i];
+    double q;
+    const double m = markstein_quotient(a[i], b[i], rinv, q);
+    const bool fast = markstein_divisor_ok(b[i]) && quotient_in_range(q);
+    out[i] = fast ? m : a[i] / b[i];
+    took_division[i] = fast ? 0 : 1;
+}
+
 __global__ __launch_bounds__(64) void k_test_sqr_norm(const double *x, int64_t rows, int64_t d, int nlu, double *out) {
     const int lane = lane_id();
     const int64_t r = blockIdx.x;

@@ -70,7 +70,7 @@ EXPORTS = [
     "pte_get_swap_acceptance", "pte_get_log_sum_ratio", "pte_get_round_trip",
     "pte_get_index_process", "pte_get_explorer_stats", "pte_get_automala_stats",
     "pte_get_online", "pte_get_state", "pte_set_state",
-    "pte_timing_reset", "pte_timing_get", "pte_timing_get_samples", "pte_test_rng_fill", "pte_test_sqr_norm",
+    "pte_timing_reset", "pte_timing_get", "pte_timing_get_samples", "pte_test_rng_fill", "pte_test_sqr_norm", "pte_test_quotient",
     "pte_shard_info", "pte_swap_begin", "pte_swap_finish", "pte_boundary_payload_bytes",
     "pte_boundary_export", "pte_boundary_import", "pte_get_index_process_shard", "pte_get_replica_ids",
     "pte_get_stream", "pte_shard_message_bytes", "pte_shard_set_buffers", "pte_shard_scan_begin",
@@ -139,6 +139,7 @@ def load(path=None):
     L.pte_timing_get_samples.argtypes = [vp, C.c_int, dp, C.c_int64, ip]
     L.pte_test_rng_fill.argtypes = [C.c_int32, up, C.c_int32, C.c_int64, dp]
     L.pte_test_sqr_norm.argtypes = [C.c_int32, dp, C.c_int64, C.c_int64, dp]
+    L.pte_test_quotient.argtypes = [C.c_int32, dp, dp, C.c_int64, dp, C.POINTER(C.c_int32)]
     i32p = C.POINTER(C.c_int32)
     L.pte_shard_info.argtypes = [vp, ip, ip, ip]
     L.pte_swap_begin.argtypes = [vp, C.c_int64, dp, i32p]

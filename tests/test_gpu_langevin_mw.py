@@ -143,3 +143,35 @@ def test_four_waves_against_the_oracle(P, path, N, d, rounds, seed):
             _check_am_round(P, pt, ref, rtol=1e-9)
         else:
             _check_am_round(P, pt, ref, rtol=1e-6, acc_rtol=1e-5, state_atol=1e-6)
+
+
+def test_quotient_procedure_is_the_ieee_quotient():
+    """pte_test_quotient: the quotient procedure of the Langevin-family kernels (Markstein's q' = fma(fma(-q, b, a), r, q) behind its guards) against
+    numpy's a / b, bit for bit: 4 M random pairs over 600 binades, divisors the preconditioner and the funnel's sigma produce, and every edge the guards
+    exist for -- zeros of both signs, subnormals, infinities, NaN, quotients that over / underflow, divisors with an all-ones significand or an extreme
+    exponent.  The fast path must take the bulk (else the test tests nothing) and the edges must take the division."""
+    import ctypes as C
+    from pigeons_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(7)
+    n = 1 << 22
+    a = rng.standard_normal(n) * np.exp2(rng.integers(-300, 300, n).astype(np.float64))
+    b = (1.0 + rng.random(n)) * np.exp2(rng.integers(-300, 300, n).astype(np.float64)) * np.where(rng.random(n) < 0.1, -1.0, 1.0)
+    b[: n // 4] = 1.0 / (1e-3 + 5.0 * rng.random(n // 4))                                   # 1 / sd and mix + (1 - mix) / sd
+    b[n // 4: n // 2] = np.exp(rng.standard_normal(n // 4) * 3.0)                            # sigma = exp(y / 2)
+    ones = np.uint64(0x000FFFFFFFFFFFFF)
+    edges_a = np.array([0.0, -0.0, 5e-324, -5e-324, 1e-310, np.inf, -np.inf, np.nan, 1.7e308, -1.7e308, 1e-300, 3.0, -3.0, 1.0, 2.0 ** -1000, 2.0 ** 1000])
+    edges_b = np.array([1.0, 3.0, 1e-300, 1e300, 2.0 ** -600, 2.0 ** 600, 7.0, 0.1, (np.array([0x3FF0000000000000], dtype=np.uint64) | ones).view(np.float64)[0],
+                        (np.array([0x4000000000000000], dtype=np.uint64) | ones).view(np.float64)[0], -2.5, 1e-320])
+    ea, eb = np.meshgrid(edges_a, edges_b)
+    a = np.concatenate([a, ea.ravel()]); b = np.concatenate([b, eb.ravel()])
+    out = np.zeros(len(a)); took = np.zeros(len(a), dtype=np.int32)
+    dp = C.POINTER(C.c_double)
+    assert L.pte_test_quotient(0, a.ctypes.data_as(dp), b.ctypes.data_as(dp), len(a), out.ctypes.data_as(dp), took.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+    with np.errstate(all="ignore"):
+        want = a / b
+    same = (out.view(np.uint64) == want.view(np.uint64)) | (np.isnan(out) & np.isnan(want))
+    assert same.all(), (int((~same).sum()), a[~same][:5], b[~same][:5], out[~same][:5], want[~same][:5])
+    assert took[:n].mean() < 0.02                                                            # the fast path takes the bulk
+    assert took[n:].mean() > 0.5                                                             # the edges take the division
+    assert (took[n:][(ea.ravel() == 0.0) | ~np.isfinite(ea.ravel())] == 1).all()             # zeros (of both signs), infinities, NaN: always
