@@ -260,6 +260,14 @@ end
 # either way; `debug_kernel = PTE_KERNEL_TWO_LAUNCHES` (0x1000) in the config forces the per-scan loop, `PTE_KERNEL_SCAN_LOOP_ONE_CHAIN`
 # (0x2000) the one-chain-per-workgroup form of the one-kernel loop.
 scan_loop_name(r::DeviceReplicas) = unsafe_string(ccall((:pte_scan_loop_name, libpte), Cstring, (Ptr{Cvoid},), r.handle))
+# Round 6: the one kernel cannot hang (residency gate inside the launch, fallback to the launch-per-scan loop: include/pte.h, pte_scan_loop_stats).
+# (fused_calls, gate_aborts, poisoned): calls that ran as one launch; launches that found a workgroup missing and fell back (same results); whether
+# a failure inside the kernel has poisoned the handle -- then only `pte_set_state` (a checkpoint's state, chain, rng) or `pte_destroy` are accepted.
+function scan_loop_stats(r::DeviceReplicas)
+    f = Ref{Int64}(0); a = Ref{Int64}(0); p = Ref{Int32}(0)
+    check(r, ccall((:pte_scan_loop_stats, libpte), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int32}), r.handle, f, a, p))
+    return (fused_calls = f[], gate_aborts = a[], poisoned = p[] != 0)
+end
 
 # adapt(pt, reduced_recorders) ran on the host (adapt_tempering: src/tempering/NonReversiblePT.jl:46-66, StabilizedPT.jl:53-65;
 # adapt_explorer: AutoMALA.jl:70-79, MALA.jl:63-69, Compose.jl:10-14; update_reference!: GaussianReference.jl:24-31): push the results
