@@ -55,7 +55,7 @@ struct MwLds {
     double fi[256];                                                  // ... and the wedge test's
 #endif
     union { double v[4][MW_DMAX]; MwMomentum mom; };
-    double part[2][MW_NWV][4];            // the waves' partial sums of up to four reductions taken in lockstep, double-buffered
+    alignas(16) double part[2][4][MW_NWV]; // the waves' partial sums of up to four reductions taken in lockstep, double-buffered; [sum][wave]: a sum's four words are two 16-byte reads
     double ybuf[2][4];                    // the funnel's first coordinate y and what every term needs of it: sigma = exp(y / 2), log sigma, 1 / sigma (evaluated by wave 0 alone)
     double bounds[2];                     // log of the two uniforms that bound the step-size search (evaluated by wave 0 alone)
     unsigned long long seed[MW_NWV];      // sequential procedure: stream position after wave w's momentum blocks
@@ -340,11 +340,14 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
         MW_X0();
         if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) L.part[par][w][k] = mine[k];
+            for (int k = 0; k < K; ++k) L.part[par][k][w] = mine[k];
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < K; ++k) out[k] = U((L.part[par][0][k] + L.part[par][1][k]) + (L.part[par][2][k] + L.part[par][3][k]));
+        for (int k = 0; k < K; ++k) {
+            const double2 a = *reinterpret_cast<const double2 *>(&L.part[par][k][0]), b = *reinterpret_cast<const double2 *>(&L.part[par][k][2]);
+            out[k] = U((a.x + a.y) + (b.x + b.y));
+        }
         par ^= 1;
         MW_X1();
     };
@@ -416,22 +419,25 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
         return reduce1(t);
     };
     auto ref_lp = [&](const double (&x)[EW], double S) -> double { if (__builtin_expect(vr, 0)) return variational_lp(x); return ref_nhp * S; };
-    // a / sigma for the wave's coordinates (sigma uniform; rinv = 1 / sigma)
-    auto div_sigma = [&](const double (&a)[EW], double sigma, double rinv, bool divisor_ok, double (&o)[EW]) {
-        double tq[EW];
-        bool bad = false;
+    // the guard of a vector of quotient estimates: every live lane's four exponent fields inside [123, 1923] (2^-900 ... 2^900; zero and subnormals
+    // have field 0, infinities and NaN 2047): one v_bfe_u32 per estimate, three min / max pairs, two compares per lane, one ballot per vector
+    auto quotients_out_of_range = [&](const double (&q)[EW]) -> bool {
+        unsigned lo = 0x7FFu, hi = 0u;
 #pragma unroll
         for (int j = 0; j < EW; ++j) {
-            const double q = a[j] * rinv;
-            tq[j] = __builtin_fma(__builtin_fma(-q, sigma, a[j]), rinv, q);
-            bad = bad || (valid(j) && !quotient_in_range(q));
+            const unsigned ex = valid(j) ? quotient_exponent_field(q[j]) : 1023u;
+            lo = min(lo, ex); hi = max(hi, ex);
         }
-        if (__builtin_expect(!divisor_ok || ballot64(bad) != 0ull, 0)) {
+        return ballot64(lo < 123u || hi > 1923u) != 0ull;
+    };
+    // a / sigma for the wave's coordinates (sigma uniform; rinv = 1 / sigma); `o` must not be `a`
+    auto div_sigma = [&](const double (&a)[EW], double sigma, double rinv, bool divisor_ok, double (&o)[EW]) {
+        double qe[EW];
+#pragma unroll
+        for (int j = 0; j < EW; ++j) o[j] = markstein_quotient(a[j], sigma, rinv, qe[j]);
+        if (__builtin_expect(!divisor_ok || quotients_out_of_range(qe), 0)) {
 #pragma unroll
             for (int j = 0; j < EW; ++j) o[j] = mw_div_exact(a[j], sigma);
-        } else {
-#pragma unroll
-            for (int j = 0; j < EW; ++j) o[j] = tq[j];
         }
     };
     // the funnel's gradient without the first coordinate's sum (AmTarget::funnel: g2 = -(z / sigma) / sigma) blended with the reference's:
@@ -577,27 +583,19 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
     }
     const bool m_one = ballot64(m_not_one) == 0ull;                    // the identity (round 1; a third of the scans of MixDiagonalPreconditioner): a / 1.0 is a
     const bool m_ok = ballot64(m_excluded) == 0ull;
-    // a[j] / M[j] for the wave's coordinates; `o` may be `a`
+    // a[j] / M[j] for the wave's coordinates; `o` must not be `a` (the rare branch reads `a` again)
     auto div_M = [&](const double (&a)[EW], double (&o)[EW]) {
         if (m_one) {
 #pragma unroll
             for (int j = 0; j < EW; ++j) o[j] = a[j];
             return;
         }
-        double tq[EW];
-        bool bad = false;
+        double qe[EW];
 #pragma unroll
-        for (int j = 0; j < EW; ++j) {
-            const double q = a[j] * Minv[j];
-            tq[j] = __builtin_fma(__builtin_fma(-q, M[j], a[j]), Minv[j], q);
-            bad = bad || (valid(j) && !quotient_in_range(q));
-        }
-        if (__builtin_expect(!m_ok || ballot64(bad) != 0ull, 0)) {
+        for (int j = 0; j < EW; ++j) o[j] = markstein_quotient(a[j], M[j], Minv[j], qe[j]);
+        if (__builtin_expect(!m_ok || quotients_out_of_range(qe), 0)) {
 #pragma unroll
             for (int j = 0; j < EW; ++j) o[j] = mw_div_exact(a[j], M[j]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < EW; ++j) o[j] = tq[j];
         }
     };
 
@@ -612,60 +610,65 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
     double lp0 = 0.0, pp0 = 0.0;
     // log density and CONDITIONED gradient at x, with Q = sum q^2
     auto density_and_conditioned_gradient = [&](double (&gout)[EW], const double (&q)[EW], double &Q) -> double {
-        double lp;
+        double lp, gr[EW];
         if constexpr (TGT == TGT_MVN) {
             double mine[2], out[2];
             partial_sqr2(x, q, mine[0], mine[1]);
 #pragma unroll
-            for (int j = 0; j < EW; ++j) gout[j] = nprec * x[j];
+            for (int j = 0; j < EW; ++j) gr[j] = nprec * x[j];
             exchange(mine, out);
             Q = out[1];
             lp = nhp * out[0];
-        } else lp = funnel_logdensity_and_gradient_q(x, gout, q, Q);
-        div_M(gout, gout);
+        } else lp = funnel_logdensity_and_gradient_q(x, gr, q, Q);
+        div_M(gr, gout);
         return lp;
     };
     // the conditioned gradient at x alone, given the first coordinate's entry (kept from the evaluation that made the sum): elementwise
     auto conditioned_gradient_again = [&](double (&gout)[EW], double first_entry) {
+        double gr[EW];
         if constexpr (TGT == TGT_MVN) {
 #pragma unroll
-            for (int j = 0; j < EW; ++j) gout[j] = nprec * x[j];
+            for (int j = 0; j < EW; ++j) gr[j] = nprec * x[j];
         } else {
             const FunnelScale fs = funnel_scale(x);
             const double sigma = fs.sigma, rinv = fs.rinv;
             const bool sok = markstein_divisor_ok(sigma);
             double zi[EW];
             div_sigma(x, sigma, rinv, sok, zi);
-            funnel_gradient_elementwise(x, zi, sigma, rinv, sok, gout);
+            funnel_gradient_elementwise(x, zi, sigma, rinv, sok, gr);
         }
-        div_M(gout, gout);
+        div_M(gr, gout);
         if (TGT != TGT_MVN && owns_first) gout[0] = first_entry;
     };
     auto kinetic = [&]() -> double { return U(0.5 * sqr_norm(p)); };
-    auto leap_frog = [&](double eps, double &logp_out, double &ke_out) -> bool {      // hamiltonian_dynamics! with n_steps = 1
+    // hamiltonian_dynamics! with n_steps = 1 FROM the point (state = LDS row xsrc, momentum = psrc, conditioned gradient = g0): every trial of a search
+    // starts from the same point, so the "restore" of the reference is reading it again -- no copies back into x and p after a trial
+    auto leap_frog = [&](double eps, int xsrc, const double (&psrc)[EW], double &logp_out, double &ke_out) -> bool {
         const double half = eps / 2;
 #pragma unroll
-        for (int j = 0; j < EW; ++j) p[j] = p[j] + half * g0[j];
+        for (int j = 0; j < EW; ++j) p[j] = psrc[j] + half * g0[j];
         {
             double pm[EW];
             div_M(p, pm);
 #pragma unroll
-            for (int j = 0; j < EW; ++j) x[j] = x[j] + eps * pm[j];
+            for (int j = 0; j < EW; ++j) x[j] = L.v[xsrc][gidx(j)] + eps * pm[j];
         }
         if constexpr (TGT == TGT_MVN) {
             // the gradient is elementwise here (-prec x), so the momentum after the second half kick is known before any sum is: |x|^2, |p|^2
             // after the first kick and |p|^2 after the second are three independent fixed trees -- ONE exchange per leapfrog instead of two,
-            // the same bits.  The second kick is committed only where the reference makes it (a non-finite joint returns first).
-            double mine[3], out[3], pn[EW];
+            // the same bits.  The second kick is made in place; where the reference returns BEFORE it (a non-finite joint: rare) the momentum
+            // after the first kick is evaluated again -- the same expression, the same bits.
+            double mine[3], out[3], gr[EW];
 #pragma unroll
-            for (int j = 0; j < EW; ++j) g[j] = nprec * x[j];
-            div_M(g, g);
+            for (int j = 0; j < EW; ++j) gr[j] = nprec * x[j];
+            div_M(gr, g);
             {
                 double t[3][EW];
 #pragma unroll
                 for (int j = 0; j < EW; ++j) {
-                    pn[j] = p[j] + half * g[j];
-                    t[0][j] = x[j] * x[j]; t[1][j] = p[j] * p[j]; t[2][j] = pn[j] * pn[j];
+                    t[0][j] = x[j] * x[j]; t[1][j] = p[j] * p[j];
+                    p[j] = p[j] + half * g[j];
+                    t[2][j] = p[j] * p[j];
                 }
                 wave_nodes(t, mine);
             }
@@ -675,9 +678,11 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
             const double ke_mid = U(0.5 * out[1]);
             ke_out = ke_mid;
             const double cur = logp - ke_mid;
-            if (__builtin_expect(!isfinite(cur), 0)) return false;
+            if (__builtin_expect(!isfinite(cur), 0)) {
 #pragma unroll
-            for (int j = 0; j < EW; ++j) p[j] = pn[j];
+                for (int j = 0; j < EW; ++j) p[j] = psrc[j] + half * g0[j];
+                return false;
+            }
             const double sq = out[2];
             ke_out = U(0.5 * sq);
             if (__builtin_expect(!isfinite(sq), 0)) return false;
@@ -702,8 +707,9 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
     // auto_step_size (AutoMALA.jl:184-214) as ONE loop with one trial leapfrog in it (mode 0: the first trial at the current step size; 1: halving
     // until the joint's change rises above `lower`; 2: doubling until it falls below `upper` or stops being finite) -- the sequence of trials,
     // of kept trials and of restores is the reference's; one copy of the leapfrog in the kernel instead of six.  `forward`: the search from the
-    // refresh's start point (it keeps the trial the proposal would repeat; x is restored from the start state); otherwise from the proposed
-    // point (x restored from the kept trial's state).  p is restored from pb.
+    // refresh's start point (it keeps the trial the proposal would repeat; every trial starts from the start state in LDS); otherwise from the
+    // proposed point (the kept trial's state in LDS).  The momentum every trial starts from is pb.  x and p are NOT restored behind the last trial:
+    // the callers load what they go on with.
     auto auto_step_size = [&](double &lower, double &upper, double h_before, bool forward) -> int {
         const int xsrc = forward ? MW_XS : MW_XK;
 #pragma unroll
@@ -712,7 +718,7 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
         int mode = 0, n = 0, n_steps = 0, exponent = 0;
         for (;;) {
             double t_lp = 0.0, t_ke = 0.0;
-            const bool t_ok = leap_frog(eps, t_lp, t_ke);
+            const bool t_ok = leap_frog(eps, xsrc, pb, t_lp, t_ke);
             if (forward && mode == 0) { lower = U(L.bounds[0]); upper = U(L.bounds[1]); }      // (behind the leapfrog's exchange barrier: wave 0 has published them)
             const double diff = U((t_lp - t_ke) - h_before);
             const bool stop_growing = mode == 2 && (!isfinite(diff) || diff < upper);
@@ -722,8 +728,6 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
                 gk_first = g[0];
                 lpk = t_lp; kek = t_ke; okk = t_ok;
             }
-#pragma unroll
-            for (int j = 0; j < EW; ++j) { x[j] = L.v[xsrc][gidx(j)]; p[j] = pb[j]; }
             if (mode == 0) {
                 if (!isfinite(diff) || diff < lower) mode = 1;
                 else if (diff > upper) mode = 2;
@@ -762,7 +766,9 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
         if (!isfinite(init_joint)) { err = ERR_AM_DENSITY; break; }
         if (ap.mala) {                                   // mala! (MALA.jl:79-96)
             double lpn, ken;
-            leap_frog(ap.step_size, lpn, ken);
+#pragma unroll
+            for (int j = 0; j < EW; ++j) pb[j] = p[j];
+            leap_frog(ap.step_size, MW_XS, pb, lpn, ken);
 #pragma unroll
             for (int j = 0; j < EW; ++j) p[j] = p[j] * -1.0;
             const double ex = exp((lpn - ken) - init_joint);
@@ -824,6 +830,9 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
                 lp0 = lp_s;
 #pragma unroll
                 for (int j = 0; j < EW; ++j) { x[j] = L.v[MW_XS][gidx(j)]; g0[j] = L.v[MW_GS][gidx(j)]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < EW; ++j) x[j] = L.v[MW_XK][gidx(j)];              // the proposed point (lp0, g0 are its already)
             }
             MW_STAMP(6);
         }
@@ -858,16 +867,16 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
     if (w == 0) record_after_explore(e, cl, c, slot, lane, lp_before, S, l2, l3);
 }
 
-// Waves per SIMD the register allocation is held to.  Scaled-precision MVN path: 4 = 128 VGPRs, four workgroups per compute unit, 1024 replicas
-// resident; its trial loop is free of scratch traffic (72-88 values are spilled around it, at refresh level).  Funnel path: the evaluation (exp, log,
-// two quotient passes, four sums) does not fit 128 registers with the seven vectors -- held to 4 (or 3) it reloads ~36 values per trial leapfrog from
-// scratch and takes 4.1 (3.1) ms per scan at N = 1024 where 2 waves per SIMD (256 VGPRs, two generations of 512 replicas) take 2.2: measured,
-// profiles/r06_langevin_mw.txt.
+// Waves per SIMD the register allocation is held to: 4 = 128 VGPRs, four workgroups per compute unit, 1024 replicas resident.  Scaled-precision MVN
+// path: the trial loop is free of scratch traffic (54-68 values are spilled around it, at refresh level).  Funnel path: its evaluation (two quotient
+// passes, four sums, the blended gradient) does not fit beside the six vectors: 128-182 values spilled, a few reloaded per trial -- and still the
+// fastest setting once the trial loop stopped copying registers (funnel(1024), N = 1024: 1.86 ms per scan at 4, 2.05 at 3, 1.98 at 2 waves per
+// SIMD = two generations of 512 replicas; before that change 4.1 / 3.1 / 2.2: profiles/r06_langevin_mw.txt).
 #ifndef PTE_MW_OCC
 #define PTE_MW_OCC 4
 #endif
 #ifndef PTE_MW_OCC_FUNNEL
-#define PTE_MW_OCC_FUNNEL 2
+#define PTE_MW_OCC_FUNNEL 4
 #endif
 template <int TGT, bool FULL>
 __global__ __launch_bounds__(64 * MW_NWV)

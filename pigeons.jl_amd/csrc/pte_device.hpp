@@ -251,7 +251,7 @@ __device__ __forceinline__ void wave_sum_pairs(double (&v)[M], double (&out)[M /
 // a / b as q = a r, q' = fma(fma(-q, b, a), r, q) with r = RN(1 / b): CORRECTLY ROUNDED (Markstein 1990: r the correctly rounded reciprocal, no over /
 // underflow on the way, b's significand not all ones) -- the same bits as the division the reference makes, in 3 instructions instead of ~13 with ~10
 // temporaries.  What the theorem does not cover takes the division itself, decided per vector by the caller (a uniform branch): a quotient estimate
-// outside [2^-900, 2^900] -- zero, subnormal, infinite, NaN -- in a lane that holds a coordinate, or an excluded divisor (extreme exponent, all-ones
+// outside [2^-900, 2^901) -- zero, subnormal, infinite, NaN -- in a lane that holds a coordinate, or an excluded divisor (extreme exponent, all-ones
 // significand).  pte_test_quotient holds the procedure to a / b on the host; the kernels that use it are held to kernels that divide
 // (tests/test_gpu_langevin_mw.py) and to the oracle.
 __device__ __forceinline__ bool markstein_divisor_ok(double b) {
@@ -259,7 +259,9 @@ __device__ __forceinline__ bool markstein_divisor_ok(double b) {
     const int ex = (int)((u >> 52) & 0x7FF);
     return (u & MASK52) != MASK52 && ex > 1023 - 500 && ex < 1023 + 500;
 }
-__device__ __forceinline__ bool quotient_in_range(double q) { const double a = fabs(q); return a >= 0x1p-900 && a <= 0x1p900; }
+// (the estimate's exponent field inside [123, 1923] = magnitude in [2^-900, 2^901): zero and subnormals have field 0, infinities and NaN 2047 -- one v_bfe_u32)
+__device__ __forceinline__ unsigned quotient_exponent_field(double q) { return __builtin_amdgcn_ubfe((unsigned)__double2hiint(q), 20u, 11u); }
+__device__ __forceinline__ bool quotient_in_range(double q) { const unsigned ex = quotient_exponent_field(q); return ex >= 123u && ex <= 1923u; }
 __device__ __forceinline__ double markstein_quotient(double a, double b, double rinv, double &q_estimate) {
     const double q = a * rinv;
     q_estimate = q;

@@ -147,27 +147,26 @@ def test_swap_kernels_are_light(cg):
 
 
 def test_langevin_mw_kernels(cg):
-    """k_explore_langevin_mw (round 6: AutoMALA / MALA at 512 < d <= 1024, four waves per replica).  The scaled-precision MVN path is held to 128 VGPRs = four
-    waves per SIMD = four workgroups per compute unit (1024 replicas resident; 39 KB of LDS each: four fit the 160 KB) and its hot loops -- the one trial
-    leapfrog of the step-size search and everything below it -- touch no scratch: what is spilled (71-79 values) is spilled at refresh level.  The funnel
-    path does not fit 128 registers (held there it reloads ~36 values per trial leapfrog and is SLOWER than the kernel it replaces: profiles/r06_langevin_mw.txt)
-    and is held to two waves per SIMD."""
+    """k_explore_langevin_mw (round 6: AutoMALA / MALA at 512 < d <= 1024, four waves per replica): 128 VGPRs = four waves per SIMD = four workgroups per
+    compute unit (1024 replicas resident; 39 KB of LDS each: four fit the 160 KB).  Scaled-precision MVN path: the loop of trial leapfrogs (~300 VALU + 150
+    scalar + 15 LDS instructions: the one holding the cross-wave exchange) touches no scratch and holds no spill write -- what is spilled (55-68 values) is
+    spilled at refresh level.  Funnel path: its evaluation does not fit beside the vectors (124-176 values spilled) and is still fastest at this setting
+    (profiles/r06_langevin_mw.txt)."""
     C, res, lines = cg
     for full in ("true", "false"):
         r = res["k_explore_langevin_mw<0, %s>" % full]
         assert r["vgpr"] <= 128 and r["waves_per_simd"] == 4 and r["lds_B"] <= 40960, r
-        assert r["spilled_vgpr"] <= 96 and r["scratch_B_per_lane"] <= 320, r
+        assert r["spilled_vgpr"] <= 80 and r["scratch_B_per_lane"] <= 340, r
         name, body = C.kernel_body(lines, "k_explore_langevin_mwILi0ELb%dE" % (1 if full == "true" else 0))
-        loops = C.loops(body)
-        inner = {k: L for k, L in loops.items() if k[0] >= 3}              # refresh -> forward / reversed search -> TRIAL leapfrog (and below)
-        assert len(inner) >= 1 and max(L["v"] for L in inner.values()) >= 250          # (the trial leapfrog is among them: ~310 VALU + 155 scalar + 15 LDS)
-        for k, L in inner.items():             # whole blocks (d = 1024): nothing; a ragged last block (validity masks live across the loop): one reload per trial
-            assert L["scratch"] <= (0 if full == "true" else 2) and L["w"] == 0 and L["r"] <= (0 if full == "true" else 8), (full, k, L)
+        loops = {k: L for k, L in C.loops(body).items() if k[0] >= 2}
+        trial = [L for L in loops.values() if L["l"] >= 10 and 250 <= L["v"] <= 340]          # (the 437-VALU loops are wave_randn_block's: reference chain, sequential momentum)
+        assert len(trial) == 1, loops
+        t = trial[0]
+        assert t["scratch"] == 0 and t["w"] == 0 and t["r"] <= 2 and t["v"] <= 320 and t["s"] <= 170, (full, t)
         for k, L in loops.items():
-            if k[0] == 2:                                                  # the two searches of a refresh: a handful of reloads per search
-                assert L["scratch"] <= 8, (full, k, L)
+            assert L["scratch"] <= 2, (full, k, L)                          # nothing at any loop level below the refresh reloads more than a value or two from scratch
         f = res["k_explore_langevin_mw<2, %s>" % full]
-        assert f["waves_per_simd"] >= 2 and f["lds_B"] <= 40960 and f["spilled_vgpr"] <= 64, f
+        assert f["vgpr"] <= 128 and f["waves_per_simd"] == 4 and f["lds_B"] <= 40960 and f["spilled_vgpr"] <= 200, f
     # the one-wave kernels with sixteen blocks per lane are gone from the product build (their SliceSampler instantiation, which does not spill, stays)
     assert [k for k in res if k.startswith("k_explore_automala<16,")] == ["k_explore_automala<16, 2, true, false>"]
     s16 = res["k_explore_automala<16, 2, true, false>"]
