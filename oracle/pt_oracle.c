@@ -850,6 +850,205 @@ static int slice_step(po_pt *pt, po_replica *r) {
 }
 
 
+/* ---- SliceSampler on Bool / Integer / mixed states (SliceSampler.jl:43-95, 128-142, 188-189) --------------------------------
+ * SURVEY.md 8 row a8's last sub-row.  The reference dispatches slice_sample_coord! on typeof(pointer[]) PER COORDINATE (:47-48), so a
+ * state may mix Float64, Integer and Bool coordinates (its DynamicPPL models do).  The device has no target with such coordinates (closed
+ * enum of log-potential families; pte_create refuses), so this part of the restatement stands alone behind a log-potential call-back
+ * instead of a po_pt: state coordinates are held as doubles (integers exact below 2^53, Bool = 0.0 / 1.0), `kind` says which method a
+ * coordinate takes.  The Float64 method here is the same arithmetic as slice_sample_coord above (tests/test_oracle_slice_mixed.py holds
+ * the two bit for bit against each other).
+ *
+ * rand(rng, a:b) on Int64 ranges: Julia's Random stdlib (>= 1.5; Project.toml compat julia = "1.8") builds SamplerRangeNDL for every
+ * AbstractRNG and BitInteger64 element type -- Lemire's "nearly division-less" sampler over rand(rng, UInt64): s = b - a + 1 (mod 2^64),
+ * m = x * s as UInt128, low = m mod 2^64; if low < s { t = (2^64 - s) mod s; redraw while low < t }; result = a + (s == 0 ? x : m >> 64).
+ * The stdlib is not under /root/reference: restated from the published algorithm (Random/src/generation.jl, "SamplerRangeNDL") -- UNPINNED
+ * like the other stdlib samplers (pt_oracle.h). */
+int64_t po_rand_range(po_rng *r, int64_t a, int64_t b) {
+    const uint64_t s = (uint64_t)b - (uint64_t)a + 1ULL;                    /* overflow ok: 0 = the full range */
+    uint64_t x = po_rng_next_u64(r);
+    unsigned __int128 m = (unsigned __int128)x * s;
+    uint64_t low = (uint64_t)m;
+    if (low < s) {
+        const uint64_t t = (0ULL - s) % s;                                  /* mod(-s, s); s != 0 here because low < s */
+        while (low < t) {
+            x = po_rng_next_u64(r);
+            m = (unsigned __int128)x * s;
+            low = (uint64_t)m;
+        }
+    }
+    return (int64_t)((s == 0 ? x : (uint64_t)(m >> 64)) + (uint64_t)a);
+}
+
+typedef struct {
+    po_rng *rng; double *state; int64_t d, c;
+    const po_slice_params *h;
+    po_logpotential_fn lp; void *lp_ctx;
+    po_slice_stats *st;
+} mixed_ctx;
+static inline double mixed_lp(mixed_ctx *s) { return s->lp(s->state, s->d, s->lp_ctx); }
+static inline void mixed_rec_steps(mixed_ctx *s, double v) { if (s->st) { s->st->steps_sum += v; s->st->steps_n += 1; } }
+static inline void mixed_rec_acc(mixed_ctx *s, double v) {                /* Mean(): mu += (1/n)(x - mu), as mean_fit */
+    if (s->st) { s->st->acc_n += 1; s->st->acc_mean += (1.0 / (double)s->st->acc_n) * (v - s->st->acc_mean); }
+}
+
+/* slice_accept :192-237 -- one body for Float64 and Integer coordinates: with an Integer pointer Lhat / Rhat start as Int64 and turn
+ * into Float64 at the first M = (Lhat + Rhat) / 2.0; R - L = w 2^k with integer w keeps every M integral, so the stores into the
+ * Integer pointer convert exactly, and every comparison (Int against Float64) is exact below 2^53: doubles carry it. */
+static int mixed_slice_accept(mixed_ctx *s, double new_position, double z, double L, double R, double lp_L, double lp_R) {
+    double *ptr = &s->state[s->c];
+    const double old_position = *ptr;
+    double Lhat = L, Rhat = R;
+    int Rstale = 0, Lstale = 0, D = 0;
+    while (Rhat - Lhat > 1.1 * s->h->w) {
+        const double M = (Lhat + Rhat) / 2.0;
+        if ((old_position < M && new_position >= M) || (old_position >= M && new_position < M)) D = 1;
+        if (new_position < M) { Rhat = M; Rstale = 1; }
+        else { Lhat = M; Lstale = 1; }
+        if (D) {
+            if (Lstale) { *ptr = Lhat; lp_L = mixed_lp(s); Lstale = 0; }
+            if (Rstale) { *ptr = Rhat; lp_R = mixed_lp(s); Rstale = 0; }
+            if (z >= lp_L && z >= lp_R) { *ptr = old_position; mixed_rec_acc(s, 0.0); return 0; }
+        }
+    }
+    *ptr = old_position;
+    mixed_rec_acc(s, 1.0);
+    return 1;
+}
+
+/* slice_sample_coord!(..., ::Type{Bool}) :65-86: the full conditional, ONE density evaluation, ONE rand(rng); records nothing */
+static void mixed_coord_bool(mixed_ctx *s, double *cached_lp) {
+    double *ptr = &s->state[s->c];
+    double lp0, lp1;
+    if (*ptr != 0.0) { lp1 = *cached_lp; *ptr = 0.0; lp0 = mixed_lp(s); }
+    else             { lp0 = *cached_lp; *ptr = 1.0; lp1 = mixed_lp(s); }
+    const double prob_ratio = exp(lp1 - lp0);
+    const double prob_zero = 1.0 / (1.0 + prob_ratio);                      /* inv(1 + prob_ratio) */
+    if (po_rand(s->rng) < prob_zero) { *ptr = 0.0; *cached_lp = lp0; }
+    else                             { *ptr = 1.0; *cached_lp = lp1; }
+}
+
+/* slice_sample_coord!(..., ::Type) :89-95 on an Integer coordinate: slice_double :97-126 with initialize_slice_endpoints(::Integer)
+ * :136-142 (L = current - rand(rng, 0:width), width = ceil(T, w), w must be integral), slice_shrink! :144-186 with
+ * draw_new_position(::Integer, ::Integer) = rand(rng, L:R) :189 and Lbar ≈ Rbar, which is == on Integers (Base.isapprox, rtol = 0). */
+static int mixed_coord_integer(mixed_ctx *s, double *cached_lp, char *err, size_t errlen) {
+    const po_slice_params *h = s->h;
+    double *ptr = &s->state[s->c];
+    if (h->w != floor(h->w) || !isfinite(h->w)) {
+        snprintf(err, errlen, "for integer variables, the width should be an integer. Got: %g", h->w);   /* @assert :137 */
+        return 1;
+    }
+    const double z = *cached_lp - po_randexp(s->rng);
+    const int64_t old_position = (int64_t)*ptr;
+    const int64_t width = (int64_t)ceil(h->w);
+    int64_t L = old_position - po_rand_range(s->rng, 0, width);
+    int64_t R = L + width;
+    int K = h->p;
+    *ptr = (double)L; double potent_L = mixed_lp(s);
+    *ptr = (double)R; double potent_R = mixed_lp(s);
+    while (K > 0 && (z < potent_L || z < potent_R)) {
+        const double V = po_rand(s->rng);
+        if (V <= 0.5) { L = L - (R - L); *ptr = (double)L; potent_L = mixed_lp(s); }
+        else          { R = R + (R - L); *ptr = (double)R; potent_R = mixed_lp(s); }
+        K -= 1;
+    }
+    mixed_rec_steps(s, (double)(h->p - K));
+    *ptr = (double)old_position;
+    int64_t Lbar = L, Rbar = R;
+    for (int n = 1; n <= h->max_iter; n++) {
+        const int64_t new_position = po_rand_range(s->rng, Lbar, Rbar);
+        *ptr = (double)new_position;
+        const double new_lp = mixed_lp(s);
+        const int consider = z < new_lp;
+        *ptr = (double)old_position;
+        if (consider && mixed_slice_accept(s, (double)new_position, z, (double)L, (double)R, potent_L, potent_R)) {
+            *ptr = (double)new_position;
+            mixed_rec_steps(s, (double)n);
+            *cached_lp = new_lp;
+            return 0;
+        }
+        if (new_position < old_position) Lbar = new_position; else Rbar = new_position;
+        if (Lbar == Rbar) {
+            *ptr = (double)old_position;
+            mixed_rec_steps(s, (double)n);
+            *cached_lp = mixed_lp(s);
+            return 0;
+        }
+    }
+    snprintf(err, errlen, "SliceSampler: maximum number of iterations reached");
+    return 1;
+}
+
+/* the Float64 method, as slice_sample_coord above (same statements, the log potential through the call-back) */
+static int mixed_coord_float(mixed_ctx *s, double *cached_lp, char *err, size_t errlen) {
+    const po_slice_params *h = s->h;
+    double *ptr = &s->state[s->c];
+    const double z = *cached_lp - po_randexp(s->rng);
+    const double old_position = *ptr;
+    double L = old_position - h->w * po_rand(s->rng);
+    double R = L + h->w;
+    int K = h->p;
+    *ptr = L; double potent_L = mixed_lp(s);
+    *ptr = R; double potent_R = mixed_lp(s);
+    while (K > 0 && (z < potent_L || z < potent_R)) {
+        const double V = po_rand(s->rng);
+        if (V <= 0.5) { L = L - (R - L); *ptr = L; potent_L = mixed_lp(s); }
+        else          { R = R + (R - L); *ptr = R; potent_R = mixed_lp(s); }
+        K -= 1;
+    }
+    mixed_rec_steps(s, (double)(h->p - K));
+    *ptr = old_position;
+    double Lbar = L, Rbar = R;
+    for (int n = 1; n <= h->max_iter; n++) {
+        const double new_position = Lbar + po_rand(s->rng) * (Rbar - Lbar);
+        *ptr = new_position;
+        const double new_lp = mixed_lp(s);
+        const int consider = z < new_lp;
+        *ptr = old_position;
+        if (consider && mixed_slice_accept(s, new_position, z, L, R, potent_L, potent_R)) {
+            *ptr = new_position;
+            mixed_rec_steps(s, (double)n);
+            *cached_lp = new_lp;
+            return 0;
+        }
+        if (new_position < *ptr) Lbar = new_position; else Rbar = new_position;
+        if (jl_isapprox(Lbar, Rbar)) {
+            *ptr = old_position;
+            mixed_rec_steps(s, (double)n);
+            *cached_lp = mixed_lp(s);
+            return 0;
+        }
+    }
+    snprintf(err, errlen, "SliceSampler: maximum number of iterations reached");
+    return 1;
+}
+
+/* step!(::SliceSampler) :24-30 over slice_sample!(h, state::AbstractVector, ...) :43-62, dispatching per coordinate on kind[c] */
+int po_slice_step_mixed(po_rng *rng, double *state, const int32_t *kind, int64_t d, const po_slice_params *h,
+                        po_logpotential_fn lp, void *lp_ctx, po_slice_stats *stats, char *err, size_t errlen) {
+    mixed_ctx s = { rng, state, d, 0, h, lp, lp_ctx, stats };
+    char dummy[8];
+    if (!err) { err = dummy; errlen = sizeof(dummy); }
+    err[0] = 0;
+    double cached_lp = -INFINITY;
+    for (int pass = 0; pass < h->n_passes; pass++) {
+        if (cached_lp == -INFINITY) {                                       /* cached_log_potential :32-41 */
+            cached_lp = mixed_lp(&s);
+            if (cached_lp == -INFINITY) { snprintf(err, errlen, "SliceSampler: initialized outside the support"); return 1; }
+        }
+        for (int64_t c = 0; c < d; c++) {
+            s.c = c;
+            switch (kind ? kind[c] : PO_COORD_FLOAT64) {
+            case PO_COORD_BOOL:    mixed_coord_bool(&s, &cached_lp); break;
+            case PO_COORD_INTEGER: if (mixed_coord_integer(&s, &cached_lp, err, errlen)) return 1; break;
+            case PO_COORD_FLOAT64: if (mixed_coord_float(&s, &cached_lp, err, errlen)) return 1; break;
+            default: snprintf(err, errlen, "po_slice_step_mixed: coordinate %lld has kind %d", (long long)c, (int)kind[c]); return 1;
+            }
+            if (!isfinite(cached_lp)) { snprintf(err, errlen, "SliceSampler: invalid log density after update"); return 1; }
+        }
+    }
+    return 0;
+}
+
 /* ---- AutoMALA (src/explorers/AutoMALA.jl, src/explorers/hamiltonian_dynamics.jl) -------------- */
 typedef struct {
     po_pt *pt; po_replica *r; int64_t chain;

@@ -11,7 +11,7 @@
  * answers (tests/test_oracle_kat.py) and (ii) the public SplitMix64 vector and the
  * four recalled ziggurat table entries.  Third-party arithmetic restated from
  * published algorithms: SplittableRandoms.jl 0.1 (Java SplittableRandom),
- * Julia Random stdlib rand/randn/randexp, OnlineStatsBase 1.x Mean/Variance/Sum,
+ * Julia Random stdlib rand/randn/randexp and rand(rng, a:b) (SamplerRangeNDL), OnlineStatsBase 1.x Mean/Variance/Sum,
  * Interpolations.jl FritschCarlsonMonotonicInterpolation, LogExpFunctions logaddexp.
  *
  * All indices crossing this API are 0-based (chain 0 = reference, chain N-1 =
@@ -49,6 +49,19 @@ double po_logaddexp(double a, double b);
 void   po_fc_build(const double *x, const double *y, int64_t n, double *m, double *c, double *dd);
 double po_fc_eval(const double *x, const double *y, const double *m, const double *c,
                   const double *dd, int64_t n, double t);
+
+/* ---- SliceSampler on Bool / Integer / mixed states (SliceSampler.jl:43-95, 128-142, 188-189) -----
+ * Stand-alone (no po_pt): the device has no target with Bool / Integer coordinates and refuses them, so these methods are restated
+ * behind a log-potential call-back, for tier 3.  State coordinates are doubles (Integer: exact below 2^53; Bool: 0.0 / 1.0). */
+#include <stddef.h>
+enum { PO_COORD_FLOAT64 = 0, PO_COORD_INTEGER = 1, PO_COORD_BOOL = 2 };
+typedef double (*po_logpotential_fn)(const double *state, int64_t d, void *ctx);
+typedef struct po_slice_params { double w; int32_t p, n_passes, max_iter; } po_slice_params;       /* SliceSampler.jl:8-20 */
+typedef struct po_slice_stats { double acc_mean; int64_t acc_n; double steps_sum; int64_t steps_n; } po_slice_stats;   /* explorer_acceptance_pr (Mean), explorer_n_steps (Sum) */
+int64_t po_rand_range(po_rng *r, int64_t a, int64_t b);          /* rand(rng, a:b), Int64: Random.SamplerRangeNDL */
+/* one step!(::SliceSampler) on `state`; kind[c] in PO_COORD_* (NULL = all Float64); stats may be NULL; returns != 0 with a message in err */
+int     po_slice_step_mixed(po_rng *rng, double *state, const int32_t *kind, int64_t d, const po_slice_params *h,
+                            po_logpotential_fn lp, void *lp_ctx, po_slice_stats *stats, char *err, size_t errlen);
 
 /* ---- parallel tempering --------------------------------------------------- */
 enum { PO_TARGET_MVN = 0, PO_TARGET_TEST_SWAPPER = 1, PO_TARGET_FUNNEL = 2, PO_TARGET_ISING = 3 };

@@ -671,6 +671,9 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     if (ising) {
         const int64_t L = (int64_t)std::llround(std::sqrt((double)cfg->dim));
         if (L < 2 || L * L != cfg->dim || cfg->dim > 65536) return fail(nullptr, "pte_create: Ising needs dim = base_length^2 <= 65536");
+        if (cfg->explorer == PTE_EXPLORER_SLICE || cfg->explorer2 == PTE_EXPLORER_SLICE)   // spins are Bool coordinates: SliceSampler.jl:65-86 (and :136-142, :189 for Integer ones)
+            return fail(nullptr, "pte_create: SliceSampler's Bool / Integer coordinate methods are not available on the device (its Float64 methods are); "
+                                 "the Ising path is explored by IsingMetropolis only -- use the reference CPU path for Bool / Integer states");
         if (cfg->explorer != PTE_EXPLORER_ISING_METROPOLIS) return fail(nullptr, "pte_create: the Ising path is explored by IsingMetropolis only");
     } else if (cfg->explorer == PTE_EXPLORER_ISING_METROPOLIS) return fail(nullptr, "pte_create: IsingMetropolis needs the Ising target");
     if (!swapper && !funnel && !ising && cfg->target != PTE_TARGET_MVN_SCALED_PRECISION)

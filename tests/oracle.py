@@ -40,6 +40,18 @@ class Rng(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("gamma", C.c_uint64)]
 
 
+class SliceParams(C.Structure):      # SliceSampler's fields, src/explorers/SliceSampler.jl:8-20
+    _fields_ = [("w", C.c_double), ("p", C.c_int32), ("n_passes", C.c_int32), ("max_iter", C.c_int32)]
+
+
+class SliceStats(C.Structure):       # explorer_acceptance_pr (Mean), explorer_n_steps (Sum) of one replica
+    _fields_ = [("acc_mean", C.c_double), ("acc_n", C.c_int64), ("steps_sum", C.c_double), ("steps_n", C.c_int64)]
+
+
+LOGPOTENTIAL_FN = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.c_int64, C.c_void_p)
+COORD_FLOAT64, COORD_INTEGER, COORD_BOOL = 0, 1, 2
+
+
 def build(force=False):
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("pt_oracle.c", "pt_oracle.h", "Makefile")] + [os.path.join(ROOT, "include", "pte_rng_policy.h")]
     stale = (not os.path.exists(LIB_PATH)) or any(
@@ -164,6 +176,11 @@ def lib(path=None):
     L.po_shard_replica_ids.argtypes = [C.c_void_p, ip]
     L.po_shard_index_process.restype = C.c_int64
     L.po_shard_index_process.argtypes = [C.c_void_p, ip, ip]
+    L.po_rand_range.restype = C.c_int64
+    L.po_rand_range.argtypes = [C.POINTER(Rng), C.c_int64, C.c_int64]
+    L.po_slice_step_mixed.restype = C.c_int
+    L.po_slice_step_mixed.argtypes = [C.POINTER(Rng), dp, i32p, C.c_int64, C.POINTER(SliceParams), LOGPOTENTIAL_FN, C.c_void_p,
+                                      C.POINTER(SliceStats), C.c_char_p, C.c_size_t]
     _libs[path] = L
     _install_reference_tables(L)
     return L
@@ -255,9 +272,41 @@ class OracleRng:
     def rand_bool(self):
         return self.L.po_rand_bool_pub(C.byref(self.r))
 
+    def rand_range(self, a, b):
+        """rand(rng, a:b) on Int64 (Random.SamplerRangeNDL)"""
+        return self.L.po_rand_range(C.byref(self.r), a, b)
+
     @property
     def state(self):
         return (self.r.seed, self.r.gamma)
+
+
+class MixedSliceSampler:
+    """step!(::SliceSampler) on a state whose coordinates are Float64 / Integer / Bool (kinds: COORD_* per coordinate), behind a Python
+    log potential  lp(state: np.ndarray) -> float.  Counts the density evaluations."""
+
+    def __init__(self, log_potential, kinds, w=10.0, p=20, n_passes=3, max_iter=1024):
+        self.L = lib()
+        self.kinds = np.ascontiguousarray(kinds, dtype=np.int32)
+        self.h = SliceParams(w, p, n_passes, max_iter)
+        self.stats = SliceStats(0.0, 0, 0.0, 0)
+        self.n_evals = 0
+        d = len(self.kinds)
+
+        def cb(ptr, dd, _ctx):
+            self.n_evals += 1
+            return float(log_potential(np.ctypeslib.as_array(ptr, shape=(d,))))
+        self._cb = LOGPOTENTIAL_FN(cb)
+
+    def step(self, rng, state):
+        """one exploration step in place (state: float64 array); raises RuntimeError with the oracle's message"""
+        assert state.dtype == np.float64 and state.flags.c_contiguous and len(state) == len(self.kinds)
+        err = C.create_string_buffer(256)
+        rc = self.L.po_slice_step_mixed(C.byref(rng.r), _dp(state), self.kinds.ctypes.data_as(C.POINTER(C.c_int32)), len(state),
+                                        C.byref(self.h), self._cb, None, C.byref(self.stats), err, 256)
+        if rc:
+            raise RuntimeError(err.value.decode())
+        return state
 
 
 class OraclePT:

@@ -165,15 +165,13 @@ def test_inputs_defaults_match_reference(P):
 def test_the_product_ignores_pte_lib(monkeypatch):
     """$PTE_LIB used to swap the whole product library silently: the package does not read it any more; a development
     tool opts in through tools/_variant.py -> _lib.use_library(path)."""
-    import importlib, os, sys
-    monkeypatch.setenv("PTE_LIB", "/nonexistent/libpte_other.so")
-    from pigeons_amd import _lib
-    importlib.reload(_lib)
-    try:
-        assert _lib.LIB_PATH.endswith(os.path.join("pigeons.jl_amd", "lib", "libpte.so"))
-        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-        import _variant
-        assert _variant.apply() == "/nonexistent/libpte_other.so" and _lib.LIB_PATH == "/nonexistent/libpte_other.so"
-    finally:
-        monkeypatch.delenv("PTE_LIB")
-        importlib.reload(_lib)
+    import subprocess, sys                              # a fresh interpreter: reloading _lib here would leave engine.py with the old PteConfig class
+    prog = ("import os, sys; sys.path[:0] = [%r, %r]\n"
+            "from pigeons_amd import _lib\n"
+            "assert _lib.LIB_PATH.endswith(os.path.join('pigeons.jl_amd', 'lib', 'libpte.so')), _lib.LIB_PATH\n"
+            "import _variant\n"
+            "assert _variant.apply() == '/nonexistent/libpte_other.so' and _lib.LIB_PATH == '/nonexistent/libpte_other.so'\n"
+            % (os.path.join(ROOT, "pigeons.jl_amd"), os.path.join(ROOT, "tools")))
+    env = dict(os.environ, PTE_LIB="/nonexistent/libpte_other.so")
+    r = subprocess.run([sys.executable, "-c", prog], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
