@@ -287,6 +287,50 @@ def test_mixed_state_dispatches_per_coordinate():
         O.MixedSliceSampler(lp, [0, 7, 2]).step(r, x)
 
 
+# ---- tier 3: a live Pigeons.jl (tools/gen_golden.jl) -----------------------------------------------------------------------------------------
+import json, os
+_REF_PATH = os.path.join(O.ROOT, "tests", "golden", "reference_pigeons.json")
+_REF = json.load(open(_REF_PATH)) if os.path.exists(_REF_PATH) else None
+needs_reference = pytest.mark.skipif(_REF is None or "rand_range" not in _REF, reason="tests/golden/reference_pigeons.json holds no rand_range / slice_* "
+                                     "records (tools/gen_golden.jl needs Julia + Pigeons.jl): these methods stay unpinned against the live reference")
+
+
+@needs_reference
+def test_rand_range_against_live_reference():
+    for entry in _REF["rand_range"]:
+        r = O.OracleRng(entry["seed"]).split()
+        for (a, b), draws in zip(entry["ranges"], entry["draws"]):
+            got = [r.rand_range(int(a), int(b)) for _ in draws]
+            bad = [i for i, (g, w) in enumerate(zip(got, draws)) if g != int(w)]
+            assert not bad, "rand(rng, %s:%s), seed %d: draw %d is %d here, %s in Julia" % (a, b, entry["seed"], bad[0], got[bad[0]], draws[bad[0]])
+        assert [str(v) for v in r.state] == entry["final_rng"]
+
+
+_GOLDEN_LPS = {     # the same expressions, term by term, as golden_lp_* in tools/gen_golden.jl
+    "slice_integer": (lambda x: -0.125 * ((x[0] - 3.0) * (x[0] - 3.0) + (x[1] + 2.0) * (x[1] + 2.0)), [O.COORD_INTEGER] * 2, [0.0, 0.0]),
+    "slice_bool": (lambda x: (0.5 if x[0] else 0.0) - (1.25 if x[1] else 0.0) + (0.75 if (x[0] and x[2]) else 0.0), [O.COORD_BOOL] * 3, [0.0, 1.0, 0.0]),
+    "slice_mixed": (lambda x: -0.5 * (x[0] * x[0]) - 0.125 * ((x[1] - 3.0) * (x[1] - 3.0)) + (0.75 if x[2] else 0.0),
+                    [O.COORD_FLOAT64, O.COORD_INTEGER, O.COORD_BOOL], [0.25, 3.0, 1.0]),
+}
+
+
+@needs_reference
+@pytest.mark.parametrize("name", sorted(_GOLDEN_LPS))
+def test_slice_methods_against_live_reference(name):
+    if name not in _REF:
+        pytest.skip("the fixture has no %s record (%s)" % (name, _REF.get("slice_mixed_error", "not generated")))
+    lp, kinds, x0 = _GOLDEN_LPS[name]
+    g = _REF[name]
+    s = O.MixedSliceSampler(lp, kinds)                               # SliceSampler() defaults, as the generator
+    r = O.OracleRng(g["seed"]).split()
+    x = np.array(x0)
+    for i, want in enumerate(g["states"]):
+        s.step(r, x)
+        w = np.array([int(b) for b in want], dtype=np.uint64).view(np.float64)
+        assert np.array_equal(x, w), "%s: state after step %d is %r here, %r in Julia" % (name, i + 1, x, w)
+    assert [str(v) for v in r.state] == g["final_rng"]
+
+
 # ---- the device keeps refusing ------------------------------------------------------------------------------------------------------------
 
 def test_device_refuses_slice_sampling_of_bool_coordinates():

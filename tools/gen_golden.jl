@@ -9,6 +9,8 @@
 #     (tools/import_tables.py installs them into pigeons.jl_amd/csrc/zig_tables.h; tests/oracle.py installs them into the oracle);
 #   * raw streams of a replica's SplittableRandom: 4096 rand / randn / randexp per seed (several slow-path and tail draws each)
 #     and 1024 rand(rng, Bool) -- these decide the conventions named in include/pte_rng_policy.h;
+#   * rand(rng, a:b) on Int64 ranges and SliceSampler steps on Integer / Bool / mixed states (SliceSampler.jl:65-86, 136-142, 189), which only
+#     the oracle restates (po_rand_range, po_slice_step_mixed): tests/test_oracle_slice_mixed.py::test_*_against_live_reference;
 #   * seeded runs of the real reference: C1 with SliceSampler / ToyExplorer, AutoMALA on the MVN path, a two-leg TestSwapper
 #     run, a C5-shaped Ising run (examples/ising.jl, base_length 8) and a C3-shaped funnel run with AutoMALA.
 # Once the file is committed, tests/test_golden.py::test_*_against_live_reference and tests/test_zig_tables.py stop skipping
@@ -97,6 +99,40 @@ try
         reference = Pigeons.ScaledPrecisionNormalLogPotential(1.0 / 9.0, 8), n_chains = 6, n_rounds = 6, explorer = AutoMALA()))
 catch err
     out["funnel8_error"] = sprint(showerror, err)
+end
+
+# rand(rng, a:b) (Random.SamplerRangeNDL over rand(rng, UInt64)) and SliceSampler's Integer / Bool / mixed-state methods: oracle only
+const GOLDEN_RANGES = [(0, 10), (-5, 5), (0, 1), (3, 1023), (-(2^62), 2^62), (typemin(Int64), typemax(Int64)), (7, 7 + 2^62 + 2^61), (-17, 2^33 + 5)]
+function range_streams(seed; n = 256)
+    r = split(SplittableRandom(seed))
+    Dict("seed" => seed, "ranges" => [[string(a), string(b)] for (a, b) in GOLDEN_RANGES],
+         "draws" => [[string(rand(r, a:b)) for _ in 1:n] for (a, b) in GOLDEN_RANGES],          # ONE stream, range after range
+         "final_rng" => [string(r.seed), string(r.gamma)])
+end
+golden_lp_int(x)   = -0.125 * ((x[1] - 3)^2 + (x[2] + 2)^2)
+golden_lp_bool(x)  = (x[1] ? 0.5 : 0.0) - (x[2] ? 1.25 : 0.0) + ((x[1] && x[3]) ? 0.75 : 0.0)
+golden_lp_mixed(x) = -0.5 * x[1]^2 - 0.125 * (x[2] - 3)^2 + (x[3] ? 0.75 : 0.0)
+function slice_mixed(state, lp; steps = 64, seed = 1)
+    rng = split(SplittableRandom(seed))
+    replica = Pigeons.Replica(state, 1, rng, (;), 1)
+    h = SliceSampler()
+    trace = Vector{Vector{String}}()
+    for _ in 1:steps
+        cached = -Inf
+        for _ in 1:h.n_passes                                  # step!(::SliceSampler), SliceSampler.jl:24-30
+            cached = Pigeons.slice_sample!(h, replica.state, lp, cached, replica)
+        end
+        push!(trace, bits(Float64[Float64(v) for v in replica.state]))
+    end
+    Dict("seed" => seed, "states" => trace, "final_rng" => [string(rng.seed), string(rng.gamma)])
+end
+try
+    out["rand_range"] = [range_streams(s) for s in 1:3]
+    out["slice_integer"] = slice_mixed([0, 0], golden_lp_int)
+    out["slice_bool"] = slice_mixed([false, true, false], golden_lp_bool)
+    out["slice_mixed"] = slice_mixed(Real[0.25, 3, true], golden_lp_mixed)
+catch err
+    out["slice_mixed_error"] = sprint(showerror, err)
 end
 
 # minimal JSON writer (no extra dependency)
