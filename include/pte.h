@@ -291,7 +291,8 @@ const char *pte_kernel_name(const pte_engine *h);
  * the DEO swap is a hand-shake between the two waves of a pair, no launch boundary and no grid-wide barrier per scan).  Chosen when one GPU
  * holds the whole ladder, every workgroup is resident at once, the explorer has such a kernel and pte_config.debug_kernel does not carry
  * PTE_KERNEL_TWO_LAUNCHES; results are bit-identical either way.  A name ending in "_wg" (AutoMALA / MALA) is the form with several
- * consecutive chains per workgroup, whose inner pairs shake hands through LDS (PTE_KERNEL_SCAN_LOOP_ONE_CHAIN selects the other form).
+ * consecutive chains per workgroup, whose inner pairs shake hands through LDS (PTE_KERNEL_SCAN_LOOP_ONE_CHAIN selects the other form);
+ * "k_scans_langevin_mw" (AutoMALA / MALA on the scaled-precision MVN path, 512 < dim <= 1024) gives a chain a 256-thread workgroup.
  * pte_timing_get(kernel = 4) times these launches. */
 const char *pte_scan_loop_name(const pte_engine *h);
 int pte_scan_loop_info(const pte_engine *h, int64_t *resident_limit, int64_t *timed_launches, int64_t *timed_scans);

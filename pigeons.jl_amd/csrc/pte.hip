@@ -494,14 +494,20 @@ int fused_slice_variant(const pte_engine *h) {
 #define PTE_FUSED_SLICE_MAX_D 2048       // profiles/r05_fused_shapes.txt: 1024 chains, d = 512 x1.055, 1024 x1.03, 2048 x1.00, 4096 x0.99 against two launches per scan
 #endif
 #ifndef PTE_FUSED_LANGEVIN_MAX_D
-#define PTE_FUSED_LANGEVIN_MAX_D 512     // the Langevin-family loop exists for the register layouts one wave holds without spilling (E <= 8 blocks; profiles/r05_am_wg_ab.txt)
+#define PTE_FUSED_LANGEVIN_MAX_D 1024    // d <= 512: one wave per chain (k_scans_automala[_wg]; profiles/r05_am_wg_ab.txt); 512 < d <= 1024, MVN path: four waves per chain (k_scans_langevin_mw; profiles/r06_langevin_mw.txt)
 #endif
 // 0: not a fused kind; 1: SliceSampler on the MVN path (k_scans_slice8*); 2: AutoMALA / MALA on the MVN or funnel path (k_scans_automala)
 int fused_kind(const pte_engine *h) {
     if (h->cfg.explorer2 != PTE_EXPLORER_NONE) return 0;
     if (h->cfg.explorer == PTE_EXPLORER_SLICE && h->cfg.target == PTE_TARGET_MVN_SCALED_PRECISION && h->slice_impl == 8) return h->d <= PTE_FUSED_SLICE_MAX_D ? 1 : 0;
     if ((h->cfg.explorer == PTE_EXPLORER_AUTOMALA || h->cfg.explorer == PTE_EXPLORER_MALA) &&
-        (h->cfg.target == PTE_TARGET_MVN_SCALED_PRECISION || h->cfg.target == PTE_TARGET_FUNNEL)) return h->d <= PTE_FUSED_LANGEVIN_MAX_D ? 2 : 0;
+        (h->cfg.target == PTE_TARGET_MVN_SCALED_PRECISION || h->cfg.target == PTE_TARGET_FUNNEL)) {
+        if (h->d > 512) {      // four waves per chain: the scaled-precision MVN path only (the funnel's loop measured no gain: pte_langevin_launch.hpp)
+            if (h->cfg.target != PTE_TARGET_MVN_SCALED_PRECISION) return 0;
+            if (h->cfg.debug_kernel & PTE_KERNEL_TEST_LANGEVIN_ONE_WAVE) return 0;                 // (test build: the one-wave kernel with sixteen blocks per lane has no loop form)
+        }
+        return h->d <= PTE_FUSED_LANGEVIN_MAX_D ? 2 : 0;
+    }
     return 0;
 }
 int langevin_E(const pte_engine *h) { return h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16; }
@@ -1682,7 +1688,7 @@ const char *pte_scan_loop_name(const pte_engine *hc) {
     if (!h) return "";
     hipSetDevice(h->cfg.device);
     if (!fused_scans_eligible(h, 1)) return "";
-    if (fused_kind(h) == 2) return h->fused_wg > 1 ? "k_scans_automala_wg" : "k_scans_automala";
+    if (fused_kind(h) == 2) return h->d > 512 ? "k_scans_langevin_mw" : h->fused_wg > 1 ? "k_scans_automala_wg" : "k_scans_automala";
     return fused_slice_variant(h) == 0 ? "k_scans_slice8" : "k_scans_slice8_generic";
 }
 int pte_scan_loop_info(const pte_engine *hc, int64_t *resident_limit, int64_t *timed_launches, int64_t *timed_scans) {

@@ -843,7 +843,9 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
         for (int k = 0; k < 7; ++k) o[k] = (double)mw_prof[k];
         o[0] += (double)mw_prof[7];            // (loop head + the start state's store: with the momentum)
         o[7] = (double)(mw_rt0 & 0xFFFFFFFFFFFull); o[10] = (double)mw_sync;       // (o[7]: the workgroup's start on the 100 MHz clock)
-        o[8] = (double)(__builtin_amdgcn_s_memrealtime() - mw_rt0); o[9] = (double)steps_sum; o[11] = (double)ap.n_refresh;
+        o[8] = (double)(__builtin_amdgcn_s_memrealtime() - mw_rt0); o[9] = (double)steps_sum;
+        const uint32_t hw_ = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc_ = __builtin_amdgcn_s_getreg((3 << 11) | 20);     // HW_ID (cu_id 11:8, sh_id 12, se_id 15:13), XCC_ID
+        o[11] = (double)ap.n_refresh + 4096.0 * (double)(((xcc_ & 15u) << 8) | ((hw_ >> 8) & 0xFFu));                          // (which compute unit ran this replica)
     }
 #endif
     if (err) { if (owns_first) set_error(e, err, (int)c, -1); return; }
@@ -878,11 +880,86 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
 #ifndef PTE_MW_OCC_FUNNEL
 #define PTE_MW_OCC_FUNNEL 4
 #endif
+// The body as a CALLED function in the scan loop (as automala_body_called: inlined, the loop's long-lived values push the spilled values from 54-182
+// to 147-365).  What it must NOT get is a reference to the caller's copies of the engine and the parameters: every e.* / ap.* would be a load from the
+// caller's stack, to be repeated after any store that might alias it -- 4x the vector memory reads, 0.65 -> 0.97 ms per scan measured.  It gets the
+// KERNEL-ARGUMENT segment instead (constant address space: scalar loads, invariant, re-loadable instead of spilled -- what the per-scan kernel sees)
+// plus the two words the scan loop changes per scan.
+// Nor may they arrive as ordinary arguments: a called function's arguments live in VECTOR registers and count as divergent -- every value derived from them
+// would be a vector value, every branch on them a divergent one.  The function reads the kernel-argument segment pointer and the workgroup id itself (implicit
+// scalar inputs of any function of the call graph) and takes the two per-scan words through v_readfirstlane.
+// (llvm.amdgcn.kernarg.segment.ptr is null outside a kernel; the IMPLICIT-argument pointer is an input of every function, and the implicit arguments
+// follow the explicit ones: the segment starts sizeof(explicit arguments), rounded up to 8, before it.)
+typedef const char __attribute__((address_space(4))) *MwKernargP;
+constexpr size_t mw_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr size_t MW_KERNARG_AP = mw_align_up(sizeof(EngineDev), alignof(AmParams));                                         // k_*_langevin_mw(EngineDev, AmParams[, ScanLoop])
+constexpr size_t MW_KERNARG_END_EXPLORE = mw_align_up(MW_KERNARG_AP + sizeof(AmParams), 8);
+constexpr size_t MW_KERNARG_END_SCANS = mw_align_up(mw_align_up(MW_KERNARG_AP + sizeof(AmParams), alignof(ScanLoop)) + sizeof(ScanLoop), 8);
+template <int TGT, bool FULL, bool SCANS>
+__device__ __attribute__((noinline))        // (amdgpu_waves_per_eu is a kernel attribute; the AMDGPU attributor hands the caller's bound down to this function)
+void langevin_mw_body_called(const int trace_idx_lo, const int trace_idx_hi, const int use_mh) {
+    const MwKernargP ka = (MwKernargP)__builtin_amdgcn_implicitarg_ptr() - (SCANS ? MW_KERNARG_END_SCANS : MW_KERNARG_END_EXPLORE);
+    EngineDev e = *(const EngineDev *)ka;                               // (cast to generic for the copy constructor's sake: InferAddressSpaces takes the loads back to address space 4)
+    AmParams ap = *(const AmParams *)(ka + MW_KERNARG_AP);
+    e.trace_idx = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(trace_idx_hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(trace_idx_lo));
+    ap.use_mh = __builtin_amdgcn_readfirstlane(use_mh);
+    langevin_mw_body<TGT, FULL>(e, ap, blockIdx.x);
+}
+
 template <int TGT, bool FULL>
 __global__ __launch_bounds__(64 * MW_NWV)
 __attribute__((amdgpu_waves_per_eu(TGT == TGT_FUNNEL ? PTE_MW_OCC_FUNNEL : PTE_MW_OCC, TGT == TGT_FUNNEL ? PTE_MW_OCC_FUNNEL : PTE_MW_OCC)))
 void k_explore_langevin_mw(EngineDev e, AmParams ap) {
+#ifdef PTE_MW_EXPLORE_CALLED               // development builds only: what the call costs the per-scan kernel
+    langevin_mw_body_called<TGT, FULL, false>((int)(uint32_t)e.trace_idx, (int)(uint32_t)((uint64_t)e.trace_idx >> 32), ap.use_mh);
+#else
     langevin_mw_body<TGT, FULL>(e, ap, blockIdx.x);
+#endif
+}
+
+#ifndef PTE_MW_PRIO
+#define PTE_MW_PRIO 1
+#endif
+// One launch per pte_run_scans (pte_kernels.hpp "ScanLoop"), as k_scans_automala: the refreshes of a scan, then the pairwise swap hand-shake
+// (thread 0; the other 255 wait at the workgroup barrier and take no issue slots), for all the scans of the call.  Why here, where the loop was
+// held to d <= 512 through round 5: with four workgroups per compute unit and an age-ordered instruction arbiter the per-scan launch is as long
+// as the most loaded compute unit's LAST replica (profiles/r06_langevin_mw.txt: ends p10 / p50 / max 1180 / 1430 / 1950 us on the funnel,
+// correlation of a replica's duration with its own work 0.73, 0.28 on the MVN path; the sum of a compute unit's four replicas varies by +- 30 %
+// from scan to scan, at random) -- without a launch boundary the next scan's work fills those tails.
+template <int TGT, bool FULL>
+__global__ __launch_bounds__(64 * MW_NWV)
+__attribute__((amdgpu_waves_per_eu(TGT == TGT_FUNNEL ? PTE_MW_OCC_FUNNEL : PTE_MW_OCC, TGT == TGT_FUNNEL ? PTE_MW_OCC_FUNNEL : PTE_MW_OCC)))
+void k_scans_langevin_mw(EngineDev e, AmParams ap, ScanLoop sl) {
+    __shared__ int wg_word, wg_prio;
+    const int64_t cl = am_chain_of_workgroup(e.K, blockIdx.x);
+    if (threadIdx.x == 0) { wg_word = scan_loop_gate(sl) ? 1 : 0; wg_prio = 1; }       // every workgroup of the launch is resident, or nobody starts (pte_kernels.hpp)
+    __syncthreads();
+    if (!wg_word) return;
+    for (int64_t i = 0; i < sl.n_scans; ++i) {
+        e.trace_idx = sl.scan_idx0 + i;
+        if (!ap.mala) ap.use_mh = (sl.first_scan + i != 1) ? 1 : 0;
+        langevin_mw_body_called<TGT, FULL, true>((int)(uint32_t)e.trace_idx, (int)(uint32_t)((uint64_t)e.trace_idx >> 32), ap.use_mh);
+        __syncthreads();                                               // every thread's stores of the explore step happen before thread 0's release
+        if (threadIdx.x == 0) {
+#if PTE_MW_PRIO
+            // Who waits for whom?  A chain whose partner has already published this scan's epoch is on the ladder's critical path: its waves ask the
+            // instruction arbiter for more (s_setprio); one that is there first gives way.  (Four waves share a SIMD and keep it ~96 % busy.)
+            const int64_t c = e.c0 + cl, pc = deo_partner(e.N, ((sl.first_scan + i) % 2 == 0) ? 1 : 0, c);
+            if (pc != c) {
+                const bool late = __hip_atomic_load(&sl.flag[pc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= sl.epoch0 + 1ull + (unsigned long long)i;
+                int p = wg_prio;
+                p = late ? (p < 3 ? p + 1 : 3) : (p > 0 ? p - 1 : 0);
+                wg_prio = p;
+            }
+#endif
+            wg_word = swap_handshake(e, sl, i, cl, e.slot_of_chain[cl]);
+        }
+        __syncthreads();                                               // ... and thread 0's acquire before every thread's loads of the next one
+        if (wg_word < 0) return;
+#if PTE_MW_PRIO
+        switch (wg_prio) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); break; }
+#endif
+    }
 }
 
 }  // namespace pte

@@ -26,7 +26,7 @@ static inline void langevin_launch_scans(K kernel, const LangevinLaunch &L, cons
     else hipLaunchKernelGGL(kernel, dim3(grid), dim3(64 * wg), 0, L.stream, dev, ap, *L.scans);
 }
 
-// the fused scan loop exists for the shapes one wave holds comfortably (E <= 8: d <= 512); the d > 512 instantiations spill and stay per scan
+// the fused scan loop: one wave per chain for the shapes one wave holds comfortably (E <= 8: d <= 512), four waves per chain beyond (E = 16: k_scans_langevin_mw)
 #define AM_SCANS_ONE(EE, WHAT)                                                                                                   \
     if (target == TGT_FUNNEL && full) { WHAT((k_scans_automala<EE, TGT_FUNNEL, true>)); }                                        \
     else if (target == TGT_FUNNEL) { WHAT((k_scans_automala<EE, TGT_FUNNEL, false>)); }                                          \
@@ -38,12 +38,36 @@ static inline void langevin_launch_scans(K kernel, const LangevinLaunch &L, cons
     else if (full) { WHAT((k_scans_automala_wg<EE, TGT_MVN, true>)); }                                                           \
     else { WHAT((k_scans_automala_wg<EE, TGT_MVN, false>)); }
 
+template <typename K>
+static inline void langevin_launch_scans_mw(K kernel, const LangevinLaunch &L, const EngineDev &dev, const AmParams &ap) {      // one 256-thread workgroup per chain
+    if (L.ext) hipExtLaunchKernelGGL(kernel, dim3(L.N), dim3(64 * MW_NWV), 0, L.stream, L.ev_a, L.ev_b, 0, dev, ap, *L.scans);
+    else hipLaunchKernelGGL(kernel, dim3(L.N), dim3(64 * MW_NWV), 0, L.stream, dev, ap, *L.scans);
+}
+// (the scaled-precision MVN path only: on the funnel path the loop measured 1.905 ms per scan against 1.875-1.90 of the per-scan launches -- its
+// body as a called function is 7 % slower than inlined, which eats what the loop gains; profiles/r06_langevin_mw.txt -- and is not instantiated)
+#define AM_SCANS_MW(WHAT)                                                                                                        \
+    if (target == TGT_FUNNEL) { return MW_NO_FUNNEL_LOOP; }                                                                      \
+    else if (full) { WHAT((k_scans_langevin_mw<TGT_MVN, true>)); }                                                               \
+    else { WHAT((k_scans_langevin_mw<TGT_MVN, false>)); }
+
 int langevin_scan_wg() { return PTE_SCAN_WG; }
 int langevin_scan_loop_blocks_per_cu(int E, int target, bool full, int scan_wg) {
-#if defined(PTE_DEV_NO_LANGEVIN) || defined(PTE_DEV_ONLY_MW)
+#if defined(PTE_DEV_NO_LANGEVIN)
     (void)E; (void)target; (void)full; (void)scan_wg; return 0;
 #else
     int n = 0;
+    if (E == 16) {                                      // 512 < d <= 1024: four waves per chain (k_scans_langevin_mw)
+        if (scan_wg > 1) return 0;
+#define MW_NO_FUNNEL_LOOP 0
+#define AM_OCC(KERNEL) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, KERNEL, 64 * MW_NWV, 0)
+        AM_SCANS_MW(AM_OCC)
+#undef AM_OCC
+#undef MW_NO_FUNNEL_LOOP
+        return n;
+    }
+#ifdef PTE_DEV_ONLY_MW
+    return 0;
+#else
     if (scan_wg > 1) {
         if (scan_wg != PTE_SCAN_WG) return 0;
 #define AM_OCC(KERNEL) hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, KERNEL, 64 * PTE_SCAN_WG, 0)
@@ -56,14 +80,25 @@ int langevin_scan_loop_blocks_per_cu(int E, int target, bool full, int scan_wg) 
 #undef AM_OCC
     return n;
 #endif
+#endif
 }
 
 int langevin_launch(const LangevinLaunch &L, const EngineDev &dev, const AmParams &ap) {
 #ifdef PTE_DEV_NO_LANGEVIN      // development builds only (tools/build_variant.sh): three quarters of the compile time are these instantiations
     (void)L; (void)dev; (void)ap; return 1;
 #else
-#ifdef PTE_DEV_ONLY_MW           // development builds only (tools/build_variant_mw.sh): the four-waves-per-replica kernel and nothing else of the family
-    if (L.scans || L.slice || L.E != 16) return 1;
+#ifdef PTE_DEV_ONLY_MW           // development builds only (tools/build_variant_mw.sh): the four-waves-per-replica kernels and nothing else of the family
+    if (L.slice || L.E != 16) return 1;
+    if (L.scans) {
+        const int target = L.target; const bool full = L.full;
+        if (L.scan_wg > 1) return 1;
+#define MW_NO_FUNNEL_LOOP 1
+#define AM_GO(KERNEL) langevin_launch_scans_mw(KERNEL, L, dev, ap)
+        AM_SCANS_MW(AM_GO)
+#undef AM_GO
+#undef MW_NO_FUNNEL_LOOP
+        return 0;
+    }
     if (L.target == TGT_FUNNEL && L.full) langevin_launch_mw(k_explore_langevin_mw<TGT_FUNNEL, true>, L, dev, ap);
     else if (L.target == TGT_FUNNEL) langevin_launch_mw(k_explore_langevin_mw<TGT_FUNNEL, false>, L, dev, ap);
     else if (L.full) langevin_launch_mw(k_explore_langevin_mw<TGT_MVN, true>, L, dev, ap);
@@ -73,6 +108,15 @@ int langevin_launch(const LangevinLaunch &L, const EngineDev &dev, const AmParam
     if (L.scans) {
         const int target = L.target; const bool full = L.full;
 #define AM_GO(KERNEL) langevin_launch_scans(KERNEL, L, dev, ap)
+        if (L.E == 16) {                                 // 512 < d <= 1024: four waves per chain
+            if (L.scan_wg > 1) return 1;
+#define MW_NO_FUNNEL_LOOP 1
+#define AM_GO_MW(KERNEL) langevin_launch_scans_mw(KERNEL, L, dev, ap)
+            AM_SCANS_MW(AM_GO_MW)
+#undef AM_GO_MW
+#undef MW_NO_FUNNEL_LOOP
+            return 0;
+        }
         if (L.scan_wg > 1) {
             if (L.scan_wg != PTE_SCAN_WG) return 1;
             switch (L.E) { case 1: AM_SCANS_WG_ONE(1, AM_GO) break; case 2: AM_SCANS_WG_ONE(2, AM_GO) break; case 4: AM_SCANS_WG_ONE(4, AM_GO) break; case 8: AM_SCANS_WG_ONE(8, AM_GO) break; default: return 1; }

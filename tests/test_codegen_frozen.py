@@ -147,7 +147,7 @@ def test_swap_kernels_are_light(cg):
 
 
 def test_langevin_mw_kernels(cg):
-    """k_explore_langevin_mw (round 6: AutoMALA / MALA at 512 < d <= 1024, four waves per replica): 128 VGPRs = four waves per SIMD = four workgroups per
+    """k_explore_langevin_mw / k_scans_langevin_mw (round 6: AutoMALA / MALA at 512 < d <= 1024, four waves per replica): 128 VGPRs = four waves per SIMD = four workgroups per
     compute unit (1024 replicas resident; 39 KB of LDS each: four fit the 160 KB).  Scaled-precision MVN path: the loop of trial leapfrogs (~300 VALU + 150
     scalar + 15 LDS instructions: the one holding the cross-wave exchange) touches no scratch and holds no spill write -- what is spilled (55-68 values) is
     spilled at refresh level.  Funnel path: its evaluation does not fit beside the vectors (124-176 values spilled) and is still fastest at this setting
@@ -165,6 +165,16 @@ def test_langevin_mw_kernels(cg):
         assert t["scratch"] == 0 and t["w"] == 0 and t["r"] <= 2 and t["v"] <= 320 and t["s"] <= 170, (full, t)
         for k, L in loops.items():
             assert L["scratch"] <= 2, (full, k, L)                          # nothing at any loop level below the refresh reloads more than a value or two from scratch
+        # the scan loop's body (k_scans_langevin_mw calls it): the SAME trial loop -- it reads the kernel-argument segment itself (scalar loads); handed a reference
+        # to the caller's copies it issued 4x the vector memory reads and ran at 0.97 instead of 0.65 ms per scan
+        s_ = res["k_scans_langevin_mw<0, %s>" % full]
+        assert s_["vgpr"] <= 128 and s_["waves_per_simd"] == 4 and s_["lds_B"] <= 40960, s_
+        cname, cbody = C.kernel_body(lines, "langevin_mw_body_calledILi0ELb%dELb1E" % (1 if full == "true" else 0))
+        cloops = {k: L for k, L in C.loops(cbody).items() if k[0] >= 2}
+        ctrial = [L for L in cloops.values() if L["l"] >= 10 and 250 <= L["v"] <= 340]
+        assert len(ctrial) == 1, cloops
+        assert ctrial[0]["scratch"] <= (0 if full == "true" else 2) and ctrial[0]["w"] == 0 and ctrial[0]["r"] <= 2 and ctrial[0]["v"] <= 320 and ctrial[0]["s"] <= 170, (full, ctrial[0])
+        assert sum("flat_load" in l for l in cbody) == 0 and sum("s_load_dword" in l for l in cbody) >= 20, cname     # the engine's fields: scalar loads from the constant address space
         f = res["k_explore_langevin_mw<2, %s>" % full]
         assert f["vgpr"] <= 128 and f["waves_per_simd"] == 4 and f["lds_B"] <= 40960 and f["spilled_vgpr"] <= 200, f
     # the one-wave kernels with sixteen blocks per lane are gone from the product build (their SliceSampler instantiation, which does not spill, stays)

@@ -176,6 +176,52 @@ def test_fused_langevin_scan_loop_equals_launch_per_scan(P, target, N, d, rounds
         assert np.array_equal(x, y) and np.array_equal(x, z)
 
 
+@pytest.mark.parametrize("N,d,rounds,seed,explorer", [
+    (1024, 1024, 3, 1, "automala"),               # every workgroup slot of the device taken: four 256-thread workgroups per compute unit
+    (64, 1024, 5, 2, "automala"),
+    (33, 600, 5, 3, "automala"),                  # ragged blocks, odd N
+    (16, 1024, 5, 4, "mala"),
+    (7, 513, 5, 5, "automala"),
+    (2, 777, 6, 6, "automala"),                   # reference + target only
+    (1, 1024, 4, 7, "automala"),                  # a single chain
+])
+def test_fused_langevin_mw_scan_loop_equals_launch_per_scan(P, N, d, rounds, seed, explorer):
+    """512 < d <= 1024 on the scaled-precision MVN path (round 6, late): k_scans_langevin_mw -- the four-waves-per-chain body as a called function,
+    reading the kernel-argument segment through the implicit-argument pointer, thread 0 shaking hands, wave priorities following who waited for
+    whom -- against explore + swap launches per scan, bit for bit: every recorder of every round, states, chains, streams."""
+    ex = (lambda: P.AutoMALA()) if explorer == "automala" else (lambda: P.MALA(step_size=0.05))
+    pa, a = _run_am(P, N, d, rounds, seed, True, "mvn", ex())
+    pb, b = _run_am(P, N, d, rounds, seed, False, "mvn", ex())
+    assert pa.replicas.scan_loop_name() == "" and pb.replicas.scan_loop_name() == "k_scans_langevin_mw"
+    assert pa.replicas.kernel_name() == pb.replicas.kernel_name() == "k_explore_langevin_mw"
+    _same(a, b)
+    for x, y in zip(pa.replicas.states(), pb.replicas.states()):
+        assert np.array_equal(x, y)
+    calls, aborts, poisoned = pb.replicas.scan_loop_stats()
+    assert calls == rounds and aborts == 0 and not poisoned
+
+
+def test_fused_langevin_mw_loop_with_traces_and_split_calls(P):
+    """the per-scan words the called body takes through v_readfirstlane (trace row, the scan != 1 rule) across several pte_run_scans calls per round"""
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.traces, P.online]
+    def run(two):
+        from pigeons_amd import _lib
+        pt = P.PT(P.Inputs(target=P.toy_mvn_target(640), n_chains=9, n_rounds=5, seed=11, explorer=P.AutoMALA(), record=rec, show_report=False),
+                  debug_kernel=_lib.KERNEL_TWO_LAUNCHES if two else 0)
+        e = pt.replicas
+        e.run_scans(1, 1); e.run_scans(2, 3); e.run_scans(5, 2); e.run_scans(7, 1)     # scan 1 alone (no MH step), then a call that starts at scan 2
+        from pigeons_amd.pt import reduce_recorders
+        red = reduce_recorders(pt)
+        return pt, [red.index_process.copy(), red.swap_acceptance_pr[0].copy(), red.log_sum_ratio[0].copy(), np.array(red.traces).copy(),
+                    np.array(red.online[0]).copy(), red.explorer_acceptance_pr[0].copy(), np.array(red.am_factors[0]).copy()]
+    pa, a = run(True); pb, b = run(False)
+    assert pb.replicas.scan_loop_name() == "k_scans_langevin_mw" and pa.replicas.scan_loop_name() == ""
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y, equal_nan=True), k
+    for x, y in zip(pa.replicas.states(), pb.replicas.states()):
+        assert np.array_equal(x, y)
+
+
 def test_which_engines_run_the_fused_loop(P):
     """the documented choice: SliceSampler on the MVN path with the default kernel generation, one engine, all workgroups resident"""
     from pigeons_amd import _lib
@@ -184,7 +230,9 @@ def test_which_engines_run_the_fused_loop(P):
     assert mk().replicas.scan_loop_name() == "k_scans_slice8"
     assert mk(explorer=P.ToyExplorer()).replicas.scan_loop_name() == ""
     assert mk(explorer=P.AutoMALA()).replicas.scan_loop_name() == "k_scans_automala_wg"
-    assert mk(explorer=P.AutoMALA(), target=P.toy_mvn_target(600)).replicas.scan_loop_name() == ""   # d > 512: the spilling register layouts stay per scan
+    assert mk(explorer=P.AutoMALA(), target=P.toy_mvn_target(600)).replicas.scan_loop_name() == "k_scans_langevin_mw"   # 512 < d <= 1024, MVN path: four waves per chain
+    assert mk(explorer=P.AutoMALA(), target=P.Funnel(600), reference=P.ScaledPrecisionNormalLogPotential(1 / 9., 600)).replicas.scan_loop_name() == ""   # the funnel's loop measured no gain at d > 512
+    assert mk(explorer=P.AutoMALA(), target=P.toy_mvn_target(600), n_chains=1025).replicas.scan_loop_name() == ""       # more 256-thread workgroups than the device holds at once
     assert mk(explorer=P.Compose(P.SliceSampler(), P.AutoMALA())).replicas.scan_loop_name() == ""
     assert mk(target=P.toy_mvn_target(64), n_chains=8192).replicas.scan_loop_name() == ""            # more workgroups than the GPU holds at once
     assert mk(target=P.toy_mvn_target(64), n_chains=1025).replicas.scan_loop_name() == ""            # more than one wave per SIMD: measured slower (0.91x at 2048 chains)

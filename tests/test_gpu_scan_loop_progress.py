@@ -131,7 +131,7 @@ def test_two_engines_from_two_processes():
     assert serial[0][0] != serial[1][0]
 
 
-@pytest.mark.parametrize("explorer,N,d,kernel", [("slice", 64, 96, "k_scans_slice8"), ("automala", 37, 24, "k_scans_automala_wg")])
+@pytest.mark.parametrize("explorer,N,d,kernel", [("slice", 64, 96, "k_scans_slice8"), ("automala", 37, 24, "k_scans_automala_wg"), ("automala", 12, 600, "k_scans_langevin_mw")])
 def test_late_workgroup_aborts_the_launch_and_the_call_falls_back(P, explorer, N, d, kernel):
     """PTE_KERNEL_TEST_LATE_WORKGROUP (test build): workgroup 3 arrives 80 ms late at every launch's gate -> the gate's 50 ms bound passes,
     every workgroup leaves with NOTHING written, pte_run_scans runs explore + swap launches instead.  Same results as the undisturbed
@@ -160,7 +160,7 @@ def test_product_library_refuses_the_fault_injection_flags(P):
         Engine(n_chains=16, dim=8, explorer=_lib.EXPLORER_SLICE, debug_kernel=_lib.KERNEL_TEST_DEAD_CHAIN)
 
 
-@pytest.mark.parametrize("explorer,N,d", [("slice", 64, 96), ("automala", 40, 24)])
+@pytest.mark.parametrize("explorer,N,d", [("slice", 64, 96), ("automala", 40, 24), ("automala", 12, 600)])      # (d = 600: k_scans_langevin_mw, 256 threads per chain)
 def test_dead_chain_times_out_once_poisons_the_engine_and_set_state_revives_it(P, explorer, N, d):
     from pigeons_amd import _lib
     ex = (lambda: P.SliceSampler()) if explorer == "slice" else (lambda: P.AutoMALA())

@@ -28,7 +28,7 @@ for scan in range(6):
     assert L.pte_debug_wave_profile(e.h, out.ctypes.data_as(C.POINTER(C.c_double))) == 0
     acc.append(out.reshape(N, 12)[1:])
 o = np.mean(acc[1:], axis=0)
-tot = o[:, :7].sum(axis=1); nref = o[0, 11]; leaps = o[:, 9]
+tot = o[:, :7].sum(axis=1); nref = int(o[0, 11]) % 4096; leaps = o[:, 9]
 print("%s(%d) N = %d k_explore_langevin_mw: n_refresh %d; per replica and scan %.0f ticks in the loop = %.1f us (100 MHz clock): %.1f ticks per us" % (path, d, N, nref, tot.mean(), o[:, 8].mean() / 100.0, tot.mean() / (o[:, 8].mean() / 100.0)))
 for k in range(7):
     print("  %-48s %9.0f ticks  %5.1f %%   per refresh %7.0f" % (names[k], o[:, k].mean(), 100.0 * o[:, k].mean() / tot.mean(), o[:, k].mean() / nref))

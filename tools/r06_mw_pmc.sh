@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_mw_pmc; mkdir -p $O
 V=$1
 if [ -n "$V" ]; then export PTE_LIB=$R/build_variants/libpte_mw_$V.so; fi
-export BM_ONLY=mw
+export BM_ONLY=${BM_ONLY:-mw}
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O -o sq -- python3 $R/tools/bench_mw.py > $O/sq.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 -d $O -o sq2 -- python3 $R/tools/bench_mw.py > $O/sq2.log 2>&1
 python3 - "$O" <<'PY'
