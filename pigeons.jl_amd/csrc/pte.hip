@@ -104,6 +104,7 @@ struct pte_engine {
     int64_t t_scans4 = 0;             // scans inside the timed launches of kind 4
     // one launch per pte_run_scans (k_scans_*: pte_kernels.hpp "ScanLoop"): pairwise hand-shakes instead of a launch boundary per scan
     bool fused_allowed = true;        // pte_config.debug_kernel & PTE_KERNEL_TWO_LAUNCHES clears it
+    int n_cus = -1;                   // compute units of the device (lazily)
     bool fused_wg_allowed = true;     // ... & PTE_KERNEL_SCAN_LOOP_ONE_CHAIN clears it
     int fused_wg = 1;                 // chains (waves) per workgroup of the scan-loop kernel this engine launches
     int64_t fused_limit = -1;         // workgroups of the scan-loop kernel the device holds at once (-1: not asked yet, 0: not available)
@@ -304,11 +305,20 @@ void time_collect(pte_engine *h) {
 }
 
 
+// k_*_langevin_mw steer their waves' priorities by the replicas' pace where that can help: more workgroups than compute units (they share SIMDs) and
+// all of them resident at once (four per compute unit) -- one per compute unit the counter costs 3-6 %, with a second generation the late starters
+// look slow and the steering costs 3-5 % (profiles/r06_langevin_mw.txt)
+static int langevin_mw_paced(pte_engine *h) {
+    if (h->n_cus < 0) { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->cfg.device) != hipSuccess) cus = 0; (void)hipGetLastError(); h->n_cus = cus; }
+    return (h->n_cus > 0 && h->K > (int64_t)h->n_cus && h->K <= 4 * (int64_t)h->n_cus) ? 1 : 0;
+}
+
 // one launch of the Langevin-family kernel (pte_automala_params.hpp); like PTE_LAUNCH1, the open timing bracket's events ride on it
 static int launch_langevin(pte_engine *h, int E, int target, bool slice, bool full, int64_t N, const AmParams &ap) {
     LangevinLaunch L{E, target, slice, full, (unsigned)N, h->stream, false, nullptr, nullptr};
     L.one_wave16 = (h->cfg.debug_kernel & PTE_KERNEL_TEST_LANGEVIN_ONE_WAVE) != 0;       // (test build only: pte_create refuses the flag otherwise)
     if (h->ev_open && h->ev_ext && !h->ev_ext_done) { L.ext = true; L.ev_a = h->events.back().a; L.ev_b = h->events.back().b; h->ev_ext_done = true; }
+    if (E == 16 && !slice && !L.one_wave16) HIP_OK(h, hipMemsetAsync(h->dev.pace, 0, sizeof(unsigned int), h->stream));      // k_explore_langevin_mw: its workgroups count their refreshes here
     if (langevin_launch(L, h->dev, ap)) return fail(h, "this build holds no Langevin-family kernels (PTE_DEV_NO_LANGEVIN)");
     return 0;
 }
@@ -395,6 +405,7 @@ int launch_explorer_kind(pte_engine *h, int64_t scan, int kind) {
         ap.target_std = h->have_target_std ? h->d_target_std : nullptr;
         ap.use_mh = (scan != 1) ? 1 : 0;                 // AutoMALA.jl:87,96-102
         ap.ref_prec = h->cfg.target_params[0]; ap.log3 = std::log(3.0);
+        ap.pace = h->d > 512 ? langevin_mw_paced(h) : 0;
         const int E = h->d <= 64 ? 1 : h->d <= 128 ? 2 : h->d <= 256 ? 4 : h->d <= 512 ? 8 : 16;
         const bool fun = h->cfg.target == PTE_TARGET_FUNNEL;
         time_begin(h, 0, true);
@@ -589,9 +600,11 @@ int run_scans_fused(pte_engine *h, int64_t first_scan, int64_t n_scans) {
         ap.target_std = h->have_target_std ? h->d_target_std : nullptr;
         ap.use_mh = 1;
         ap.ref_prec = h->cfg.target_params[0]; ap.log3 = std::log(3.0);
+        ap.pace = h->d > 512 ? langevin_mw_paced(h) : 0;
         const int E = langevin_E(h);
         LangevinLaunch L{E, h->cfg.target == PTE_TARGET_FUNNEL ? TGT_FUNNEL : TGT_MVN, false, h->d == 64 * (int64_t)E, (unsigned)N, h->stream, false, nullptr, nullptr, &sl, h->fused_wg};
         if (h->ev_open && h->ev_ext && !h->ev_ext_done) { L.ext = true; L.ev_a = h->events.back().a; L.ev_b = h->events.back().b; h->ev_ext_done = true; }
+        if (E == 16) HIP_OK(h, hipMemsetAsync(h->dev.pace, 0, sizeof(unsigned int), h->stream));      // k_scans_langevin_mw: its workgroups count their refreshes here
         if (langevin_launch(L, h->dev, ap)) { time_end(h); return fail(h, "this build holds no fused Langevin-family kernel"); }
     }
     time_end(h);
@@ -804,6 +817,7 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.index_process, (size_t)ipcap, false);
     rc |= dev_alloc(h, &e.ip_replica, (size_t)ipcap, false);
     rc |= dev_alloc(h, &e.error, 4);
+    rc |= dev_alloc(h, &e.pace, 2);
     e.swap_log = nullptr;
     if (cfg->record_flags & PTE_RECORD_REFERENCE_REDUCTION) rc |= dev_alloc(h, &e.swap_log, (size_t)(cfg->max_scans_per_round * K * 2), false);
     e.am_log = nullptr; e.am_log_cap = 0;

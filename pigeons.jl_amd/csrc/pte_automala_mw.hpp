@@ -60,6 +60,7 @@ struct MwLds {
     double bounds[2];                     // log of the two uniforms that bound the step-size search (evaluated by wave 0 alone)
     unsigned long long seed[MW_NWV];      // sequential procedure: stream position after wave w's momentum blocks
     int mom_cons[MW_NWV], mom_fail[MW_NWV], mom_below[MW_NWV];      // compaction: positions a segment consumed; what it cannot follow; consumed by the attempts of the outputs below d
+    int prio;                             // per-scan launches: the priority this replica's waves ask for in the refresh that begins (by its pace against the launch's mean)
 #ifdef PTE_MW_LDS_PAD                     // development builds only: where does the fourth workgroup of a compute unit stop fitting
     char pad[PTE_MW_LDS_PAD];
 #endif
@@ -280,8 +281,23 @@ __device__ __forceinline__ uint64_t mw_draw_momentum(const MwLdsP L, const uint6
     return seed0 + (uint64_t)(dn + ((L->mom_below[0] + L->mom_below[1]) + (L->mom_below[2] + L->mom_below[3]))) * gamma;
 }
 
-template <int TGT, bool FULL>
-__device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmParams &ap, const int64_t wg) {
+#ifndef PTE_MW_PACE
+#define PTE_MW_PACE 1
+#endif
+#ifndef PTE_MW_PACE_SCANS
+#define PTE_MW_PACE_SCANS 1             // the scan loop too, beside its hand-shake rule (its launch zeroes the counter, a replica's own count runs over the scans of the call): toy_mvn(600) 0.471 -> 0.436, toy_mvn(1024) 0.552 -> 0.524-0.554
+#endif
+#ifndef PTE_MW_PACE_T0
+#define PTE_MW_PACE_T0 0               // ahead of the mean: lowest; up to two refreshes behind: 1; up to four: 2; more: 3 -- measured flat around (0, 4, 8) and (2, 6, 10);
+#define PTE_MW_PACE_T1 4               // finer steps -- (0, 1, 2), (0, 2, 4) -- and coarser ones -- (0, 8, 16) -- cost 1-4 % (profiles/r06_langevin_mw.txt)
+#define PTE_MW_PACE_T2 8
+#endif
+// PACE (the per-scan launch): four replicas share a compute unit's SIMDs, the instruction arbiter serves the oldest wave first, so they END staggered and the
+// last one runs alone, at a lone wave's poor issue rate -- and the launch is as long as the slowest replica of the most loaded compute unit
+// (profiles/r06_langevin_mw.txt).  Every replica counts its refreshes into e.pace; one that has begun fewer than the launch's mean asks for more issue
+// slots (s_setprio), one that is ahead gives way: the replicas of a compute unit finish together, with all four waves of a SIMD busy to the end.
+template <int TGT, bool FULL, bool PACE = false>
+__device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmParams &ap, const int64_t wg, const int pace_base = 0) {      // pace_base: refreshes this replica has begun since e.pace was zeroed
     constexpr int EW = MW_EW, NWV = MW_NWV;
     static_assert(NWV == 4, "the cross-wave levels of the tree are written for four waves");
     __shared__ MwLds L;
@@ -747,6 +763,9 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
 
     for (int it = 0; it < ap.n_refresh && !err; ++it) {
         MW_STAMP(7);
+        unsigned int begun = 0;
+        const bool paced = PACE && PTE_MW_PACE && ap.pace && !ap.mala;             // (MALA: a refresh is one leapfrog -- equal work, and 37 k increments of one word per 0.3 ms cost more than they steer: 0.335 -> 0.49 ms)
+        if (paced && owns_first) begun = __hip_atomic_fetch_add(e.pace, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (consumed behind the momentum)
         // the refresh's start state (read back by the forward search's restores and on a rejection)
 #pragma unroll
         for (int j = 0; j < EW; ++j) L.v[MW_XS][gidx(j)] = x[j];
@@ -754,7 +773,17 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
         r.seed = mw_draw_momentum<FULL>(Lp, r.seed, r.gamma, d);
 #pragma unroll
         for (int j = 0; j < EW; ++j) p[j] = valid(j) ? L.mom.out[gidx(j)] : 0.0;
+        if (paced) {
+            if (owns_first) {                                           // refreshes begun by the K workgroups before this one: mean = begun / K against this replica's own count
+                const long long ahead = (long long)begun - (long long)(pace_base + it) * (long long)e.K;
+                const long long hk = (long long)e.K / 2;                  // thresholds in half refreshes of the mean
+                L.prio = ahead < PTE_MW_PACE_T0 * hk ? 0 : ahead < PTE_MW_PACE_T1 * hk ? 1 : ahead < PTE_MW_PACE_T2 * hk ? 2 : 3;
+            }
+        }
         __syncthreads();                                                // (the workspace's bytes are the kept trial's and the start gradient's again from here on)
+        if (paced) {
+            switch (L.prio) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); break; }
+        }
         MW_STAMP(0);
         if (it == 0) lp0 = U(density_and_conditioned_gradient(g0, p, pp0));
         else pp0 = sqr_norm(p);
@@ -897,13 +926,13 @@ constexpr size_t MW_KERNARG_END_EXPLORE = mw_align_up(MW_KERNARG_AP + sizeof(AmP
 constexpr size_t MW_KERNARG_END_SCANS = mw_align_up(mw_align_up(MW_KERNARG_AP + sizeof(AmParams), alignof(ScanLoop)) + sizeof(ScanLoop), 8);
 template <int TGT, bool FULL, bool SCANS>
 __device__ __attribute__((noinline))        // (amdgpu_waves_per_eu is a kernel attribute; the AMDGPU attributor hands the caller's bound down to this function)
-void langevin_mw_body_called(const int trace_idx_lo, const int trace_idx_hi, const int use_mh) {
+void langevin_mw_body_called(const int trace_idx_lo, const int trace_idx_hi, const int use_mh, const int pace_base) {
     const MwKernargP ka = (MwKernargP)__builtin_amdgcn_implicitarg_ptr() - (SCANS ? MW_KERNARG_END_SCANS : MW_KERNARG_END_EXPLORE);
     EngineDev e = *(const EngineDev *)ka;                               // (cast to generic for the copy constructor's sake: InferAddressSpaces takes the loads back to address space 4)
     AmParams ap = *(const AmParams *)(ka + MW_KERNARG_AP);
     e.trace_idx = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(trace_idx_hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(trace_idx_lo));
     ap.use_mh = __builtin_amdgcn_readfirstlane(use_mh);
-    langevin_mw_body<TGT, FULL>(e, ap, blockIdx.x);
+    langevin_mw_body<TGT, FULL, !SCANS || PTE_MW_PACE_SCANS>(e, ap, blockIdx.x, __builtin_amdgcn_readfirstlane(pace_base));
 }
 
 template <int TGT, bool FULL>
@@ -911,9 +940,9 @@ __global__ __launch_bounds__(64 * MW_NWV)
 __attribute__((amdgpu_waves_per_eu(TGT == TGT_FUNNEL ? PTE_MW_OCC_FUNNEL : PTE_MW_OCC, TGT == TGT_FUNNEL ? PTE_MW_OCC_FUNNEL : PTE_MW_OCC)))
 void k_explore_langevin_mw(EngineDev e, AmParams ap) {
 #ifdef PTE_MW_EXPLORE_CALLED               // development builds only: what the call costs the per-scan kernel
-    langevin_mw_body_called<TGT, FULL, false>((int)(uint32_t)e.trace_idx, (int)(uint32_t)((uint64_t)e.trace_idx >> 32), ap.use_mh);
+    langevin_mw_body_called<TGT, FULL, false>((int)(uint32_t)e.trace_idx, (int)(uint32_t)((uint64_t)e.trace_idx >> 32), ap.use_mh, 0);
 #else
-    langevin_mw_body<TGT, FULL>(e, ap, blockIdx.x);
+    langevin_mw_body<TGT, FULL, true>(e, ap, blockIdx.x);
 #endif
 }
 
@@ -938,7 +967,7 @@ void k_scans_langevin_mw(EngineDev e, AmParams ap, ScanLoop sl) {
     for (int64_t i = 0; i < sl.n_scans; ++i) {
         e.trace_idx = sl.scan_idx0 + i;
         if (!ap.mala) ap.use_mh = (sl.first_scan + i != 1) ? 1 : 0;
-        langevin_mw_body_called<TGT, FULL, true>((int)(uint32_t)e.trace_idx, (int)(uint32_t)((uint64_t)e.trace_idx >> 32), ap.use_mh);
+        langevin_mw_body_called<TGT, FULL, true>((int)(uint32_t)e.trace_idx, (int)(uint32_t)((uint64_t)e.trace_idx >> 32), ap.use_mh, (int)i * ap.n_refresh);
         __syncthreads();                                               // every thread's stores of the explore step happen before thread 0's release
         if (threadIdx.x == 0) {
 #if PTE_MW_PRIO

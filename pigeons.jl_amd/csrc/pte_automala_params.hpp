@@ -23,6 +23,7 @@ struct AmParams {
     double slice_w; int slice_p, slice_n_passes, slice_max_iter;
     double ref_prec;        // funnel: precision of the normal reference
     double log3;            // log(3.0) from the host libm
+    int pace;               // k_*_langevin_mw: 1 = steer the waves' priorities by the replicas' pace (several workgroups share a compute unit and all are resident)
 };
 
 // one launch of k_explore_automala<E, target, slice mode, whole blocks>: N workgroups of one wave on `stream`; `ext`: the launch carries
