@@ -818,6 +818,8 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.ip_replica, (size_t)ipcap, false);
     rc |= dev_alloc(h, &e.error, 4);
     rc |= dev_alloc(h, &e.pace, 2);
+    e.mw_gk = nullptr;
+    if (funnel && uses_grad && d > 512) rc |= dev_alloc(h, &e.mw_gk, (size_t)K * 1024, false);
     e.swap_log = nullptr;
     if (cfg->record_flags & PTE_RECORD_REFERENCE_REDUCTION) rc |= dev_alloc(h, &e.swap_log, (size_t)(cfg->max_scans_per_round * K * 2), false);
     e.am_log = nullptr; e.am_log_cap = 0;

@@ -284,6 +284,12 @@ __device__ __forceinline__ uint64_t mw_draw_momentum(const MwLdsP L, const uint6
 #ifndef PTE_MW_PACE
 #define PTE_MW_PACE 1
 #endif
+#ifndef PTE_MW_KEEP_GK
+#define PTE_MW_KEEP_GK 1
+#endif
+#ifndef PTE_MW_PACKED_SUMS
+#define PTE_MW_PACKED_SUMS 0            // development builds: wave_sum_packed4 for the leapfrog's three / four sums (32 fewer instructions, a longer dependent chain): funnel(1024)
+#endif                                  // 1.593 -> 1.585, toy_mvn(1024) -1 %, toy_mvn(600) +10 % (0.447 -> 0.494) -- not taken
 #ifndef PTE_MW_PACE_SCANS
 #define PTE_MW_PACE_SCANS 1             // the scan loop too, beside its hand-shake rule (its launch zeroes the counter, a replica's own count runs over the scans of the call): toy_mvn(600) 0.471 -> 0.436, toy_mvn(1024) 0.552 -> 0.524-0.554
 #endif
@@ -375,7 +381,14 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
 #pragma unroll
         for (int k = 0; k < K; ++k) v[k] = (leaf4[k][0] + leaf4[k][1]) + (leaf4[k][2] + leaf4[k][3]);
         if constexpr (K == 1) nodes[0] = wave_sum_dpp(v[0]);
-        else {
+        else if constexpr ((K == 3 || K == 4) && PTE_MW_PACKED_SUMS) {      // levels 3-6 of the tree paid once for all of them (pte_device.hpp: 48 instructions against 60 / 80)
+            double v4[4], o4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v4[k] = k < K ? v[k] : 0.0;
+            wave_sum_packed4<K>(v4, o4);
+#pragma unroll
+            for (int k = 0; k < K; ++k) nodes[k] = o4[k];
+        } else {
             wave_sum_dpp_multi<K>(v);
 #pragma unroll
             for (int k = 0; k < K; ++k) nodes[k] = v[k];
@@ -491,6 +504,31 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
         const bool sok = markstein_divisor_ok(sigma);
         const double LOG2PI = 1.8378770664093453;
         double mine[4], out[4];
+#if PTE_MW_PACKED_SUMS
+        {
+            // |x|^2, the log-density terms, the first coordinate's gradient terms, |q|^2: their two in-lane levels one after the other (four doubles
+            // stay), then ONE packed butterfly (levels 3-6 of the tree paid once for the four sums)
+            double v4[4];
+            v4[0] = (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+            v4[3] = (q[0] * q[0] + q[1] * q[1]) + (q[2] * q[2] + q[3] * q[3]);
+            double zi[EW];
+            div_sigma(x, sigma, rinv, sok, zi);
+            {
+                double t[2][EW];
+#pragma unroll
+                for (int j = 0; j < EW; ++j) {
+                    t[0][j] = valid(j) ? (-(zi[j] * zi[j] + LOG2PI) / 2.0 - logsigma) : 0.0;
+                    t[1][j] = valid(j) ? (zi[j] * zi[j] - 1.0) / 2.0 : 0.0;
+                }
+                const double zv = y / 3.0;
+                if (owns_first) { t[0][0] = -(zv * zv + LOG2PI) / 2.0 - log3; t[1][0] = -(y / 9.0); }
+                v4[1] = (t[0][0] + t[0][1]) + (t[0][2] + t[0][3]);
+                v4[2] = (t[1][0] + t[1][1]) + (t[1][2] + t[1][3]);
+            }
+            wave_sum_packed4<4>(v4, mine);
+            funnel_gradient_elementwise(x, zi, sigma, rinv, sok, g);
+        }
+#else
         partial_sqr2(x, q, mine[0], mine[3]);
         {
             double zi[EW];
@@ -509,6 +547,7 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
             }
             funnel_gradient_elementwise(x, zi, sigma, rinv, sok, g);
         }
+#endif
         exchange(mine, out);
         const double S = out[0], l2 = out[1];
         Q = out[3];
@@ -719,6 +758,7 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
             return true;
         }
     };
+    double *gk_row = (TGT == TGT_FUNNEL && PTE_MW_KEEP_GK) ? e.mw_gk + ((int64_t)cl * NWV + w) * (64 * EW) : nullptr;      // this wave's 256 words of the kept trial's conditioned gradient
     double lpk = 0.0, kek = 0.0, gk_first = 0.0; bool okk = true;   // the kept trial's scalars (gk_first: its conditioned gradient's first entry, per lane); its vectors: L.v[MW_XK], L.v[MW_PK]
     // auto_step_size (AutoMALA.jl:184-214) as ONE loop with one trial leapfrog in it (mode 0: the first trial at the current step size; 1: halving
     // until the joint's change rises above `lower`; 2: doubling until it falls below `upper` or stops being finite) -- the sequence of trials,
@@ -742,6 +782,10 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
 #pragma unroll
                 for (int j = 0; j < EW; ++j) { L.v[MW_XK][gidx(j)] = x[j]; L.v[MW_PK][gidx(j)] = p[j]; }
                 gk_first = g[0];
+                if constexpr (TGT == TGT_FUNNEL && PTE_MW_KEEP_GK) {      // ... and its conditioned gradient (8 KB per replica: no room beside the four LDS rows; it stays in the L2)
+                    double2 *gk = reinterpret_cast<double2 *>(gk_row + 4 * lane);
+                    gk[0] = make_double2(g[0], g[1]); gk[1] = make_double2(g[2], g[3]);
+                }
                 lpk = t_lp; kek = t_ke; okk = t_ok;
             }
             if (mode == 0) {
@@ -834,7 +878,11 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
 #pragma unroll
                 for (int j = 0; j < EW; ++j) { x[j] = L.v[MW_XK][gidx(j)]; p[j] = L.v[MW_PK][gidx(j)]; }
                 lp0 = lpk;                                   // log density at the proposed point: the leapfrog computed it
-                conditioned_gradient_again(g0, gk_first);
+                if constexpr (TGT == TGT_FUNNEL && PTE_MW_KEEP_GK) {      // the funnel's evaluation is ~450 instructions and a barrier: read the bits back instead (0.8 of a trial leapfrog per refresh)
+                    const double2 *gk = reinterpret_cast<const double2 *>(gk_row + 4 * lane);
+                    const double2 a = gk[0], b = gk[1];
+                    g0[0] = a.x; g0[1] = a.y; g0[2] = b.x; g0[3] = b.y;
+                } else conditioned_gradient_again(g0, gk_first);
                 MW_STAMP(4);
                 if (!ap.use_mh) break;                       // no MH step: the chain stays where the proposal leapfrog ended
 #pragma unroll

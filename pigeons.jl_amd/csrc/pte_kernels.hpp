@@ -65,6 +65,7 @@ struct EngineDev {
     int compose_phase; double *lp_stash;                   // Compose(first, second): 0 single explorer, 1 first, 2 second kernel of the scan; [K] lp before the first
     int32_t *index_process;                                // [scan][slot]
     int32_t *error;                                        // [4] code, chain, coordinate, spare
+    double *mw_gk;                                         // null, or [K][1024]: k_explore_langevin_mw on the funnel path keeps the kept trial's conditioned gradient here (each lane reads back what it wrote)
     unsigned int *pace;                                    // [1] refreshes begun by the workgroups of the running k_explore_langevin_mw launch (zeroed before it): wave priority by pace
     uint32_t record_flags;
     int32_t target;
