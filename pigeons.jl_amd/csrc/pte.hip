@@ -514,7 +514,9 @@ int fused_kind(const pte_engine *h) {
     if ((h->cfg.explorer == PTE_EXPLORER_AUTOMALA || h->cfg.explorer == PTE_EXPLORER_MALA) &&
         (h->cfg.target == PTE_TARGET_MVN_SCALED_PRECISION || h->cfg.target == PTE_TARGET_FUNNEL)) {
         if (h->d > 512) {      // four waves per chain: the scaled-precision MVN path only (the funnel's loop measured no gain: pte_langevin_launch.hpp)
+#ifndef PTE_DEV_MW_FUNNEL_LOOP
             if (h->cfg.target != PTE_TARGET_MVN_SCALED_PRECISION) return 0;
+#endif
             if (h->cfg.debug_kernel & PTE_KERNEL_TEST_LANGEVIN_ONE_WAVE) return 0;                 // (test build: the one-wave kernel with sixteen blocks per lane has no loop form)
         }
         return h->d <= PTE_FUSED_LANGEVIN_MAX_D ? 2 : 0;

@@ -45,10 +45,18 @@ static inline void langevin_launch_scans_mw(K kernel, const LangevinLaunch &L, c
 }
 // (the scaled-precision MVN path only: on the funnel path the loop measured 1.905 ms per scan against 1.875-1.90 of the per-scan launches -- its
 // body as a called function is 7 % slower than inlined, which eats what the loop gains; profiles/r06_langevin_mw.txt -- and is not instantiated)
+#ifdef PTE_DEV_MW_FUNNEL_LOOP    // development builds only: the funnel's loop, to measure it again
+#define AM_SCANS_MW(WHAT)                                                                                                        \
+    if (target == TGT_FUNNEL && full) { WHAT((k_scans_langevin_mw<TGT_FUNNEL, true>)); }                                         \
+    else if (target == TGT_FUNNEL) { WHAT((k_scans_langevin_mw<TGT_FUNNEL, false>)); }                                           \
+    else if (full) { WHAT((k_scans_langevin_mw<TGT_MVN, true>)); }                                                               \
+    else { WHAT((k_scans_langevin_mw<TGT_MVN, false>)); }
+#else
 #define AM_SCANS_MW(WHAT)                                                                                                        \
     if (target == TGT_FUNNEL) { return MW_NO_FUNNEL_LOOP; }                                                                      \
     else if (full) { WHAT((k_scans_langevin_mw<TGT_MVN, true>)); }                                                               \
     else { WHAT((k_scans_langevin_mw<TGT_MVN, false>)); }
+#endif
 
 int langevin_scan_wg() { return PTE_SCAN_WG; }
 int langevin_scan_loop_blocks_per_cu(int E, int target, bool full, int scan_wg) {

@@ -28,11 +28,11 @@ for scan in range(6):
     assert L.pte_debug_wave_profile(e.h, out.ctypes.data_as(C.POINTER(C.c_double))) == 0
     acc.append(out.reshape(N, 12)[1:])
 o = np.mean(acc[1:], axis=0)
-tot = o[:, :7].sum(axis=1); nref = int(o[0, 11]) % 4096; leaps = o[:, 9]
+tot = o[:, :7].sum(axis=1); nref = int(acc[-1][0, 11]) % 4096; leaps = o[:, 9]
 print("%s(%d) N = %d k_explore_langevin_mw: n_refresh %d; per replica and scan %.0f ticks in the loop = %.1f us (100 MHz clock): %.1f ticks per us" % (path, d, N, nref, tot.mean(), o[:, 8].mean() / 100.0, tot.mean() / (o[:, 8].mean() / 100.0)))
 for k in range(7):
     print("  %-48s %9.0f ticks  %5.1f %%   per refresh %7.0f" % (names[k], o[:, k].mean(), 100.0 * o[:, k].mean() / tot.mean(), o[:, k].mean() / nref))
-print("  of which: fixed-tree sums inside the wave %.0f ticks (%.1f %%), exchange + barrier %.0f ticks (%.1f %%)" % (o[:, 7].mean(), 100 * o[:, 7].mean() / tot.mean(), o[:, 10].mean(), 100 * o[:, 10].mean() / tot.mean()))
+print("  of which: waiting at exchanges / barriers (wave 0) %.0f ticks (%.1f %%)" % (o[:, 10].mean(), 100 * o[:, 10].mean() / tot.mean()))
 st = acc[-1][:, 7] / 100.0; en = st + acc[-1][:, 8] / 100.0; t0 = st.min()
 print("last scan, us after the first workgroup's start: starts p10 / p50 / p90 / max %.0f %.0f %.0f %.0f; ends p10 / p50 / p90 / max %.0f %.0f %.0f %.0f; a replica's loop: mean %.0f us" % (
       *np.percentile(st - t0, [10, 50, 90, 100]), *np.percentile(en - t0, [10, 50, 90, 100]), (en - st).mean()))
