@@ -972,12 +972,16 @@ constexpr size_t mw_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr size_t MW_KERNARG_AP = mw_align_up(sizeof(EngineDev), alignof(AmParams));                                         // k_*_langevin_mw(EngineDev, AmParams[, ScanLoop])
 constexpr size_t MW_KERNARG_END_EXPLORE = mw_align_up(MW_KERNARG_AP + sizeof(AmParams), 8);
 constexpr size_t MW_KERNARG_END_SCANS = mw_align_up(mw_align_up(MW_KERNARG_AP + sizeof(AmParams), alignof(ScanLoop)) + sizeof(ScanLoop), 8);
+__device__ __forceinline__ int mw_kernarg_check(const EngineDev &e, const AmParams &ap) { return (int)e.K * 31 + (int)e.d * 7 + ap.n_refresh; }
 template <int TGT, bool FULL, bool SCANS>
 __device__ __attribute__((noinline))        // (amdgpu_waves_per_eu is a kernel attribute; the AMDGPU attributor hands the caller's bound down to this function)
-void langevin_mw_body_called(const int trace_idx_lo, const int trace_idx_hi, const int use_mh, const int pace_base) {
+void langevin_mw_body_called(const int trace_idx_lo, const int trace_idx_hi, const int use_mh, const int pace_base, const int check) {
     const MwKernargP ka = (MwKernargP)__builtin_amdgcn_implicitarg_ptr() - (SCANS ? MW_KERNARG_END_SCANS : MW_KERNARG_END_EXPLORE);
     EngineDev e = *(const EngineDev *)ka;                               // (cast to generic for the copy constructor's sake: InferAddressSpaces takes the loads back to address space 4)
     AmParams ap = *(const AmParams *)(ka + MW_KERNARG_AP);
+    // the layout this relies on (implicit arguments right behind the explicit ones) is the code-object ABI's, not the language's: should a toolchain ever
+    // move them, the words read here are not the caller's -- stop the launch (hipErrorLaunchFailure) instead of running on them
+    if (mw_kernarg_check(e, ap) != __builtin_amdgcn_readfirstlane(check)) __builtin_trap();
     e.trace_idx = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(trace_idx_hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(trace_idx_lo));
     ap.use_mh = __builtin_amdgcn_readfirstlane(use_mh);
     langevin_mw_body<TGT, FULL, !SCANS || PTE_MW_PACE_SCANS>(e, ap, blockIdx.x, __builtin_amdgcn_readfirstlane(pace_base));
@@ -988,7 +992,7 @@ __global__ __launch_bounds__(64 * MW_NWV)
 __attribute__((amdgpu_waves_per_eu(TGT == TGT_FUNNEL ? PTE_MW_OCC_FUNNEL : PTE_MW_OCC, TGT == TGT_FUNNEL ? PTE_MW_OCC_FUNNEL : PTE_MW_OCC)))
 void k_explore_langevin_mw(EngineDev e, AmParams ap) {
 #ifdef PTE_MW_EXPLORE_CALLED               // development builds only: what the call costs the per-scan kernel
-    langevin_mw_body_called<TGT, FULL, false>((int)(uint32_t)e.trace_idx, (int)(uint32_t)((uint64_t)e.trace_idx >> 32), ap.use_mh, 0);
+    langevin_mw_body_called<TGT, FULL, false>((int)(uint32_t)e.trace_idx, (int)(uint32_t)((uint64_t)e.trace_idx >> 32), ap.use_mh, 0, mw_kernarg_check(e, ap));
 #else
     langevin_mw_body<TGT, FULL, true>(e, ap, blockIdx.x);
 #endif
@@ -1015,7 +1019,7 @@ void k_scans_langevin_mw(EngineDev e, AmParams ap, ScanLoop sl) {
     for (int64_t i = 0; i < sl.n_scans; ++i) {
         e.trace_idx = sl.scan_idx0 + i;
         if (!ap.mala) ap.use_mh = (sl.first_scan + i != 1) ? 1 : 0;
-        langevin_mw_body_called<TGT, FULL, true>((int)(uint32_t)e.trace_idx, (int)(uint32_t)((uint64_t)e.trace_idx >> 32), ap.use_mh, (int)i * ap.n_refresh);
+        langevin_mw_body_called<TGT, FULL, true>((int)(uint32_t)e.trace_idx, (int)(uint32_t)((uint64_t)e.trace_idx >> 32), ap.use_mh, (int)i * ap.n_refresh, mw_kernarg_check(e, ap));
         __syncthreads();                                               // every thread's stores of the explore step happen before thread 0's release
         if (threadIdx.x == 0) {
 #if PTE_MW_PRIO
