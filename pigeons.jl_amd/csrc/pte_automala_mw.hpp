@@ -73,7 +73,32 @@ using MwLdsP = __attribute__((address_space(3))) MwLds *;
 // ---- cold paths as CALLED functions: the code a refresh walks through stays small (the kernel's instruction footprint, not its arithmetic, is
 // what a lone wave per SIMD waits for) and the register allocation of the hot path is not bent around them
 __device__ __attribute__((noinline)) double mw_div_exact(double a, double b) { return a / b; }
+// The funnel's scale (wave 0, once per evaluation) as a called function too, though it is anything but cold: inlined into the trial loop, the ~20 polynomial
+// coefficients of exp and log (they initialise the accumulators of the Horner steps, so they must sit in vector registers) are hoisted out of the loop as
+// loop invariants, spilled, and read back from SCRATCH one by one, each behind its own s_waitcnt -- 17 exposed memory round trips per trial leapfrog on
+// the path the other three waves wait for at the barrier.  Called, the constants are materialised where they are used.
+struct MwScale3 { double sigma, logsigma, rinv; };
+__device__ __attribute__((noinline)) MwScale3 mw_funnel_scale_eval(double y) {
+    MwScale3 r;
+    r.sigma = exp(y / 2.0);
+    r.logsigma = log(r.sigma);
+    r.rinv = 1.0 / r.sigma;
+    return r;
+}
 __device__ __attribute__((noinline)) double mw_exp_exact(double t) { return exp(t); }
+// (the refresh level's exp / log -- the acceptance ratio, the two bounds of the search -- for the same reason as mw_funnel_scale_eval: inlined, their
+// coefficients are loop invariants of the refresh loop: six vector registers held for the whole kernel and 6 + 19 reads from scratch per refresh)
+__device__ __attribute__((noinline)) double mw_log_exact(double t) { return log(t); }
+#ifndef PTE_MW_REFRESH_MATH_CALLED
+#define PTE_MW_REFRESH_MATH_CALLED 1
+#endif
+#if PTE_MW_REFRESH_MATH_CALLED
+#define MW_EXP(x) mw_exp_exact(x)
+#define MW_LOG(x) mw_log_exact(x)
+#else
+#define MW_EXP(x) exp(x)
+#define MW_LOG(x) log(x)
+#endif
 // tail of the normal ziggurat (Random/src/normal.jl randn_unlikely, idx == 0) for the two lanes of an event's pair, exactly, at stream position zt:
 // trial k takes the draws 2k - 1 (-> xx) and 2k (-> yy) behind the event; the even lane evaluates the first, the odd lane the second.  Returns xx; *pairs_out = trials
 __device__ __attribute__((noinline)) double mw_tail_event(uint64_t zt, const uint64_t gamma, const int role, const bool tail_log1p, const int max_pairs, int *pairs_out) {
@@ -287,6 +312,9 @@ __device__ __forceinline__ uint64_t mw_draw_momentum(const MwLdsP L, const uint6
 #ifndef PTE_MW_KEEP_GK
 #define PTE_MW_KEEP_GK 1
 #endif
+#ifndef PTE_MW_SCALE_CALLED
+#define PTE_MW_SCALE_CALLED 1
+#endif
 #ifndef PTE_MW_PACKED_SUMS
 #define PTE_MW_PACKED_SUMS 0            // development builds: wave_sum_packed4 for the leapfrog's three / four sums (32 fewer instructions, a longer dependent chain): funnel(1024)
 #endif                                  // 1.593 -> 1.585, toy_mvn(1024) -1 %, toy_mvn(600) +10 % (0.447 -> 0.494) -- not taken
@@ -425,9 +453,14 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
         MW_X0();
         if (w == 0) {
             const double y = U(x[0]);                                 // (lane 0 is the first lane: coordinate 0)
+#if PTE_MW_SCALE_CALLED
+            const MwScale3 sc = mw_funnel_scale_eval(y);
+            const double sigma = sc.sigma, logsigma = sc.logsigma, rinv = sc.rinv;
+#else
             const double sigma = exp(y / 2.0);
             const double logsigma = log(sigma);
             const double rinv = 1.0 / sigma;
+#endif
             if (lane == 0) { L.ybuf[ypar][0] = y; L.ybuf[ypar][1] = sigma; L.ybuf[ypar][2] = logsigma; L.ybuf[ypar][3] = rinv; }
         }
         __syncthreads();
@@ -844,7 +877,7 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
             leap_frog(ap.step_size, MW_XS, pb, lpn, ken);
 #pragma unroll
             for (int j = 0; j < EW; ++j) p[j] = p[j] * -1.0;
-            const double ex = exp((lpn - ken) - init_joint);
+            const double ex = MW_EXP((lpn - ken) - init_joint);
             const double probability = ex < 1.0 ? ex : (isnan(ex) ? ex : 1.0);
             acc_sum = U(acc_sum + probability); acc_n += 1;
             if (!(r.rand() < probability)) {
@@ -862,7 +895,7 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
         // wave-uniform arithmetic -- by wave 0 alone, published before the first trial leapfrog's exchange and read by everybody behind its barrier
         const double ua = r.rand(), ub = r.rand();
         if (w == 0) {
-            const double lo_ = log(ua < ub ? ua : ub), hi_ = log(ua < ub ? ub : ua);
+            const double lo_ = MW_LOG(ua < ub ? ua : ub), hi_ = MW_LOG(ua < ub ? ub : ua);
             if (lane == 0) { L.bounds[0] = lo_; L.bounds[1] = hi_; }
         }
         double lower = 0.0, upper = 0.0;                 // (set by the forward search behind its first exchange)
@@ -899,7 +932,7 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
             rev_sum += passed ? 1 : 0; rev_n += 1;
             double probability = 0.0;
             if (passed) {
-                const double ex = exp(h_rev - init_joint);      // final_joint_log == log_joint at the proposed point
+                const double ex = MW_EXP(h_rev - init_joint);   // final_joint_log == log_joint at the proposed point
                 probability = ex < 1.0 ? ex : (isnan(ex) ? ex : 1.0);
             }
             acc_sum = U(acc_sum + probability); acc_n += 1;

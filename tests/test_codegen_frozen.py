@@ -176,7 +176,13 @@ def test_langevin_mw_kernels(cg):
         assert ctrial[0]["scratch"] <= (0 if full == "true" else 2) and ctrial[0]["w"] == 0 and ctrial[0]["r"] <= 2 and ctrial[0]["v"] <= 320 and ctrial[0]["s"] <= 170, (full, ctrial[0])
         assert sum("flat_load" in l for l in cbody) == 0 and sum("s_load_dword" in l for l in cbody) >= 20, cname     # the engine's fields: scalar loads from the constant address space
         f = res["k_explore_langevin_mw<2, %s>" % full]
-        assert f["vgpr"] <= 128 and f["waves_per_simd"] == 4 and f["lds_B"] <= 40960 and f["spilled_vgpr"] <= 200, f
+        assert f["vgpr"] <= 128 and f["waves_per_simd"] == 4 and f["lds_B"] <= 40960 and f["spilled_vgpr"] <= 100, f
+        # the funnel's trial loop: its exp / log / reciprocal (wave 0's funnel_scale) are a CALLED function -- inlined, their ~20 polynomial coefficients are hoisted out
+        # of the loop, spilled and read back from scratch one by one behind an s_waitcnt each: 17 exposed round trips per trial, 1.60 instead of 1.20 ms per scan
+        fname, fbody = C.kernel_body(lines, "k_explore_langevin_mwILi2ELb%dE" % (1 if full == "true" else 0))
+        ftrial = [L for k, L in C.loops(fbody).items() if k[0] >= 2 and L["l"] >= 20 and 500 <= L["v"] <= 760]
+        assert len(ftrial) == 1, C.loops(fbody)
+        assert ftrial[0]["scratch"] <= 6 and ftrial[0]["w"] <= 2, (full, ftrial[0])
     # the one-wave kernels with sixteen blocks per lane are gone from the product build (their SliceSampler instantiation, which does not spill, stays)
     assert [k for k in res if k.startswith("k_explore_automala<16,")] == ["k_explore_automala<16, 2, true, false>"]
     s16 = res["k_explore_automala<16, 2, true, false>"]
