@@ -1065,29 +1065,51 @@ static int reference_reduce(pte_engine *h, Snapshot &s) {
         const int cap = h->dev.am_log_cap;
         std::vector<int16_t> al((size_t)(T * K * cap));
         HIP_OK(h, hipMemcpy(al.data(), h->dev.am_log, sizeof(int16_t) * al.size(), hipMemcpyDeviceToHost));
+        // reversibility_rate (AutoMALA.jl:294: one fit of `reversed exponent == proposed exponent` per refresh with an MH step) comes out of the same log:
+        // a refresh logs its forward search, then -- scan != 1 -- its reversed one, so a scan's row holds n_refresh entries (no MH step) or n_refresh PAIRS.
+        // Nothing adapts on it; replayed so that it EQUALS the reference's number too instead of sitting 1e-16 away.
         struct Mn { double mu; int64_t n; };
-        std::vector<Mn> mn((size_t)N);
-        for (int64_t c = 0; c < K; ++c) {
-            for (auto &r : mn) r = Mn{0.0, 0};
-            for (int64_t t = 0; t < T; ++t) {
-                Mn &r = mn[(size_t)holder[(size_t)(t * K + c)]];
-                const int16_t *a = &al[(size_t)((t * K + c) * cap)];
-                for (int j = 0; j < cap && a[j] != (int16_t)0x7F7F; ++j) {
-                    r.n += 1;
-                    r.mu = r.mu + (1.0 / (double)r.n) * (std::ldexp(1.0, (int)a[j]) - r.mu);
-                }
-            }
+        std::vector<Mn> mn((size_t)N), rv((size_t)N);
+        auto merge = [&](std::vector<Mn> &v) {
             for (int64_t sp = 1; sp < N; sp *= 2)
                 for (int64_t i = 0; i + sp < N; i += 2 * sp) {
-                    Mn &a = mn[(size_t)i]; const Mn &b = mn[(size_t)(i + sp)];
+                    Mn &a = v[(size_t)i]; const Mn &b = v[(size_t)(i + sp)];
                     if (b.n == 0) continue;
                     if (a.n == 0) { a = b; continue; }
                     a.n += b.n;
                     a.mu = a.mu + ((double)b.n / (double)a.n) * (b.mu - a.mu);
                 }
+        };
+        const int nref = h->am_n_refresh;
+        for (int64_t c = 0; c < K; ++c) {
+            for (auto &r : mn) r = Mn{0.0, 0};
+            for (auto &r : rv) r = Mn{0.0, 0};
+            bool pairs_ok = true;
+            for (int64_t t = 0; t < T; ++t) {
+                Mn &r = mn[(size_t)holder[(size_t)(t * K + c)]];
+                const int16_t *a = &al[(size_t)((t * K + c) * cap)];
+                int m = 0;
+                for (int j = 0; j < cap && a[j] != (int16_t)0x7F7F; ++j) {
+                    r.n += 1;
+                    r.mu = r.mu + (1.0 / (double)r.n) * (std::ldexp(1.0, (int)a[j]) - r.mu);
+                    m += 1;
+                }
+                if (m == 2 * nref) {
+                    Mn &q = rv[(size_t)holder[(size_t)(t * K + c)]];
+                    for (int j = 0; j < m; j += 2) {
+                        q.n += 1;
+                        q.mu = q.mu + (1.0 / (double)q.n) * ((a[j] == a[j + 1] ? 1.0 : 0.0) - q.mu);
+                    }
+                } else if (m != nref && m != 0) pairs_ok = false;           // (a search that failed mid-refresh: the call has reported it; leave the device's sums)
+            }
+            merge(mn);
             if (mn[0].n != h->fac_n[(size_t)c])
                 return fail(h, "PTE_RECORD_REFERENCE_REDUCTION: the log holds %lld step-size searches of chain %lld, the device counted %lld", (long long)mn[0].n, (long long)(c0 + c), (long long)h->fac_n[(size_t)c]);
             if (mn[0].n > 0) h->fac_mean[(size_t)c] = mn[0].mu;
+            if (pairs_ok && h->cfg.explorer2 == PTE_EXPLORER_NONE) {
+                merge(rv);
+                if (rv[0].n == h->rev_n[(size_t)c] && rv[0].n > 0) h->rev_mean[(size_t)c] = rv[0].mu;
+            }
         }
     }
     // :online / :_transformed_online the same way, when the round's traces are there to replay them from (PTE_RECORD_TRACES: the target

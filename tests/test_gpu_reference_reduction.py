@@ -179,6 +179,8 @@ def test_automala_on_the_mvn_path_equals_the_oracle_bit_for_bit(P, kind, N, d, r
         assert np.array_equal(red.online[0], ref.online()[0]) and np.array_equal(red.online[1], ref.online()[1])
         fm, fn, rm, rn = ref.automala_stats()
         assert np.array_equal(red.am_factors[1], fn) and np.array_equal(red.am_factors[0], fm)
+        if kind in ("automala", "sharded"):            # reversibility_rate (AutoMALA.jl:294) out of the same log: EQUAL too (round 6; nothing adapts on it)
+            assert np.array_equal(red.reversibility_rate[1], rn) and np.array_equal(red.reversibility_rate[0], rm), (red.reversibility_rate[0] - rm)
         x, chain, rng = (pt.shards if pt.shards is not None else pt.replicas).states(); xr, cr, rr = ref.states()
         assert np.array_equal(chain, cr) and np.array_equal(rng, rr) and np.array_equal(x, xr)
 
