@@ -76,7 +76,9 @@ enum {                                   /* Inputs.record (src/pt/Inputs.jl:57-6
                                               * is the reference's to the last bit instead of to 1e-11.  Needs PTE_RECORD_INDEX_PROCESS (who held the lower chain).  A
                                               * chain-shard replays the pairs whose lower chain it owns (log and index rows are local; the tree runs over the global
                                               * replica index).  With PTE_RECORD_TRACES the online statistics are rebuilt the same way, and AutoMALA's am_factors (the
-                                              * exponent of every step-size search is logged: the step size adapts on their mean) always.  Off by default: the values agree to ~1e-12 either way, and a round of 1024 x 1024 chain-scans logs 16 MB. */
+                                              * exponent of every step-size search is logged: the step size adapts on their mean) always, with its reversibility_rate (the same log).
+                                              * With PTE_RECORD_ENERGY_AC1 the pair of log densities around every explore step is logged too (by a launch of its own before and
+                                              * after the explorer kernels: such an engine runs the launch-per-scan loop) and energy_ac1's correlation replayed.  Off by default: the values agree to ~1e-12 either way, and a round of 1024 x 1024 chain-scans logs 16 MB. */
 };
 
 enum {                                   /* pte_config.debug_kernel: which kernel generation explores (0 = the default)   */

@@ -246,6 +246,7 @@ int reset_recorders(pte_engine *h) {
     HIP_OK(h, hipMemsetAsync(e.on_n, 0, 2 * sizeof(int64_t), h->stream));
     if (e.am_log)       // 0x7f7f = "no search here"
         HIP_OK(h, hipMemsetAsync(e.am_log, 0x7F, sizeof(int16_t) * (size_t)(h->cfg.max_scans_per_round * h->K * e.am_log_cap), h->stream));
+    if (e.eac_log) HIP_OK(h, hipMemsetAsync(e.eac_log, 0xFF, sizeof(double) * 2 * (size_t)(h->cfg.max_scans_per_round * h->K), h->stream));      // all-ones = "no explore step recorded here"
     if (e.swap_log)     // all-ones words = "this pair was idle at this scan" (no log ratio has that bit pattern: a NaN ratio is ERR_NAN_RATIO)
         HIP_OK(h, hipMemsetAsync(e.swap_log, 0xFF, sizeof(double) * 2 * (size_t)(h->cfg.max_scans_per_round * h->K), h->stream));
     HIP_OK(h, hipStreamSynchronize(h->stream));   // `ninf` must outlive the copies
@@ -335,7 +336,24 @@ int launch_explore(pte_engine *h, int64_t scan) {
     if (h->dev.am_log && h->scans_in_round >= h->cfg.max_scans_per_round)
         return fail(h, "step-size-search log full: %lld scans since the last pte_reduce (max_scans_per_round = %lld)",
                     (long long)h->scans_in_round, (long long)h->cfg.max_scans_per_round);
+    if (h->dev.eac_log && h->scans_in_round >= h->cfg.max_scans_per_round)
+        return fail(h, "energy log full: %lld scans since the last pte_reduce (max_scans_per_round = %lld)",
+                    (long long)h->scans_in_round, (long long)h->cfg.max_scans_per_round);
     h->dev.trace_idx = h->scans_in_round;
+    if (h->dev.eac_log && h->cfg.explorer != PTE_EXPLORER_NONE) {            // the energy pairs of the scan, logged around its explorer kernel(s) (k_log_energy)
+        hipLaunchKernelGGL(k_log_energy, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->dev, 0);
+        int rc;
+        if (h->cfg.explorer2 == PTE_EXPLORER_NONE) { h->dev.compose_phase = 0; rc = launch_explorer_kind(h, scan, h->cfg.explorer); }
+        else {
+            h->dev.compose_phase = 1; rc = launch_explorer_kind(h, scan, h->cfg.explorer);
+            if (!rc) { h->dev.compose_phase = 2; rc = launch_explorer_kind(h, scan, h->cfg.explorer2); }
+            h->dev.compose_phase = 0;
+        }
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_log_energy, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->dev, 1);
+        HIP_OK(h, hipGetLastError());
+        return 0;
+    }
     if (h->cfg.explorer2 == PTE_EXPLORER_NONE) { h->dev.compose_phase = 0; return launch_explorer_kind(h, scan, h->cfg.explorer); }
     // Compose(first, second), src/explorers/Compose.jl:16-19: two kernels back to back on the replica's stream
     h->dev.compose_phase = 1;
@@ -529,6 +547,7 @@ bool fused_scans_eligible(pte_engine *h, int64_t n_scans) {
     if (!h->fused_allowed || h->world != 1 || n_scans < 1) return false;
     const int kind = fused_kind(h);
     if (kind == 0) return false;
+    if (h->dev.eac_log) return false;          // the energy pairs are logged by launches around the explorer kernels (k_log_energy)
     // a recorder buffer that would overflow inside the call: the launch-per-scan loop reports it at the scan that overflows, as before
     if (((h->cfg.record_flags & (PTE_RECORD_TRACES | PTE_RECORD_INDEX_PROCESS | PTE_RECORD_REFERENCE_REDUCTION)) || h->dev.am_log || h->dev.swap_log) &&
         h->scans_in_round + n_scans > h->cfg.max_scans_per_round) return false;
@@ -822,8 +841,9 @@ int pte_create(const pte_config *cfg, pte_engine **out) {
     rc |= dev_alloc(h, &e.pace, 2);
     e.mw_gk = nullptr;
     if (funnel && uses_grad && d > 512) rc |= dev_alloc(h, &e.mw_gk, (size_t)K * 1024, false);
-    e.swap_log = nullptr;
+    e.swap_log = nullptr; e.eac_log = nullptr;
     if (cfg->record_flags & PTE_RECORD_REFERENCE_REDUCTION) rc |= dev_alloc(h, &e.swap_log, (size_t)(cfg->max_scans_per_round * K * 2), false);
+    if ((cfg->record_flags & PTE_RECORD_REFERENCE_REDUCTION) && (cfg->record_flags & PTE_RECORD_ENERGY_AC1)) rc |= dev_alloc(h, &e.eac_log, (size_t)(cfg->max_scans_per_round * K * 2), false);
     e.am_log = nullptr; e.am_log_cap = 0;
     if ((cfg->record_flags & PTE_RECORD_REFERENCE_REDUCTION) && (cfg->explorer == PTE_EXPLORER_AUTOMALA || cfg->explorer2 == PTE_EXPLORER_AUTOMALA)) {
         // AutoMALA searches a step size twice per refresh at most (forward, and backward for the reversibility check): am_factors' fits
@@ -1109,6 +1129,47 @@ static int reference_reduce(pte_engine *h, Snapshot &s) {
             if (pairs_ok && h->cfg.explorer2 == PTE_EXPLORER_NONE) {
                 merge(rv);
                 if (rv[0].n == h->rev_n[(size_t)c] && rv[0].n > 0) h->rev_mean[(size_t)c] = rv[0].mu;
+            }
+        }
+    }
+    // energy_ac1 (recorder.jl:113: GroupBy(Int, CovMatrix(2)) fitted with (log density before, after) the explore step, src/pt/pigeons.jl:133-143) the same way:
+    // OnlineStats' CovMatrix keeps b = mean and A = mean of x x' with a += (1/n)(x - a), merges with n_b / n, value = (A - b b') n / (n - 1), cor = D^-1/2 value D^-1/2.
+    // The device's chain-keyed Welford co-moments (pte_get_energy_ac1's `moments`) stay what they are; `cor` -- what energy_ac1s reports -- becomes the reference's number.
+    if (h->dev.eac_log) {
+        std::vector<double> el((size_t)(T * K * 2));
+        HIP_OK(h, hipMemcpy(el.data(), h->dev.eac_log, sizeof(double) * el.size(), hipMemcpyDeviceToHost));
+        struct Cv { int64_t n; double b[2], A[3]; };
+        std::vector<Cv> cv((size_t)N);
+        for (int64_t c = 0; c < K; ++c) {
+            for (auto &r : cv) r = Cv{0, {0.0, 0.0}, {0.0, 0.0, 0.0}};
+            for (int64_t t = 0; t < T; ++t) {
+                const double *w = &el[(size_t)((t * K + c) * 2)];
+                uint64_t bits; std::memcpy(&bits, w, 8);
+                if (bits == ~0ull) continue;
+                Cv &o = cv[(size_t)holder[(size_t)(t * K + c)]];
+                o.n += 1;
+                const double g = 1.0 / (double)o.n, x0 = w[0], x1 = w[1];
+                o.b[0] += g * (x0 - o.b[0]); o.b[1] += g * (x1 - o.b[1]);
+                o.A[0] += g * (x0 * x0 - o.A[0]); o.A[1] += g * (x0 * x1 - o.A[1]); o.A[2] += g * (x1 * x1 - o.A[2]);
+            }
+            for (int64_t sp = 1; sp < N; sp *= 2)
+                for (int64_t i = 0; i + sp < N; i += 2 * sp) {
+                    Cv &a = cv[(size_t)i]; const Cv &b = cv[(size_t)(i + sp)];
+                    if (b.n == 0) continue;
+                    if (a.n == 0) { a = b; continue; }
+                    a.n += b.n;
+                    const double g = (double)b.n / (double)a.n;
+                    for (int k = 0; k < 3; ++k) a.A[k] += g * (b.A[k] - a.A[k]);
+                    for (int k = 0; k < 2; ++k) a.b[k] += g * (b.b[k] - a.b[k]);
+                }
+            const Cv &o = cv[0];
+            if (o.n != s.eac_n[(size_t)c])
+                return fail(h, "PTE_RECORD_REFERENCE_REDUCTION: the log holds %lld explore steps of chain %lld, the device counted %lld", (long long)o.n, (long long)(c0 + c), (long long)s.eac_n[(size_t)c]);
+            if (o.n > 1) {
+                const double bes = (double)o.n / (double)(o.n - 1);
+                const double c00 = (o.A[0] - o.b[0] * o.b[0]) * bes, c01 = (o.A[1] - o.b[0] * o.b[1]) * bes, c11 = (o.A[2] - o.b[1] * o.b[1]) * bes;
+                const double v0 = 1.0 / std::sqrt(c00), v1 = 1.0 / std::sqrt(c11);
+                s.eac_cor[(size_t)c] = (c01 * v1) * v0;
             }
         }
     }

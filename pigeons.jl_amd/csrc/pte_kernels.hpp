@@ -53,6 +53,7 @@ struct EngineDev {
     double *expl_acc_sum; int64_t *expl_acc_n;             // [chain] explorer_acceptance_pr
     double *expl_steps_sum; int64_t *expl_steps_n;         // [chain] explorer_n_steps
     double *on_mean; double *on_m2; int64_t *on_n;         // [d+1],[d+1],[1] target-chain online stats of [state; log density]
+    double *eac_log;                                       // null, or [max_scans][K][2] {log density before, after} the explore step per scan and local chain (PTE_RECORD_REFERENCE_REDUCTION with energy_ac1): k_log_energy
     double *eac; int64_t *eac_n;                           // [5K],[K] energy_ac1: Welford (mean before, mean after, C_bb, C_ba, C_aa) per local chain
     double *traces; int64_t trace_idx;                     // [max_scans][d+1] target-chain [state; log density]; row of the current scan
     // StabilizedPT (two legs, src/tempering/StabilizedPT.jl): second reference chain (-1: one leg), the two target chains
@@ -176,6 +177,20 @@ __device__ __forceinline__ double lp_before_explore(const EngineDev &e, int64_t 
     if (e.compose_phase == 2) return e.lp_stash[c - e.c0];
     return chain_lp(e, c, e.suff[slot], e.suff2[slot], e.v_use ? e.suff3[slot] : 0.0);
 }
+// PTE_RECORD_REFERENCE_REDUCTION with energy_ac1: the pair (log density before, after explore!) of every chain and scan, logged by a launch of its own
+// before and after the scan's explorer kernel(s) -- the expressions of lp_before_explore / record_after_explore_impl on the statistics in memory, so the
+// same bits -- and replayed by pte_reduce with OnlineStats' CovMatrix arithmetic.  (Not written by the explorer kernels themselves: one more pointer and
+// store in their epilogues moved the register allocation of k_explore_toy -- 12 -> 28 B of scratch, +1.2 % -- for a diagnostic nobody adapts on.)
+#ifndef PTE_TU_LANGEVIN
+__global__ __launch_bounds__(256) void k_log_energy(EngineDev e, int which) {
+    const int64_t cl = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cl >= e.K) return;
+    const int64_t c = e.c0 + cl;
+    const int slot = e.slot_of_chain[cl];
+    e.eac_log[(e.trace_idx * e.K + cl) * 2 + which] = chain_lp(e, c, e.suff[slot], e.suff2[slot], e.v_use ? e.suff3[slot] : 0.0);
+}
+#endif
+
 __device__ __forceinline__ void record_after_explore_impl(const EngineDev &e, int64_t cl, int64_t c, int slot, int lane,
                                                           double lp_before, double S, double l2, double l3 = 0.0) {
     const unsigned f = e.record_flags;

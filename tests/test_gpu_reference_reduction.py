@@ -64,6 +64,28 @@ def test_recorders_and_schedule_equal_the_oracle_bit_for_bit(P, kind, N, d, roun
     assert np.array_equal(chain, cr) and np.array_equal(rng, rr)
 
 
+@pytest.mark.parametrize("kind,N,d,rounds,seed", [("slice", 6, 10, 8, 1), ("slice", 33, 7, 7, 4), ("toy", 16, 128, 7, 3), ("automala", 8, 64, 6, 2), ("compose", 6, 12, 6, 5)])
+def test_energy_ac1_equals_the_oracle_bit_for_bit(P, kind, N, d, rounds, seed):
+    """energy_ac1 (recorder.jl:113: CovMatrix(2) of the log density before / after explore!, src/pt/pigeons.jl:133-143) under the flag: the pair of every
+    chain and scan is logged by k_log_energy around the explorer kernels and replayed with OnlineStats' arithmetic per replica, merged over the replica
+    tree -- the correlation energy_ac1s reports EQUALS the oracle's (round 6, late).  Runs the launch-per-scan loop (the log is written between launches)."""
+    ex = {"toy": P.ToyExplorer(), "slice": P.SliceSampler(), "automala": P.AutoMALA(), "compose": P.Compose(P.AutoMALA(), P.SliceSampler())}[kind]
+    okw = {"toy": dict(explorer=O.EXPLORER_TOY), "slice": dict(explorer=O.EXPLORER_SLICE), "automala": dict(explorer=O.EXPLORER_AUTOMALA, am_preconditioner=2),
+           "compose": dict(explorer=O.EXPLORER_AUTOMALA, explorer2=O.EXPLORER_SLICE, am_preconditioner=2)}[kind]
+    langevin = kind in ("automala", "compose")
+    rec = [P.round_trip, P.index_process, P.log_sum_ratio, P.energy_ac1] + ([P.online, P.traces] if langevin else [])
+    pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=ex, seed=seed, record=rec, show_report=False), reference_reduction=True)
+    assert pt.replicas.scan_loop_name() == ""
+    ref = O.OraclePT(n_chains=N, dim=d, seed=seed, record_energy_ac1=1, **okw, **(dict(record_online=1, record_traces=1) if langevin else {}))
+    for _ in range(rounds):
+        red = _exact_round(P, pt, ref)
+        cor, cn, _ = red.energy_ac1
+        corr, cnr, _ = ref.energy_ac1()
+        assert np.array_equal(cn, cnr) and np.array_equal(cor, corr, equal_nan=True), np.nanmax(np.abs(cor - corr))
+    x, chain, rng = pt.replicas.states(); xr, cr, rr = ref.states()
+    assert np.array_equal(x, xr) and np.array_equal(chain, cr) and np.array_equal(rng, rr)
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(device_messages=True), dict(transport="group")])
 @pytest.mark.parametrize("kind,N,d,G,rounds", [("slice", 8, 40, 2, 7), ("slice", 12, 100, 4, 6), ("toy", 9, 5, 3, 8), ("slice", 16, 30, 8, 6), ("toy", 6, 3, 6, 7)])
 def test_chain_shards_replay_their_own_pairs(P, kind, N, d, G, rounds, kw):
@@ -71,10 +93,11 @@ def test_chain_shards_replay_their_own_pairs(P, kind, N, d, G, rounds, kw):
     needs; the merge tree runs over the GLOBAL replica index, so G shards give the oracle's numbers exactly like one engine does"""
     exp = {"toy": P.ToyExplorer(), "slice": P.SliceSampler()}[kind]
     pt = P.PT(P.Inputs(target=P.toy_mvn_target(d), n_chains=N, n_rounds=rounds, explorer=exp, seed=4, show_report=False,
-                       record=[P.round_trip, P.index_process, P.log_sum_ratio, P.online, P.traces]), n_shards=G, reference_reduction=True, **kw)
-    ref = O.OraclePT(n_chains=N, dim=d, seed=4, explorer={"toy": O.EXPLORER_TOY, "slice": O.EXPLORER_SLICE}[kind], record_online=1, record_traces=1)
+                       record=[P.round_trip, P.index_process, P.log_sum_ratio, P.online, P.traces, P.energy_ac1]), n_shards=G, reference_reduction=True, **kw)
+    ref = O.OraclePT(n_chains=N, dim=d, seed=4, explorer={"toy": O.EXPLORER_TOY, "slice": O.EXPLORER_SLICE}[kind], record_online=1, record_traces=1, record_energy_ac1=1)
     for _ in range(rounds):
         red = _exact_round(P, pt, ref)
+        assert np.array_equal(red.energy_ac1[1], ref.energy_ac1()[1]) and np.array_equal(red.energy_ac1[0], ref.energy_ac1()[0], equal_nan=True)
         if np.array_equal(red.traces, ref.traces()):
             assert np.array_equal(red.online[0], ref.online()[0]) and np.array_equal(red.online[1], ref.online()[1])
     assert pt.shards.n_boundary_swaps > 0
