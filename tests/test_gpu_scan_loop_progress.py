@@ -86,6 +86,37 @@ def test_two_engines_from_two_host_threads(P):
         assert not poisoned and fused + aborts >= 1, (fused, aborts)       # each of the 9 calls either ran as one launch or fell back after an abort
 
 
+def test_two_four_wave_scan_loops_from_two_host_threads(P):
+    """k_scans_langevin_mw takes EVERY workgroup slot of the device (1024 chains x 256 threads, four per compute unit): two such engines run concurrently
+    from two threads cannot both be resident -- one launch's gate finds workgroups missing, aborts with nothing written, and that call runs as explore + swap
+    launches.  Both runs equal their serial runs, nobody times out, nobody is poisoned."""
+    mk = lambda seed: _make(P, 1024, 600, seed, explorer=P.AutoMALA(), rounds=5)
+    serial = []
+    for seed in (1, 2):
+        pt = mk(seed)
+        assert pt.replicas.scan_loop_name() == "k_scans_langevin_mw"
+        serial.append(_rounds(P, pt, 5)); del pt
+    pts = [mk(seed) for seed in (1, 2)]
+    res, errs = [None, None], []
+
+    def work(i):
+        try:
+            res[i] = _rounds(P, pts[i], 5)
+        except Exception as exc:          # noqa: BLE001
+            errs.append((i, repr(exc)))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    t0 = time.time()
+    for t in th: t.start()
+    for t in th: t.join(120)
+    assert not any(t.is_alive() for t in th), "a scan loop hangs"
+    assert not errs, errs
+    assert time.time() - t0 < 60
+    for i in range(2):
+        _same(serial[i], res[i])
+        fused, aborts, poisoned = pts[i].replicas.scan_loop_stats()
+        assert not poisoned and fused + aborts >= 1, (fused, aborts)
+
+
 _CHILD = r"""
 import sys, hashlib, numpy as np
 sys.path[:0] = [%r, %r, %r]
