@@ -312,6 +312,9 @@ __device__ __forceinline__ uint64_t mw_draw_momentum(const MwLdsP L, const uint6
 #ifndef PTE_MW_KEEP_GK
 #define PTE_MW_KEEP_GK 1
 #endif
+#ifndef PTE_MW_BOUNDS_TWO_WAVES
+#define PTE_MW_BOUNDS_TWO_WAVES 1
+#endif
 #ifndef PTE_MW_SCALE_CALLED
 #define PTE_MW_SCALE_CALLED 1
 #endif
@@ -894,10 +897,17 @@ __device__ __forceinline__ void langevin_mw_body(const EngineDev &e, const AmPar
         // the bounds of the search: log of two uniforms (every wave draws them: the streams stay identical); the two logarithms -- ~250 instructions of
         // wave-uniform arithmetic -- by wave 0 alone, published before the first trial leapfrog's exchange and read by everybody behind its barrier
         const double ua = r.rand(), ub = r.rand();
+#if PTE_MW_BOUNDS_TWO_WAVES                          // ... one logarithm each by waves 0 and 1, side by side (the other two go ahead to the barrier)
+        if (w < 2) {
+            const double b_ = MW_LOG((w == 0) == (ua < ub) ? ua : ub);      // wave 0: the smaller uniform's, wave 1: the larger's
+            if (lane == 0) L.bounds[w] = b_;
+        }
+#else
         if (w == 0) {
             const double lo_ = MW_LOG(ua < ub ? ua : ub), hi_ = MW_LOG(ua < ub ? ub : ua);
             if (lane == 0) { L.bounds[0] = lo_; L.bounds[1] = hi_; }
         }
+#endif
         double lower = 0.0, upper = 0.0;                 // (set by the forward search behind its first exchange)
         MW_STAMP(2);
         // forward search from the start point, then (scan != 1) the reversed search from the proposed point: one copy of the search
